@@ -1,0 +1,307 @@
+/*
+ * umoe.h -- C-ABI of libumoe_hip.so, the MI355X (gfx950) implementation of the
+ * UniMoE-Audio hot path: DCMoE transformer forward + DAC-token decode loop.
+ *
+ * The reference (foggy-frost-forest/UniMoE-Audio) is 100% Python and has no FFI; this ABI
+ * is what the repo's Python host modules (unimoe_audio_amd/*.py, which mirror the reference
+ * module API) bind with ctypes.  Each entry point cites the reference code it replaces
+ * (paths relative to the reference root).  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (message: umoe_last_error()).
+ *   - pointers are DEVICE pointers unless named host_*; nothing is allocated or freed
+ *     behind the caller's back except inside umoe_engine_* (which owns its workspace).
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued, never synchronised.
+ *   - bf16 tensors are uint16_t bit patterns; "T" means bf16 when `*_bf16` is 1 else fp32.
+ *   - row-major everywhere; [S] tokens, [D] hidden, [E] = n_dyn + n_fix router columns.
+ */
+#ifndef UMOE_H
+#define UMOE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* umoe_stream_t;
+
+const char* umoe_last_error(void);
+int umoe_abi_version(void);
+
+/* ------------------------------------------------------------------ weight layout
+ * nn.Linear weights W[N][K] (bf16) are re-laid once at load time into the MFMA operand
+ * order used by every weight-streaming kernel ("WP16"): 16-row x 32-col fragments of
+ * v_mfma_f32_16x16x32_bf16, stored so that one wave-instruction reads 1 KiB contiguous.
+ * K is split into 4 equal quarters, lane-group h = lane>>4 owns quarter h:
+ *   packed[((nb*KB + i)*64 + lane)*8 + j] = W[nb*16 + (lane&15)][(lane>>4)*(K/4) + i*8 + j]
+ * with KB = K/32, N padded up to a multiple of 16 with zero rows.  Requires K % 32 == 0.
+ */
+size_t umoe_packed_elems(int N, int K);
+int umoe_pack_weight(const uint16_t* W, int N, int K, uint16_t* packed, umoe_stream_t stream);
+/* gate_proj / up_proj of one SwiGLU expert interleaved per 16-row block (block 2i = gate i,
+ * block 2i+1 = up i) so one wave produces silu(g)*u without a round trip.  N_packed = 2*I. */
+int umoe_pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int I, int K, uint16_t* packed, umoe_stream_t stream);
+
+/* ------------------------------------------------------------------ router
+ * Replaces utils/UniMoE_Audio_core.py:246-291,331-339 (gate GEMM, Top-P count :157-167,
+ * sparse mixer :94-154 + driver loop :262-282, renormalise / padding / shared-on :284-291,
+ * global weights :178-193) and the `router_weight * expert_mask` of :447.
+ * Integer outputs are bit-exact w.r.t. oracle/router_oracle.c given identical logits.
+ */
+typedef struct {
+    /* inputs: either (x, gate_w) or logits_in */
+    const uint16_t* x;        /* [S][D] bf16 hidden states (post-norm unless norm_w given), or NULL */
+    const uint16_t* gate_w;   /* [E][D] bf16, reference `gate.weight` */
+    const uint16_t* norm_w;   /* optional [D]: fuse RMSNorm (model.py:240) in front of the gate */
+    uint16_t* h_out;          /* optional [S][D]: normalised hidden states written for the experts */
+    const void* logits_in;    /* optional [S][E] T: skip the gate GEMM (parity tests) */
+    const uint8_t* attn_mask; /* optional [S] 0/1 padding mask (core.py:286-288) */
+    int S, D;
+    int n_dyn, n_real, n_fix; /* 9, 8, 2 */
+    int logits_bf16;          /* 1: eval (bf16 gate, core.py:251); 0: fp32 gate (core.py:249) */
+    float top_p;              /* 0 => fixed_top_k for every token (core.py:254-257) */
+    int fixed_top_k;
+    double jitter_eps;        /* router_jitter_noise */
+    float rms_eps;
+    /* outputs (any may be NULL except expert_mask / moe_w / slot tables) */
+    void* logits_out;         /* [S][E] T */
+    int64_t* top_k;           /* [S] */
+    int32_t* sel;             /* [S][n_dyn] expert picked at round j, -1 beyond k */
+    int32_t* expert_mask;     /* [S][E] */
+    float* routing_w;         /* [S][n_dyn] T-rounded values held in fp32 */
+    float* global_w;          /* [S][E]     T-rounded values held in fp32 */
+    float* moe_w;             /* [S][n_real] = global_w * mask */
+} umoe_router_args;
+int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
+
+/* Ragged dispatch tables from the 0/1 mask: the build's replacement for the dense
+ * compress_matrix / decompress_matrix pair (utils/UniMoE_Audio_utils.py:436-523) and the
+ * capacity MAX of core.py:455-457.  Wavefront ballot + prefix sums, token order preserved.
+ *   counts[n_real], offsets[n_real+1], slot_token[S*n_real], slot_of[S][n_real] (-1 = unrouted) */
+int umoe_dispatch_build(const int32_t* expert_mask, int S, int ld_mask, int n_real, int32_t* counts,
+                        int32_t* offsets, int32_t* slot_token, int32_t* slot_of, umoe_stream_t stream);
+
+/* permute: out[slot] = x[slot_token[slot]]  (the gather half of compress_matrix);
+ * bwd of unpermute.  rows = offsets[n_real] read on device. */
+int umoe_permute_fwd(const uint16_t* x, int D, const int32_t* slot_token, const int32_t* total_slots, int max_slots,
+                     uint16_t* out, umoe_stream_t stream);
+
+/* ------------------------------------------------------------------ grouped weight-streaming GEMM
+ * One launch covers any number of groups (routed experts with ragged row lists, shared
+ * experts with all rows, plain dense layers with one group).
+ */
+typedef struct {
+    const uint16_t* w;        /* WP16-packed weights of this group */
+    const float* bias;        /* optional [N] fp32 */
+    const int32_t* rows;      /* optional gather list (token index per row); NULL = identity */
+    const int32_t* row_off;   /* optional device scalar added to the row number (offsets[e]) */
+    const int32_t* count;     /* optional device scalar: number of rows; NULL => static_count */
+    int static_count;
+    int a_row_base;           /* identity mode: A row = a_row_base + r */
+    int out_row_base;         /* output row = out_row_base + (row_off ? *row_off : 0) + r */
+    int n_blocks;             /* N/16 (2*I/16 for gate/up pairs) */
+    int k;                    /* K */
+} umoe_group_t;
+
+enum { UMOE_PRO_PLAIN = 0, UMOE_PRO_RMSNORM = 1 };
+enum {
+    UMOE_EPI_BF16 = 0,      /* y = bf16(acc + bias) */
+    UMOE_EPI_BF16_RESID = 1, /* y = bf16(resid + bf16(acc + bias)) */
+    UMOE_EPI_SWIGLU = 2,     /* pairs: y = bf16(bf16(silu(bf16 g)) * bf16 u)   core.py:31,49 */
+    UMOE_EPI_F32 = 3,        /* y = float(bf16(acc))   (codec_head(...).float(), model.py:982) */
+    UMOE_EPI_F32_RAW = 4     /* y = acc (fp32, unrounded) */
+};
+
+typedef struct {
+    const umoe_group_t* groups; /* device array */
+    int num_groups;
+    int max_rows;             /* upper bound of rows per group (grid sizing; no host sync) */
+    int max_n_blocks;         /* max over groups */
+    int max_k;
+    const uint16_t* a;        /* [*, lda] bf16 activations */
+    int lda;
+    const uint16_t* norm_w;   /* UMOE_PRO_RMSNORM: [K] */
+    float rms_eps;
+    const uint16_t* resid;    /* UMOE_EPI_BF16_RESID: [*, ldo] */
+    void* out;                /* bf16 or fp32 [*, ldo] */
+    int ldo;
+    int n_valid;              /* columns >= n_valid are not stored (N not multiple of 16) */
+    int prologue, epilogue;
+} umoe_gemm_args;
+int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream);
+
+/* Named wrappers required by the scope table; thin calls of umoe_grouped_gemm.
+ * umoe_grouped_swiglu_fwd: routed experts, core.py:406-416 + :34-49 on ragged rows.
+ * umoe_shared_swiglu_fwd : shared experts, core.py:344-351 + :16-31. */
+int umoe_grouped_swiglu_fwd(const umoe_group_t* gateup_groups, const umoe_group_t* down_groups, int num_groups,
+                            int max_rows, const uint16_t* x, int D, int I, uint16_t* h_ws, uint16_t* y_slots,
+                            umoe_stream_t stream);
+
+/* combine: out[s] = resid[s] + ( sum_e moe_w[s][e] * y[slot_of[s][e]]  (+ shared_i[s] * global_w[s][n_dyn+i]) )
+ * with the reference's rounding points (einsum core.py:488, adds :342,:351, residual model.py:242). */
+typedef struct {
+    const uint16_t* y_slots;  /* [slots][D] routed expert outputs */
+    const int32_t* slot_of;   /* [S][n_real] */
+    const float* moe_w;       /* [S][n_real] */
+    const uint16_t* y_shared; /* [n_fix][S][D] or NULL */
+    const float* global_w;    /* [S][E] */
+    const uint16_t* resid;    /* [S][D] or NULL */
+    uint16_t* out;            /* [S][D] */
+    int S, D, n_real, n_dyn, n_fix;
+} umoe_combine_args;
+int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_stream_t stream);
+
+/* ------------------------------------------------------------------ norm / rope / attention
+ * umoe_rmsnorm_residual_fwd: y = w * bf16((x [+ r]) * rsqrt(mean((x+r)^2) + eps)); also writes x+r.
+ * Replaces transformers Qwen2RMSNorm (model.py:206-207,227,240,428) + residual adds (:238,:242). */
+int umoe_rmsnorm_residual_fwd(const uint16_t* x, const uint16_t* r, const uint16_t* w, float eps, int S, int D,
+                              uint16_t* sum_out, uint16_t* y, umoe_stream_t stream);
+
+/* mRoPE + KV append.  qkv [rows*T][(H+2*KVH)*hd] bf16 (bias already added).  cos/sin tables
+ * [max_pos][hd/2] bf16 built by the host exactly as Qwen2_5_VLRotaryEmbedding does; pos3 [3][rows*T]
+ * position streams; sections = mrope_section (channel block i uses stream i%3).
+ * Writes rotated q to q_out [rows*T][H*hd] and rotated k / v into the cache at kv_pos[row*T+t]:
+ * cache layout [rows][KVH][Lmax][hd].  Replaces apply_multimodal_rotary_pos_emb + DynamicCache.update. */
+typedef struct {
+    const uint16_t* qkv;
+    const uint16_t* cos_tab;
+    const uint16_t* sin_tab;
+    const int32_t* pos3;      /* [3][n_tok] */
+    const int32_t* kv_pos;    /* [n_tok] cache slot of each token */
+    int n_tok, T;             /* n_tok = rows*T; token i belongs to row i / T */
+    int H, KVH, hd;
+    int sec0, sec1, sec2;
+    int Lmax;
+    uint16_t* q_out;
+    uint16_t* k_cache;
+    uint16_t* v_cache;
+} umoe_rope_args;
+int umoe_qkv_mrope_kvappend(const umoe_rope_args* a, umoe_stream_t stream);
+
+/* Attention over the cache for nq query tokens per row (nq=1 decode, nq=T causal prefill).
+ * q [rows*nq][H*hd]; query t of a row sees cache slots [kv_start[row], q_pos0[row] + t].
+ * Split over keys (flash-decoding) + umoe_attn_combine.  out [rows*nq][H*hd] bf16.
+ * Replaces Qwen2_5_VLAttention's sdpa/eager core (model.py:228-237). */
+typedef struct {
+    const uint16_t* q;
+    const uint16_t* k_cache;
+    const uint16_t* v_cache;
+    const int32_t* kv_start;  /* [rows] first valid slot (left padding) */
+    const int32_t* q_pos0;    /* [rows] cache slot of this call's first query */
+    int rows, nq, H, KVH, hd, Lmax;
+    int splits;               /* key splits per (row, kv head, query) */
+    float scale;
+    float* part_o;            /* [rows*nq][H][splits][hd] */
+    float* part_ml;           /* [rows*nq][H][splits][2]  */
+    uint16_t* out;
+} umoe_attn_args;
+int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream);
+
+/* ------------------------------------------------------------------ codec side
+ * codec_embedding (model.py:655-661): out[r] = sum_c Emb_c[tok[r][c]], bf16 adds in channel order.
+ * emb [C][V][D]. */
+int umoe_codec_embed_sum(const int32_t* tok, const uint16_t* emb, int rows, int C, int V, int D, uint16_t* out,
+                         umoe_stream_t stream);
+
+/* CFG + masks + sampling on codec-head logits (model.py:991-1017, 873-916).
+ * logits [2B][C*V] fp32 (row 2b = uncond, 2b+1 = cond).  temperature 0 or do_sample 0 => arg-max.
+ * probs_out optional [B*C][V] (post-filter probabilities, for parity).  rng: Philox-free counter
+ * hash seeded by (seed, step, row). */
+typedef struct {
+    const float* logits;
+    int B, C, V;
+    float cfg_scale, temperature, top_p, eos_mul;
+    int top_k;                /* <=0: none */
+    int eos;
+    int enable_eos;           /* host flag; or enable_eos_from_step >= 0: enabled iff *step >= that */
+    int min_tokens;           /* -1 = None */
+    const int32_t* step;      /* device scalar dec_step (may be NULL) */
+    int do_sample;
+    uint64_t seed;
+    int64_t* pred;            /* [B][C] */
+    float* probs_out;
+} umoe_sample_args;
+int umoe_codec_head_cfg_sample(const umoe_sample_args* a, umoe_stream_t stream);
+
+/* One step of generate()'s token bookkeeping on device (model.py:1173-1203 + DecoderOutput.update_one,
+ * utils/UniMoE_Audio_utils.py:290-298): EOS detection on channel 0, countdown, forced EOS/PAD by delay
+ * pattern, BOS masking, append into tokens[B][Tmax][C], advance *step.  state = int32[4*B + 8]:
+ * eos_detected[B], countdown[B], finished[B], prefill_step[B], then {step, max_tokens, all_done, bos_over,
+ * step0 (dec_step of the first decode call), 3 reserved}. */
+int umoe_delay_step(int64_t* pred, int32_t* tokens, int32_t* state, const int32_t* delay, int B, int C, int Tmax,
+                    int eos, int pad, int max_delay, umoe_stream_t stream);
+
+/* RVQ (third-party descript-audio-codec 1.0.0 ResidualVectorQuantize, call sites
+ * utils/UniMoE_Audio_utils.py:113,123): from_codes = sum_q out_proj_q(codebook_q[code]); nearest = per level
+ * in_proj, L2-normalised nearest neighbour, subtract.  All DAC dims are load-time parameters. */
+int umoe_rvq_from_codes(const int32_t* codes, const float* codebooks, const float* out_w, const float* out_b, int NQ,
+                        int CB, int cd, int Dl, int T, float* z, umoe_stream_t stream);
+int umoe_rvq_nearest(const float* z, const float* codebooks, const float* in_w, const float* in_b, const float* out_w,
+                     const float* out_b, int NQ, int CB, int cd, int Dl, int T, int32_t* codes, float* resid_ws,
+                     umoe_stream_t stream);
+
+/* ------------------------------------------------------------------ decode engine
+ * Owns workspace + KV cache and enqueues a whole decode step (36 layers + head + sampler + delay
+ * bookkeeping) from one host call, optionally replayed as a hipGraph.  Restates
+ * generate()/_decoder_step() control flow (model.py:918-1231) without per-step host syncs. */
+typedef struct {
+    int hidden, layers, heads, kv_heads, head_dim;
+    int n_dyn, n_real, n_fix, inter_dyn, inter_shared;
+    int codec_channels, codec_vocab, eos, pad, bos;
+    int mrope0, mrope1, mrope2;
+    float rms_eps, top_p;
+    int fixed_top_k;
+    double jitter_eps;
+    int rows;                 /* 2 * batch (CFG pairs) */
+    int Lmax;                 /* KV slots per row */
+    int Tmax;                 /* token buffer length */
+    int attn_splits;
+    int ep_rank, ep_size;     /* expert parallel: this rank owns experts [rank*n_real/size, ...) */
+} umoe_engine_cfg;
+
+typedef struct {
+    const uint16_t* in_norm;      /* [D] */
+    const uint16_t* qkv_w;        /* WP16 of cat(q,k,v) [H*hd + 2*KVH*hd][D] */
+    const float* qkv_b;           /* [H*hd + 2*KVH*hd] fp32 */
+    const uint16_t* o_w;          /* WP16 [D][H*hd] */
+    const uint16_t* post_norm;    /* [D] */
+    const uint16_t* gate_w;       /* [E][D] plain bf16 */
+    const uint16_t* const* exp_gu; /* host array [n_real] of device ptrs: WP16 gate/up pairs */
+    const uint16_t* const* exp_dn; /* host array [n_real]: WP16 down */
+    const uint16_t* const* sh_gu;  /* host array [n_fix] */
+    const uint16_t* const* sh_dn;  /* host array [n_fix] */
+} umoe_layer_weights;
+
+typedef struct umoe_engine umoe_engine;
+int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out);
+void umoe_engine_destroy(umoe_engine* e);
+int umoe_engine_set_layer(umoe_engine* e, int layer, const umoe_layer_weights* w);
+/* final norm [D], codec embeddings [C][V][D], WP16 codec head [C*V][D], rope tables [max_pos][hd/2] */
+int umoe_engine_set_globals(umoe_engine* e, const uint16_t* final_norm, const uint16_t* codec_emb,
+                            const uint16_t* codec_head_w, const uint16_t* cos_tab, const uint16_t* sin_tab, int max_pos,
+                            const int32_t* delay_pattern_host);
+size_t umoe_engine_workspace_bytes(const umoe_engine* e);
+/* prefill: x [rows*T][D] input embeddings (host builds them: text embed + codec scatter, model.py:663-670),
+ * valid [rows][T] 0/1 attention mask (left padded). Fills the KV cache. */
+int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T, umoe_stream_t stream);
+/* decode bookkeeping state + token buffer (device, owned by caller) */
+typedef struct {
+    int32_t* tokens;          /* [B][Tmax][C], -1 = to be generated */
+    int32_t* state;           /* see umoe_delay_step */
+    float cfg_scale, temperature, top_p, eos_mul;
+    int top_k, do_sample, min_tokens;
+    uint64_t seed;
+} umoe_decode_io;
+int umoe_engine_decode_step(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream);
+/* graph capture of one decode step; replays read all step-dependent scalars from device memory */
+int umoe_engine_capture(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream);
+int umoe_engine_replay(umoe_engine* e, umoe_stream_t stream);
+/* introspection for parity tests: device pointers into the workspace */
+const void* umoe_engine_buffer(umoe_engine* e, const char* name, size_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMOE_H */

@@ -58,7 +58,7 @@ def block_cfg(**over):
             mlp_dynamic_top_k=2, mlp_fixed_expert_num=2, ignore_differentiable_router=True, ep_size=1,
             router_jitter_noise=0.01, input_jitter_noise=0.0, min_capacity=8, capacity_factor=6.0, token_drop=False,
             drop_policy="probs", avg_hidden_states_last=False, drop_token_num_print=False, fp32_gate=True,
-            dynamic_intermediate_size=96, shared_intermediate_size=48, hidden_act="silu",
+            dynamic_intermediate_size=96, shared_intermediate_size=64, hidden_act="silu",
             enable_expert_tensor_parallelism=False)
     c.__dict__.update(over)
     return c

@@ -1,0 +1,375 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP op, called through the C-ABI, against the
+CPU oracle (oracle/*) on the same seeded inputs, plus the golden fixtures generated from the reference.
+
+Bar: bit-exact for integer outputs (k, expert ids/order, masks, dispatch tables, arg-max codes); stated
+tolerances for bf16/fp32 tensors.
+"""
+import glob
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL = dict(rtol=2 ** -6, atol=2 ** -8)      # ~2 bf16 ulps relative + small absolute (accumulation order differs)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no GPU is visible")
+    from unimoe_audio_amd import _lib
+    _lib.lib()                                    # raises if the HIP library is missing: no silent fallback
+    return torch.device("cuda:0")
+
+
+def _ref_linear(x, w, bias=None):
+    y = x.float() @ w.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    return y
+
+
+# ----------------------------------------------------------------------------- GEMM family
+@pytest.mark.parametrize("S,K,N", [(16, 2048, 2560), (5, 2048, 2048), (40, 2752, 2048), (16, 1376, 2048),
+                                   (16, 2048, 12324), (16, 64, 96), (3, 96, 64), (33, 128, 48)])
+def test_linear_plain_bias_resid(dev, S, K, N):
+    from unimoe_audio_amd import ops
+    torch.manual_seed(S * 7 + K + N)
+    x = (torch.randn(S, K) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N) * 0.1
+    r = torch.randn(S, N).to(torch.bfloat16)
+    xd, wd = x.to(dev), w.to(dev)
+    wp = ops.pack_weight(wd)
+    ref = _ref_linear(x, w)
+    assert torch.allclose(ops.linear(xd, wp, N).float().cpu(), ref.to(torch.bfloat16).float(), **BF16_TOL)
+    y = ops.linear(xd, wp, N, bias=b.to(dev)).float().cpu()
+    assert torch.allclose(y, (ref + b).to(torch.bfloat16).float(), **BF16_TOL)
+    y = ops.linear(xd, wp, N, resid=r.to(dev)).float().cpu()
+    assert torch.allclose(y, (r.float() + ref.to(torch.bfloat16).float()).to(torch.bfloat16).float(), **BF16_TOL)
+    y = ops.linear(xd, wp, N, out_f32=True).cpu()
+    assert y.dtype == torch.float32
+    assert torch.allclose(y, ref.to(torch.bfloat16).float(), **BF16_TOL)
+
+
+@pytest.mark.parametrize("S,K,N", [(16, 2048, 2560), (7, 128, 64), (16, 2048, 12324)])
+def test_linear_rmsnorm_prologue(dev, S, K, N):
+    from oracle import decode as OD
+    from unimoe_audio_amd import ops
+    torch.manual_seed(K + N)
+    x = (torch.randn(S, K) * 2.0).to(torch.bfloat16)
+    nw = (1 + 0.1 * torch.randn(K)).to(torch.bfloat16)
+    w = (torch.randn(N, K) * 0.03).to(torch.bfloat16)
+    h = OD.rmsnorm(x, nw, 1e-6)
+    ref = _ref_linear(h, w).to(torch.bfloat16).float()
+    y = ops.linear(x.to(dev), ops.pack_weight(w.to(dev)), N, norm_w=nw.to(dev), rms_eps=1e-6).float().cpu()
+    assert torch.allclose(y, ref, **BF16_TOL)
+    yn = ops.rmsnorm(x.to(dev), nw.to(dev), 1e-6).cpu()
+    assert torch.allclose(yn.float(), h.float(), rtol=2 ** -7, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- router: ints bit-exact
+def test_router_ints_vs_reference_goldens(dev):
+    """logits in -> (k, ids, order, mask) out, against fixtures produced by the REAL reference."""
+    from unimoe_audio_amd import ops
+    g = load_golden("router_ids.npz")
+    tags = sorted({k.split("__")[0] for k in g})
+    total = 0
+    for tag in tags:
+        lg = g[tag + "__logits"]
+        top_p = float(tag.split("_p")[1].split("_k")[0])
+        top_k = int(tag.split("_k")[1])
+        r = ops.router_fwd(None, None, n_dyn=9, n_real=8, n_fix=2, top_p=top_p, fixed_top_k=top_k, jitter_eps=0.01,
+                           logits_in=lg.to(dev))
+        assert torch.equal(r["top_k"].cpu(), g[tag + "__top_k"].long()), tag
+        assert torch.equal(r["expert_mask"].cpu(), g[tag + "__expert_mask"]), tag
+        assert torch.equal(r["sel"].cpu(), g[tag + "__sel"]), tag
+        tol = 2 ** -7 if lg.dtype == torch.bfloat16 else 1e-6
+        assert torch.allclose(r["global_weight"].cpu(), g[tag + "__global_weight"].float(), rtol=tol, atol=tol * 1e-2), tag
+        total += lg.shape[0]
+    assert total > 60000
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("scale", [0.05, 0.9, 3.0])
+def test_router_ints_vs_oracle_large(dev, dt, scale):
+    """1M tokens per case: every integer output AND every weight bit-identical to the C oracle."""
+    from oracle import router as OR
+    from unimoe_audio_amd import ops
+    torch.manual_seed(int(scale * 100) + (1 if dt == torch.float32 else 0))
+    S = 1 << 20
+    lg = (torch.randn(S, 11) * scale).to(dt)
+    lg[::97, 3] = lg[::97, 5]                    # exact ties
+    am = (torch.rand(S) > 0.1)
+    r = ops.router_fwd(None, None, n_dyn=9, n_real=8, n_fix=2, top_p=0.7, jitter_eps=0.01, logits_in=lg.to(dev),
+                       attn_mask=am.to(dev))
+    o = OR.route(lg, 9, 8, 2, 0.7, 0, 0.01, am)
+    assert torch.equal(r["top_k"].cpu(), o["top_k"])
+    assert torch.equal(r["sel"].cpu(), o["sel"])
+    assert torch.equal(r["expert_mask"].cpu(), o["expert_mask"])
+    assert torch.equal(r["routing_weights"].cpu(), o["routing_weights"].float())
+    assert torch.equal(r["global_weight"].cpu(), o["global_weight"].float())
+    assert torch.equal(r["moe_weight"].cpu(), o["moe_weight"].float())
+
+
+def test_router_fused_gate_and_norm(dev):
+    """x -> RMSNorm -> gate GEMV -> routing in one kernel: logits to tolerance; ints exact once the oracle is
+    fed the logits the GPU produced (the contract of SURVEY.md 7 'hard parts')."""
+    from oracle import decode as OD
+    from oracle import router as OR
+    from unimoe_audio_amd import ops
+    torch.manual_seed(5)
+    S, D = 777, 2048
+    x = torch.randn(S, D).to(torch.bfloat16)
+    nw = (1 + 0.05 * torch.randn(D)).to(torch.bfloat16)
+    gw = (torch.randn(11, D) * 0.02).to(torch.bfloat16)
+    r = ops.router_fwd(x.to(dev), gw.to(dev), n_dyn=9, n_real=8, n_fix=2, top_p=0.7, jitter_eps=0.01, norm_w=nw.to(dev),
+                       want_h=True)
+    h = OD.rmsnorm(x, nw, 1e-6)
+    assert torch.allclose(r["h"].float().cpu(), h.float(), rtol=2 ** -7, atol=1e-6)
+    ref_logits = torch.nn.functional.linear(h, gw)
+    got = r["logits"].cpu()
+    assert torch.allclose(got.float(), ref_logits.float(), rtol=2 ** -6, atol=2 ** -7)
+    o = OR.route(got, 9, 8, 2, 0.7, 0, 0.01, None)
+    assert torch.equal(r["top_k"].cpu(), o["top_k"]) and torch.equal(r["expert_mask"].cpu(), o["expert_mask"])
+    assert torch.equal(r["sel"].cpu(), o["sel"])
+    o2 = OR.route(ref_logits, 9, 8, 2, 0.7, 0, 0.01, None)
+    mism = int((o2["expert_mask"] != o["expert_mask"]).any(-1).sum())
+    assert mism <= S * 0.03, f"index mismatch rate from logit rounding too high: {mism}/{S}"
+
+
+@pytest.mark.parametrize("S", [0, 1, 16, 257, 6240])
+def test_dispatch_tables_exact(dev, S):
+    from oracle import router as OR
+    from unimoe_audio_amd import ops
+    torch.manual_seed(S)
+    mask = (torch.rand(S, 11) < 0.45).to(torch.int32)
+    if S > 3:
+        mask[:, 2] = 0
+        mask[:, 6] = 1
+    d = ops.dispatch_build(mask.to(dev), 8) if S else None
+    if S == 0:
+        return
+    o = OR.dispatch(mask, 8)
+    assert torch.equal(d["counts"][:8].cpu(), o["counts"])
+    assert torch.equal(d["offsets"][:9].cpu(), o["offsets"])
+    assert torch.equal(d["slot_of"].cpu(), o["slot_of"])
+    assert torch.equal(d["slot_token"][: o["total"]].cpu(), o["slot_token"])
+    x = torch.randn(S, 64).to(torch.bfloat16)
+    p = ops.permute_fwd(x.to(dev), d, 8).cpu()
+    assert torch.equal(p[: o["total"]], x[o["slot_token"].long()])
+
+
+# ----------------------------------------------------------------------------- whole DCMoE block
+def _mk_block(cfgd, weights, dev):
+    from unimoe_audio_amd.dcmoe import UniMoEAudioSparseMoeBlock
+    cfg = types.SimpleNamespace(**cfgd)
+    blk = UniMoEAudioSparseMoeBlock(cfg)
+    sd = {k: v.to(torch.bfloat16) for k, v in weights.items()}
+    missing, unexpected = blk.load_state_dict(sd, strict=True), None
+    return blk.to(dev).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "dcmoe_bf16_*.npz"))), ids=os.path.basename)
+def test_dcmoe_block_vs_reference_goldens(dev, path):
+    """The drop-in module (reference parameter names, reference 6-tuple) against outputs of the real reference."""
+    from oracle import router as OR
+    g = load_golden(os.path.basename(path))
+    cfgd = g["cfg_json"]
+    w = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
+    blk = _mk_block(cfgd, w, dev)
+    blk.train(bool(int(g["train"])))
+    am = g.get("in_attention_mask")
+    aw = g.get("in_aux_balance_weight")
+    with torch.no_grad():
+        out = blk(g["in_x"].to(dev), None if am is None else am.to(dev), None if aw is None else aw.to(dev))
+    hid, logits, top_k, mask, weight, aux = [o.cpu() for o in out]
+    ref_logits = g["out_logits"]
+    assert logits.dtype == ref_logits.dtype
+    assert torch.allclose(logits.float(), ref_logits.float(), rtol=2 ** -6, atol=2 ** -7)
+    n_dyn = cfgd["mlp_dynamic_expert_num"] + cfgd["mlp_dynamic_null_expert_num"]
+    n_fix = cfgd["mlp_fixed_expert_num"]
+    same = (logits.float() == ref_logits.float()).all(-1)           # tokens whose logits came out bit-identical
+    assert same.float().mean() > 0.5
+    if not cfgd["token_drop"]:
+        assert torch.equal(top_k.long()[same], g["out_top_k"].long()[same])
+        assert torch.equal(mask[same], g["out_mask"][same])
+        # and for ALL tokens: ints must equal the oracle fed with the GPU's own logits
+        o = OR.route(logits, n_dyn, cfgd["mlp_dynamic_expert_num"], n_fix, float(cfgd["mlp_dynamic_top_p"]),
+                     int(cfgd["mlp_dynamic_top_k"]), float(cfgd["router_jitter_noise"]),
+                     None if am is None else am.reshape(-1))
+        assert torch.equal(top_k.long(), o["top_k"]) and torch.equal(mask, o["expert_mask"])
+    agree = (mask == g["out_mask"]).all(-1).reshape(hid.shape[:2])
+    ok = torch.isfinite(g["out_hidden"].float()).all(-1) & agree
+    assert ok.float().mean() > 0.5
+    assert torch.allclose(hid.float()[ok], g["out_hidden"].float()[ok], rtol=2 ** -5, atol=2 ** -7)
+    okw = ok.reshape(-1)
+    assert torch.allclose(weight.float()[okw], g["out_weight"].float()[okw], rtol=2 ** -6, atol=2 ** -8)
+    if bool(agree.all()) and bool(torch.isfinite(g["out_aux"])):
+        assert torch.allclose(aux.float(), g["out_aux"].float(), rtol=3e-2, atol=1e-3)
+
+
+def test_dcmoe_block_fullsize_vs_oracle(dev):
+    """Full utils/config.json sizes, 16 rows (decode shape) and 300 rows, against the CPU oracle."""
+    from oracle.dcmoe import DCMoEOracle
+    from unimoe_audio_amd.config import UniMoEAudioConfig
+    from unimoe_audio_amd.dcmoe import UniMoEAudioSparseMoeBlock
+    cfg = UniMoEAudioConfig()
+    torch.manual_seed(1234)
+    blk = UniMoEAudioSparseMoeBlock(cfg)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.normal_(0, 0.02)
+    blk = blk.to(torch.bfloat16).eval()
+    w = {k: v.clone() for k, v in blk.state_dict().items()}
+    orc = DCMoEOracle(cfg, w)
+    gpu = blk.to(dev)
+    for S in (16, 300):
+        x = torch.randn(1, S, cfg.hidden_size).to(torch.bfloat16)
+        with torch.no_grad():
+            out = [o.cpu() for o in gpu(x.to(dev), None, None)]
+        ref = orc(x, None, None)
+        same = (out[1].float() == ref[1].float()).all(-1)
+        assert same.float().mean() > 0.9
+        assert torch.equal(out[2][same], ref[2][same]) and torch.equal(out[3][same], ref[3][same])
+        assert torch.allclose(out[0].float()[0][same], ref[0].float()[0][same], rtol=2 ** -5, atol=2 ** -9)
+
+
+# ----------------------------------------------------------------------------- rope / attention
+def _attn_setup(rows, T, H, KVH, hd, Lmax, pads, seed):
+    from oracle import decode as OD
+    torch.manual_seed(seed)
+    cfg = types.SimpleNamespace(hidden_size=H * hd, num_attention_heads=H, num_key_value_heads=KVH, rope_theta=1e6,
+                                mrope_section=[16, 24, 24], rms_norm_eps=1e-6)
+    D = H * hd
+    w = {"a.q_proj.weight": (torch.randn(H * hd, D) * 0.03).to(torch.bfloat16), "a.q_proj.bias": (torch.randn(H * hd) * 0.1).to(torch.bfloat16),
+         "a.k_proj.weight": (torch.randn(KVH * hd, D) * 0.03).to(torch.bfloat16), "a.k_proj.bias": (torch.randn(KVH * hd) * 0.1).to(torch.bfloat16),
+         "a.v_proj.weight": (torch.randn(KVH * hd, D) * 0.03).to(torch.bfloat16), "a.v_proj.bias": (torch.randn(KVH * hd) * 0.1).to(torch.bfloat16),
+         "a.o_proj.weight": (torch.randn(D, H * hd) * 0.03).to(torch.bfloat16)}
+    x = torch.randn(rows, T + 2, D).to(torch.bfloat16)
+    valid = torch.ones(rows, T + 2, dtype=torch.bool)
+    for r, p in enumerate(pads):
+        valid[r, :p] = False
+    pos = (valid.long().cumsum(-1) - 1).masked_fill(~valid, 1)
+    pos3 = torch.stack([pos, pos + 3, pos * 2], 0)
+    return cfg, w, x, valid, pos3
+
+
+def test_rope_attention_prefill_and_decode(dev):
+    from oracle import decode as OD
+    from unimoe_audio_amd import ops
+    rows, T, H, KVH, hd, Lmax = 3, 37, 16, 2, 128, 64
+    cfg, w, x, valid, pos3 = _attn_setup(rows, T, H, KVH, hd, Lmax, [5, 0, 1], 11)
+    cos3, sin3 = OD.rope_cos_sin(pos3, hd, 1e6, torch.bfloat16)
+    cos, sin = OD.mrope_select(cos3, cfg.mrope_section), OD.mrope_select(sin3, cfg.mrope_section)
+    cos_tab, sin_tab = ops.rope_tables(256, hd, 1e6, dev)
+    wqkv = torch.cat([w["a.q_proj.weight"], w["a.k_proj.weight"], w["a.v_proj.weight"]], 0)
+    bqkv = torch.cat([w["a.q_proj.bias"], w["a.k_proj.bias"], w["a.v_proj.bias"]], 0).float()
+    wqkv_p, wo_p = ops.pack_weight(wqkv.to(dev)), ops.pack_weight(w["a.o_proj.weight"].to(dev))
+    kc = torch.zeros(rows, KVH, Lmax, hd, dtype=torch.bfloat16, device=dev)
+    vc = torch.zeros_like(kc)
+    kv_start = torch.tensor([5, 0, 1], dtype=torch.int32, device=dev)
+    cache = None
+    for (a, b, splits) in ((0, T, 1), (T, T + 1, 4), (T + 1, T + 2, 8)):
+        nq = b - a
+        xs = x[:, a:b]
+        ref, cache = OD.attention(cfg, w, "a.", xs, cos[:, a:b], sin[:, a:b], cache, valid[:, :b])
+        xd = xs.reshape(rows * nq, -1).contiguous().to(dev)
+        qkv = ops.linear(xd, wqkv_p, wqkv.shape[0], bias=bqkv.to(dev))
+        p3 = pos3[:, :, a:b].reshape(3, rows * nq).to(torch.int32).contiguous().to(dev)
+        kvp = torch.arange(a, b, dtype=torch.int32).repeat(rows).to(dev)
+        q = ops.qkv_mrope_kvappend(qkv, cos_tab, sin_tab, p3, kvp, nq, H, KVH, hd, cfg.mrope_section, kc, vc)
+        q0 = torch.full((rows,), a, dtype=torch.int32, device=dev)
+        ao = ops.attention(q, kc, vc, kv_start, q0, nq, H, splits=splits)
+        out = ops.linear(ao, wo_p, H * hd).reshape(rows, nq, -1).cpu()
+        qv = valid[:, a:b]
+        assert torch.allclose(out.float()[qv], ref.float()[qv], rtol=2 ** -5, atol=2 ** -7), (a, b)
+        # cache contents = the oracle's rotated keys / values (bf16, every rope op rounded like torch)
+        kref, vref = cache
+        got_k = kc[:, :, :b].cpu()
+        assert torch.allclose(got_k.float()[valid[:, :b].unsqueeze(1).expand(-1, KVH, -1)],
+                              kref.float()[valid[:, :b].unsqueeze(1).expand(-1, KVH, -1)], rtol=2 ** -6, atol=2 ** -7)
+
+
+# ----------------------------------------------------------------------------- codec side
+def test_codec_embed_sum(dev):
+    from unimoe_audio_amd import ops
+    torch.manual_seed(3)
+    C, V, D, rows = 12, 1027, 2048, 16
+    emb = (torch.randn(C, V, D) * 0.02).to(torch.bfloat16)
+    tok = torch.randint(0, V, (rows, C))
+    ref = None
+    for c in range(C):
+        e = emb[c][tok[:, c]]
+        ref = e if ref is None else ref + e
+    got = ops.codec_embed_sum(tok.to(dev), emb.to(dev)).cpu()
+    assert torch.equal(got, ref)                  # same bf16 adds in the same order: exact
+
+
+def test_cfg_sampler_vs_reference_goldens(dev):
+    from oracle import decode as OD
+    from unimoe_audio_amd import ops
+    g = load_golden("sampler.npz")
+    lg = g["logits"]                               # [24, 1027] treated as B=2, C=12 guided logits (cfg_scale=0 path)
+    B, C, V = 2, 12, 1027
+    two = torch.stack([torch.zeros_like(lg), lg], 1).reshape(B, C, 2, V).permute(0, 2, 1, 3).reshape(2 * B, C * V).contiguous()
+    # arg-max path, no masks beyond those already in the logits: compare with the reference's T=0 result
+    cfgo = types.SimpleNamespace(codec_eos_value=1024)
+    guided = OD.cfg_and_mask(cfgo, two.view(2 * B, C, V).clone(), 0.0, True, 1.0).reshape(B * C, V)
+    pred = ops.cfg_sample(two.to(dev), B, C, V, cfg_scale=0.0, temperature=0.0, top_p=1.0, top_k=45, eos=1024, eos_mul=1.0,
+                          enable_eos=True, do_sample=False).cpu().reshape(-1)
+    assert torch.equal(pred, torch.argmax(guided, -1))
+    for n in "abd":
+        T, tp, tk = g[f"params_{n}"].tolist()
+        ref = OD.sample_next_token(guided.clone(), T, tp, None if tk < 0 else int(tk), 1024, return_probs=True)
+        pred, probs = ops.cfg_sample(two.to(dev), B, C, V, cfg_scale=0.0, temperature=T, top_p=tp, top_k=None if tk < 0 else int(tk),
+                                     eos=1024, eos_mul=1.0, enable_eos=True, do_sample=True, seed=7, want_probs=True)
+        probs = probs.cpu()
+        assert torch.equal(probs > 0, ref > 0), n
+        assert torch.allclose(probs, ref, rtol=1e-4, atol=1e-7), n
+        assert bool((probs.gather(1, pred.cpu().reshape(-1, 1)) > 0).all())      # draws land on kept entries
+    # CFG mixing + EOS masks (model.py:991-1017) with a real uncond row
+    torch.manual_seed(9)
+    lg2 = torch.randn(2 * B, C * V) * 2
+    ref = OD.cfg_and_mask(cfgo, lg2.view(2 * B, C, V).clone(), 3.0, True, 0.8).reshape(B * C, V)
+    pred = ops.cfg_sample(lg2.to(dev), B, C, V, cfg_scale=3.0, temperature=0.0, top_p=1.0, top_k=45, eos=1024, eos_mul=0.8,
+                          enable_eos=True, do_sample=False).cpu().reshape(-1)
+    assert torch.equal(pred, torch.argmax(ref, -1))
+    ref = OD.cfg_and_mask(cfgo, lg2.view(2 * B, C, V).clone(), 3.0, False, 0.8).reshape(B * C, V)
+    pred = ops.cfg_sample(lg2.to(dev), B, C, V, cfg_scale=3.0, temperature=0.0, top_p=1.0, top_k=45, eos=1024, eos_mul=0.8,
+                          enable_eos=False, do_sample=False).cpu().reshape(-1)
+    assert torch.equal(pred, torch.argmax(ref, -1))
+
+
+def test_rvq_roundtrip_code_ids_exact(dev):
+    """RVQ with synthetic codebooks: from_codes -> nearest returns the same code ids when the codebooks are
+    well separated (encode(decode(codes)) == codes), and from_codes matches a plain fp32 restatement."""
+    from unimoe_audio_amd import ops
+    torch.manual_seed(21)
+    NQ, CB, cd, Dl, T = 12, 1024, 8, 64, 50
+    cb = torch.nn.functional.normalize(torch.randn(NQ, CB, cd), dim=-1)
+    # orthonormal-ish in/out projections per level so residual levels do not interfere: block structure
+    out_w = torch.zeros(NQ, Dl, cd)
+    in_w = torch.zeros(NQ, cd, Dl)
+    for q in range(NQ):
+        blk = torch.zeros(Dl, cd)
+        blk[(q * 5) % (Dl - cd):(q * 5) % (Dl - cd) + cd] = torch.eye(cd) * (0.5 ** q)
+        out_w[q] = blk
+        in_w[q] = blk.t() / (0.25 ** q)
+    codes = torch.randint(0, CB, (NQ, T))
+    z = ops.rvq_from_codes(codes.to(dev), cb.to(dev), out_w.to(dev), None).cpu()
+    ref = torch.zeros(Dl, T)
+    for q in range(NQ):
+        ref += out_w[q] @ cb[q][codes[q]].t()
+    assert torch.allclose(z, ref, rtol=1e-5, atol=1e-6)
+    q0 = ops.rvq_nearest(z.to(dev), cb[:1].contiguous().to(dev), in_w[:1].contiguous().to(dev), None,
+                         out_w[:1].contiguous().to(dev), None).cpu()
+    e0 = (in_w[0] @ z).t()
+    sim = torch.nn.functional.normalize(e0, dim=-1) @ torch.nn.functional.normalize(cb[0], dim=-1).t()
+    assert torch.equal(q0[0].long(), sim.argmax(-1))

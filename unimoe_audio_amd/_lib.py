@@ -1,0 +1,151 @@
+"""ctypes binding of libumoe_hip.so (the C-ABI declared in include/umoe.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libumoe_hip.so")
+_lib = None
+
+
+class UmoeError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "umoe.h"))
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _CSRC, "-j4", "-s"])
+    return _SO
+
+
+vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
+
+
+class RouterArgs(C.Structure):
+    _fields_ = [("x", vp), ("gate_w", vp), ("norm_w", vp), ("h_out", vp), ("logits_in", vp), ("attn_mask", vp),
+                ("S", i32), ("D", i32), ("n_dyn", i32), ("n_real", i32), ("n_fix", i32), ("logits_bf16", i32),
+                ("top_p", f32), ("fixed_top_k", i32), ("jitter_eps", f64), ("rms_eps", f32),
+                ("logits_out", vp), ("top_k", vp), ("sel", vp), ("expert_mask", vp), ("routing_w", vp),
+                ("global_w", vp), ("moe_w", vp)]
+
+
+class Group(C.Structure):
+    _fields_ = [("w", vp), ("bias", vp), ("rows", vp), ("row_off", vp), ("count", vp), ("static_count", i32),
+                ("a_row_base", i32), ("out_row_base", i32), ("n_blocks", i32), ("k", i32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("groups", vp), ("num_groups", i32), ("max_rows", i32), ("max_n_blocks", i32), ("max_k", i32),
+                ("a", vp), ("lda", i32), ("norm_w", vp), ("rms_eps", f32), ("resid", vp), ("out", vp), ("ldo", i32),
+                ("n_valid", i32), ("prologue", i32), ("epilogue", i32)]
+
+
+class CombineArgs(C.Structure):
+    _fields_ = [("y_slots", vp), ("slot_of", vp), ("moe_w", vp), ("y_shared", vp), ("global_w", vp), ("resid", vp),
+                ("out", vp), ("S", i32), ("D", i32), ("n_real", i32), ("n_dyn", i32), ("n_fix", i32)]
+
+
+class RopeArgs(C.Structure):
+    _fields_ = [("qkv", vp), ("cos_tab", vp), ("sin_tab", vp), ("pos3", vp), ("kv_pos", vp), ("n_tok", i32), ("T", i32),
+                ("H", i32), ("KVH", i32), ("hd", i32), ("sec0", i32), ("sec1", i32), ("sec2", i32), ("Lmax", i32),
+                ("q_out", vp), ("k_cache", vp), ("v_cache", vp)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", vp), ("k_cache", vp), ("v_cache", vp), ("kv_start", vp), ("q_pos0", vp), ("rows", i32),
+                ("nq", i32), ("H", i32), ("KVH", i32), ("hd", i32), ("Lmax", i32), ("splits", i32), ("scale", f32),
+                ("part_o", vp), ("part_ml", vp), ("out", vp)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("logits", vp), ("B", i32), ("C", i32), ("V", i32), ("cfg_scale", f32), ("temperature", f32),
+                ("top_p", f32), ("eos_mul", f32), ("top_k", i32), ("eos", i32), ("enable_eos", i32),
+                ("min_tokens", i32), ("step", vp), ("do_sample", i32), ("seed", u64), ("pred", vp), ("probs_out", vp)]
+
+
+class EngineCfg(C.Structure):
+    _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("kv_heads", i32), ("head_dim", i32),
+                ("n_dyn", i32), ("n_real", i32), ("n_fix", i32), ("inter_dyn", i32), ("inter_shared", i32),
+                ("codec_channels", i32), ("codec_vocab", i32), ("eos", i32), ("pad", i32), ("bos", i32),
+                ("mrope0", i32), ("mrope1", i32), ("mrope2", i32), ("rms_eps", f32), ("top_p", f32),
+                ("fixed_top_k", i32), ("jitter_eps", f64), ("rows", i32), ("Lmax", i32), ("Tmax", i32),
+                ("attn_splits", i32), ("ep_rank", i32), ("ep_size", i32)]
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [("in_norm", vp), ("qkv_w", vp), ("qkv_b", vp), ("o_w", vp), ("post_norm", vp), ("gate_w", vp),
+                ("exp_gu", C.POINTER(vp)), ("exp_dn", C.POINTER(vp)), ("sh_gu", C.POINTER(vp)), ("sh_dn", C.POINTER(vp))]
+
+
+class DecodeIO(C.Structure):
+    _fields_ = [("tokens", vp), ("state", vp), ("cfg_scale", f32), ("temperature", f32), ("top_p", f32),
+                ("eos_mul", f32), ("top_k", i32), ("do_sample", i32), ("min_tokens", i32), ("seed", u64)]
+
+
+EXPORTS = [
+    "umoe_last_error", "umoe_abi_version", "umoe_packed_elems", "umoe_pack_weight", "umoe_pack_gate_up",
+    "umoe_router_fwd", "umoe_dispatch_build", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd",
+    "umoe_unpermute_combine_fwd", "umoe_rmsnorm_residual_fwd", "umoe_qkv_mrope_kvappend", "umoe_attn_decode",
+    "umoe_codec_embed_sum", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
+    "umoe_rvq_nearest", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
+    "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
+    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise UmoeError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+        L = C.CDLL(_SO)
+        L.umoe_last_error.restype = C.c_char_p
+        L.umoe_packed_elems.restype = C.c_size_t
+        L.umoe_packed_elems.argtypes = [i32, i32]
+        L.umoe_engine_workspace_bytes.restype = C.c_size_t
+        L.umoe_engine_workspace_bytes.argtypes = [vp]
+        L.umoe_engine_buffer.restype = vp
+        L.umoe_engine_buffer.argtypes = [vp, C.c_char_p, C.POINTER(C.c_size_t)]
+        L.umoe_engine_destroy.restype = None
+        L.umoe_engine_destroy.argtypes = [vp]
+        L.umoe_pack_weight.argtypes = [vp, i32, i32, vp, vp]
+        L.umoe_pack_gate_up.argtypes = [vp, vp, i32, i32, vp, vp]
+        L.umoe_router_fwd.argtypes = [C.POINTER(RouterArgs), vp]
+        L.umoe_dispatch_build.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]
+        L.umoe_permute_fwd.argtypes = [vp, i32, vp, vp, i32, vp, vp]
+        L.umoe_grouped_gemm.argtypes = [C.POINTER(GemmArgs), vp]
+        L.umoe_unpermute_combine_fwd.argtypes = [C.POINTER(CombineArgs), vp]
+        L.umoe_rmsnorm_residual_fwd.argtypes = [vp, vp, vp, f32, i32, i32, vp, vp, vp]
+        L.umoe_qkv_mrope_kvappend.argtypes = [C.POINTER(RopeArgs), vp]
+        L.umoe_attn_decode.argtypes = [C.POINTER(AttnArgs), vp]
+        L.umoe_codec_embed_sum.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+        L.umoe_codec_head_cfg_sample.argtypes = [C.POINTER(SampleArgs), vp]
+        L.umoe_delay_step.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+        L.umoe_rvq_from_codes.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+        L.umoe_rvq_nearest.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        L.umoe_engine_create.argtypes = [C.POINTER(EngineCfg), C.POINTER(vp)]
+        L.umoe_engine_set_layer.argtypes = [vp, i32, C.POINTER(LayerWeights)]
+        L.umoe_engine_set_globals.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
+        L.umoe_engine_prefill.argtypes = [vp, vp, vp, i32, vp]
+        L.umoe_engine_decode_step.argtypes = [vp, C.POINTER(DecodeIO), vp]
+        L.umoe_engine_capture.argtypes = [vp, C.POINTER(DecodeIO), vp]
+        L.umoe_engine_replay.argtypes = [vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().umoe_last_error()
+        raise UmoeError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,268 @@
+// mRoPE + KV append, and GQA attention over a preallocated KV cache (decode and causal prefill).
+//
+// Replaces transformers' Qwen2_5_VLAttention internals as used by the reference
+// (utils/UniMoE_Audio_model.py:204,228-237): apply_multimodal_rotary_pos_emb, DynamicCache.update
+// (an O(L) torch.cat per layer per step in the reference, model.py:353-354,1109) and the sdpa core.
+//
+// attn_kernel: grid = (key-splits, kv-heads, rows*nq).  A workgroup owns one (query token, kv head)
+// and one contiguous slice of the keys; its 4 waves take 16-key tiles round-robin:
+//   * QK^T on v_mfma_f32_16x16x32_bf16 with the K tile as the A operand (16 keys x 128 dims, read
+//     straight from HBM, 64 contiguous bytes per lane) and the GQA query group as the B operand
+//     (up to 16 query heads that share this kv head) -- KV is read once for all heads of the group;
+//   * online softmax per head in registers (keys live on lane-groups, heads on lanes);
+//   * P.V on the VALU: each lane owns two of the 128 value columns, V rows are read coalesced.
+// Partials (m, l, O) per split are merged by attn_combine_kernel (flash-decoding).
+// Roofline: HBM (KV bytes = 2 * L * KVH * hd * 2 B per row per layer).
+#include "umoe_common.h"
+
+// ------------------------------------------------------------------------------------ rope + append
+__global__ __launch_bounds__(256) void rope_append_kernel(const umoe_rope_args a) {
+    const int tok = blockIdx.x;
+    const int row = tok / a.T;
+    const int hd = a.hd, half = hd >> 1;
+    const int nheads = a.H + 2 * a.KVH;
+    const int ld = nheads * hd;
+    const uint16_t* src = a.qkv + (size_t)tok * ld;
+    const int slot = a.kv_pos[tok];
+    const int p0 = a.pos3[tok], p1 = a.pos3[a.n_tok + tok], p2 = a.pos3[2 * a.n_tok + tok];
+    // work items: (head, i) for i < half, rotating q and k heads; v heads are copied
+    for (int w = threadIdx.x; w < nheads * half; w += blockDim.x) {
+        const int head = w / half, i = w - head * half;
+        const uint16_t* hs = src + head * hd;
+        if (head < a.H + a.KVH) {
+            const int pos = (i < a.sec0) ? p0 : (i < a.sec0 + a.sec1 ? p1 : p2);
+            const float c = bf2f(a.cos_tab[(size_t)pos * half + i]);
+            const float s = bf2f(a.sin_tab[(size_t)pos * half + i]);
+            const float x1 = bf2f(hs[i]), x2 = bf2f(hs[i + half]);
+            // q*cos + rotate_half(q)*sin, every op rounded to bf16 as torch does on bf16 tensors
+            const uint16_t o1 = f2bf(rbf(x1 * c) + rbf(-x2 * s));
+            const uint16_t o2 = f2bf(rbf(x2 * c) + rbf(x1 * s));
+            if (head < a.H) {
+                uint16_t* d = a.q_out + (size_t)tok * a.H * hd + head * hd;
+                d[i] = o1;
+                d[i + half] = o2;
+            } else {
+                const int kh = head - a.H;
+                uint16_t* d = a.k_cache + (((size_t)row * a.KVH + kh) * a.Lmax + slot) * hd;
+                d[i] = o1;
+                d[i + half] = o2;
+            }
+        } else {
+            const int vh = head - a.H - a.KVH;
+            uint16_t* d = a.v_cache + (((size_t)row * a.KVH + vh) * a.Lmax + slot) * hd;
+            d[i] = hs[i];
+            d[i + half] = hs[i + half];
+        }
+    }
+}
+
+extern "C" int umoe_qkv_mrope_kvappend(const umoe_rope_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->qkv && a->cos_tab && a->sin_tab && a->pos3 && a->kv_pos && a->q_out && a->k_cache && a->v_cache,
+                 "umoe_qkv_mrope_kvappend: null argument");
+    UMOE_REQUIRE(a->hd % 2 == 0 && a->sec0 + a->sec1 + a->sec2 == a->hd / 2 && a->T >= 1 && a->n_tok % a->T == 0,
+                 "umoe_qkv_mrope_kvappend: bad head_dim/sections/T (hd=%d sections=%d+%d+%d T=%d)", a->hd, a->sec0,
+                 a->sec1, a->sec2, a->T);
+    if (a->n_tok == 0) return 0;
+    rope_append_kernel<<<dim3((unsigned)a->n_tok), 256, 0, (hipStream_t)stream>>>(*a);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ attention
+// hd == 128 only (4 MFMA k-steps; lane owns 2 value columns).
+__global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
+    constexpr int HD = 128;
+    __shared__ float p_lds[4][16][16];       // per wave: [key in tile][head]
+    __shared__ float al_lds[4][16];          // per wave: rescale factor per head
+    __shared__ float red_o[4][16][HD];       // cross-wave merge
+    __shared__ float red_ml[4][16][2];
+    const int split = blockIdx.x, kvh = blockIdx.y, qi = blockIdx.z;
+    const int row = qi / a.nq, t = qi - row * a.nq;
+    const int G = a.H / a.KVH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h4 = lane >> 4, c = lane & 15;
+
+    const int kbeg_all = a.kv_start[row];
+    const int kend_all = a.q_pos0[row] + t + 1;  // exclusive
+    const int nkeys = max(kend_all - kbeg_all, 0);
+    int chunk = (nkeys + a.splits - 1) / a.splits;
+    chunk = (chunk + 15) & ~15;
+    const int kbeg = kbeg_all + split * chunk;
+    const int kend = min(kbeg + chunk, kend_all);
+
+    const uint16_t* Kc = a.k_cache + ((size_t)row * a.KVH + kvh) * a.Lmax * HD;
+    const uint16_t* Vc = a.v_cache + ((size_t)row * a.KVH + kvh) * a.Lmax * HD;
+
+    // Q fragments (B operand): lane (h4, c = head in group) holds q[c][h4*32 + kb*8 .. +8]
+    bf16x8_t qf[4];
+    {
+        const uint16_t* qp = a.q + ((size_t)qi * a.H + kvh * G + c) * HD + h4 * 32;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (c < G) u = ld16(qp + kb * 8);
+            qf[kb] = __builtin_bit_cast(bf16x8_t, u);
+        }
+    }
+    // running state: this lane's head is c (for m, l); O for ALL heads of the group on 2 columns
+    float m_run = -INFINITY, l_run = 0.f;
+    float o[16][2];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) o[g][0] = o[g][1] = 0.f;
+
+    for (int k0 = kbeg + wave * 16; k0 < kend; k0 += 64) {
+        // S tile: D[key = 4*h4 + r][head = c]
+        f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+        {
+            const int key = min(k0 + c, kend - 1);  // A operand row = lane&15 -> key index
+            const uint16_t* kp = Kc + (size_t)key * HD + h4 * 32;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ld16(kp + kb * 8)), qf[kb],
+                                                              sacc, 0, 0, 0);
+        }
+        float sv[4];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = k0 + 4 * h4 + r;
+            sv[r] = (key < kend) ? sacc[r] * a.scale : -INFINITY;
+            tmax = fmaxf(tmax, sv[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = (sv[r] == -INFINITY) ? 0.f : __expf(sv[r] - m_new);
+            psum += pv;
+            p_lds[wave][4 * h4 + r][c] = pv;
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (h4 == 0) al_lds[wave][c] = alpha;
+        __builtin_amdgcn_wave_barrier();
+        // P.V: lane owns value columns 2*lane, 2*lane+1
+#pragma unroll
+        for (int g = 0; g < 16; ++g)
+            if (g < G) {
+                const float al = al_lds[wave][g];
+                o[g][0] *= al;
+                o[g][1] *= al;
+            }
+        const int nk = min(16, kend - k0);
+        for (int kk = 0; kk < nk; ++kk) {
+            const uint32_t vv = *reinterpret_cast<const uint32_t*>(Vc + (size_t)(k0 + kk) * HD + 2 * lane);
+            const float v0 = __uint_as_float(vv << 16), v1 = __uint_as_float(vv & 0xffff0000u);
+#pragma unroll
+            for (int g = 0; g < 16; ++g)
+                if (g < G) {
+                    const float pv = p_lds[wave][kk][g];
+                    o[g][0] += pv * v0;
+                    o[g][1] += pv * v1;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- merge the 4 waves --------------------------------------------------------------------
+    if (h4 == 0) {
+        red_ml[wave][c][0] = m_run;
+        red_ml[wave][c][1] = l_run;
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g)
+        if (g < G) {
+            red_o[wave][g][2 * lane] = o[g][0];
+            red_o[wave][g][2 * lane + 1] = o[g][1];
+        }
+    __syncthreads();
+    // thread -> (head g, 8 columns): 16 heads x 16 column-groups
+    const int g = tid >> 4, cg = tid & 15;
+    if (g < G) {
+        float mm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, red_ml[w][g][0]);
+        float L = 0.f, acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = red_ml[w][g][0];
+            const float sc = (mw == -INFINITY) ? 0.f : __expf(mw - mm);
+            L += sc * red_ml[w][g][1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += sc * red_o[w][g][cg * 8 + j];
+        }
+        const int head = kvh * G + g;
+        float* po = a.part_o + (((size_t)qi * a.H + head) * a.splits + split) * HD + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) po[j] = acc[j];
+        if (cg == 0) {
+            float* pm = a.part_ml + (((size_t)qi * a.H + head) * a.splits + split) * 2;
+            pm[0] = mm;
+            pm[1] = L;
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void attn_combine_kernel(const umoe_attn_args a) {
+    constexpr int HD = 128;
+    const int head = blockIdx.x, qi = blockIdx.y, d = threadIdx.x;
+    const float* pm = a.part_ml + ((size_t)qi * a.H + head) * a.splits * 2;
+    const float* po = a.part_o + ((size_t)qi * a.H + head) * a.splits * HD;
+    float mm = -INFINITY;
+    for (int s = 0; s < a.splits; ++s) mm = fmaxf(mm, pm[2 * s]);
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < a.splits; ++s) {
+        const float ms = pm[2 * s];
+        const float sc = (ms == -INFINITY) ? 0.f : __expf(ms - mm);
+        L += sc * pm[2 * s + 1];
+        acc += sc * po[(size_t)s * HD + d];
+    }
+    a.out[((size_t)qi * a.H + head) * HD + d] = f2bf(L > 0.f ? acc / L : 0.f);
+}
+
+extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->q && a->k_cache && a->v_cache && a->kv_start && a->q_pos0 && a->part_o && a->part_ml && a->out,
+                 "umoe_attn_decode: null argument");
+    UMOE_REQUIRE(a->hd == 128, "umoe_attn_decode: head_dim must be 128 (got %d)", a->hd);
+    UMOE_REQUIRE(a->KVH > 0 && a->H % a->KVH == 0 && a->H / a->KVH <= 16,
+                 "umoe_attn_decode: GQA group must be <= 16 (H=%d KVH=%d)", a->H, a->KVH);
+    UMOE_REQUIRE(a->splits >= 1 && a->rows > 0 && a->nq > 0, "umoe_attn_decode: bad splits/rows/nq");
+    UMOE_REQUIRE((long)a->rows * a->nq <= 65535 * 1L * 65535, "umoe_attn_decode: too many queries");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nqi = (unsigned)(a->rows * a->nq);
+    // grid.z <= 65535: fold large query counts
+    UMOE_REQUIRE(nqi <= 65535u * 32u, "umoe_attn_decode: too many query tokens (%u)", nqi);
+    if (nqi <= 65535u) {
+        attn_kernel<<<dim3((unsigned)a->splits, (unsigned)a->KVH, nqi), 256, 0, s>>>(*a);
+        UMOE_LAUNCH_CHECK();
+        attn_combine_kernel<<<dim3((unsigned)a->H, nqi), 128, 0, s>>>(*a);
+        UMOE_LAUNCH_CHECK();
+    } else {
+        // process row by row (prefill with very long prompts)
+        for (int r = 0; r < a->rows; ++r) {
+            umoe_attn_args b = *a;
+            b.rows = 1;
+            b.q = a->q + (size_t)r * a->nq * a->H * a->hd;
+            b.out = a->out + (size_t)r * a->nq * a->H * a->hd;
+            b.kv_start = a->kv_start + r;
+            b.q_pos0 = a->q_pos0 + r;
+            b.k_cache = a->k_cache + (size_t)r * a->KVH * a->Lmax * a->hd;
+            b.v_cache = a->v_cache + (size_t)r * a->KVH * a->Lmax * a->hd;
+            b.part_o = a->part_o;
+            b.part_ml = a->part_ml;
+            UMOE_REQUIRE(a->nq <= 65535, "umoe_attn_decode: nq too large");
+            attn_kernel<<<dim3((unsigned)a->splits, (unsigned)a->KVH, (unsigned)a->nq), 256, 0, s>>>(b);
+            UMOE_LAUNCH_CHECK();
+            attn_combine_kernel<<<dim3((unsigned)a->H, (unsigned)a->nq), 128, 0, s>>>(b);
+            UMOE_LAUNCH_CHECK();
+        }
+    }
+    return 0;
+}

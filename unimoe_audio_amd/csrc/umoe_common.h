@@ -1,0 +1,110 @@
+// Shared device/host helpers for libumoe_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "umoe.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;  // one MFMA 16x16x32 operand fragment
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define UMOE_MAXE 16  // router columns kept on lanes 0..15
+
+// ---- error plumbing ----------------------------------------------------------------------
+void umoe_set_error(const char* fmt, ...);
+#define UMOE_HIP(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            umoe_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -2;                                                                      \
+        }                                                                                   \
+    } while (0)
+#define UMOE_REQUIRE(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            umoe_set_error(__VA_ARGS__); \
+            return -1;                   \
+        }                                \
+    } while (0)
+#define UMOE_LAUNCH_CHECK() UMOE_HIP(hipGetLastError())
+
+// ---- bf16 <-> f32 (round to nearest even; NaN stays NaN) -----------------------------------
+__host__ __device__ __forceinline__ float bf2f(uint16_t h) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)h) << 16;
+    return c.f;
+}
+__host__ __device__ __forceinline__ uint16_t f2bf(float f) {
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__host__ __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ float round_t(float v, int is_bf16) { return is_bf16 ? rbf(v) : v; }
+
+// 8 bf16 <-> 8 floats via one 16-byte vector
+struct alignas(16) bf16x8_raw { uint16_t v[8]; };
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+__device__ __forceinline__ void unpack8(uint4 u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 u;
+    u.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
+    u.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
+    u.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
+    u.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    return u;
+}
+
+// ---- deterministic exp: the SAME fp64 fma sequence as oracle/router_oracle.c (exp_det) ------
+// Written independently of the oracle source; the op sequence is the arithmetic contract
+// documented in DESIGN.md ("router arithmetic").
+__device__ __forceinline__ float umoe_exp_det(float xf) {
+    if (!(xf > -110.0f)) return (xf != xf) ? xf : 0.0f;
+    if (xf > 88.0f) xf = 88.0f + (xf - xf);
+    const double x = (double)xf;
+    const double k = rint(x * 1.4426950408889634074);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const long long ki = (long long)k;
+    const double scale = __longlong_as_double((ki + 1023) << 52);
+    return (float)(p * scale);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

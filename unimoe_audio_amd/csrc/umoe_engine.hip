@@ -1,0 +1,461 @@
+// Decode engine: owns the KV cache + workspace and enqueues prefill / one whole decode step
+// (36 x [RMSNorm+QKV GEMM, mRoPE+append, attention, o_proj+residual, RMSNorm+router, dispatch,
+// grouped gate/up SwiGLU, grouped down, combine+residual] + head GEMM + CFG/sampler + EOS/delay
+// bookkeeping) from ONE host call, with no host<->device synchronisation inside the step.
+// A captured hipGraph replays the step; every step-dependent scalar lives in device memory.
+//
+// Restates the control flow of the reference's generate()/_decoder_step()
+// (utils/UniMoE_Audio_model.py:918-1231) and Qwen2_5_VLMoEDecoderLayer.forward (:210-256).
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "umoe_common.h"
+
+namespace {
+
+struct LayerDev {
+    umoe_layer_weights w;
+    std::vector<const uint16_t*> exp_gu, exp_dn, sh_gu, sh_dn;
+    bool set = false;
+};
+
+struct Carver {
+    char* base = nullptr;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+}  // namespace
+
+struct umoe_engine {
+    umoe_engine_cfg c;
+    std::vector<LayerDev> layers;
+    const uint16_t *final_norm = nullptr, *codec_emb = nullptr, *codec_head_w = nullptr, *cos_tab = nullptr,
+                   *sin_tab = nullptr;
+    int max_pos = 0;
+    int max_delay = 0;
+    // device memory owned by the engine
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int cap_tok = 0;  // tokens the workspace is sized for
+    uint16_t *k_cache = nullptr, *v_cache = nullptr;
+    int32_t* d_delay = nullptr;
+    umoe_group_t* d_groups = nullptr;  // per layer: [qkv 1][o 1][gateup G][down G]; then [head 1]
+    int groups_for_tok = -1;
+    // carved buffers
+    uint16_t *x = nullptr, *x1 = nullptr, *h2 = nullptr, *qkv = nullptr, *q_r = nullptr, *attn_out = nullptr,
+             *hbuf = nullptr, *ybuf = nullptr;
+    float *part_o = nullptr, *part_ml = nullptr, *logits = nullptr;
+    int32_t *pos3 = nullptr, *kv_pos = nullptr, *q_pos0 = nullptr, *kv_start = nullptr, *tok_in = nullptr,
+            *valid_count = nullptr, *eng_state = nullptr;
+    void* r_logits = nullptr;
+    int64_t *r_topk = nullptr, *pred = nullptr;
+    int32_t *r_sel = nullptr, *r_mask = nullptr, *counts = nullptr, *offsets = nullptr, *slot_token = nullptr,
+            *slot_of = nullptr;
+    float *r_routing = nullptr, *r_global = nullptr, *r_moe = nullptr;
+    // per-layer router statistics kept for parity tests (last step): [layers][rows][E]
+    int32_t* all_mask = nullptr;
+    int64_t* all_topk = nullptr;
+    int T_prompt = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int groups_per_layer() const { return 2 + 2 * (c.n_real + c.n_fix); }
+};
+
+static size_t carve(umoe_engine* e, int n_tok, char* base) {
+    const umoe_engine_cfg& c = e->c;
+    const int D = c.hidden, QKV = (c.heads + 2 * c.kv_heads) * c.head_dim, HD = c.heads * c.head_dim;
+    const int E = c.n_dyn + c.n_fix, G = c.n_real + c.n_fix;
+    const int Imax = c.inter_dyn > c.inter_shared ? c.inter_dyn : c.inter_shared;
+    const size_t slots = (size_t)n_tok * G;
+    const int splits = c.attn_splits > 1 ? c.attn_splits : 1;
+    Carver k;
+    k.base = base;
+    e->x = k.take<uint16_t>((size_t)n_tok * D);
+    e->x1 = k.take<uint16_t>((size_t)n_tok * D);
+    e->h2 = k.take<uint16_t>((size_t)n_tok * D);
+    e->qkv = k.take<uint16_t>((size_t)n_tok * QKV);
+    e->q_r = k.take<uint16_t>((size_t)n_tok * HD);
+    e->attn_out = k.take<uint16_t>((size_t)n_tok * HD);
+    e->hbuf = k.take<uint16_t>(slots * Imax);
+    e->ybuf = k.take<uint16_t>(slots * D);
+    e->part_o = k.take<float>((size_t)n_tok * c.heads * splits * c.head_dim);
+    e->part_ml = k.take<float>((size_t)n_tok * c.heads * splits * 2);
+    e->logits = k.take<float>((size_t)c.rows * c.codec_channels * c.codec_vocab);
+    e->pos3 = k.take<int32_t>((size_t)3 * n_tok);
+    e->kv_pos = k.take<int32_t>(n_tok);
+    e->q_pos0 = k.take<int32_t>(c.rows);
+    e->kv_start = k.take<int32_t>(c.rows);
+    e->valid_count = k.take<int32_t>(c.rows);
+    e->eng_state = k.take<int32_t>(8);
+    e->tok_in = k.take<int32_t>((size_t)c.rows * c.codec_channels);
+    e->r_logits = k.take<float>((size_t)n_tok * E);
+    e->r_topk = k.take<int64_t>(n_tok);
+    e->pred = k.take<int64_t>((size_t)c.rows * c.codec_channels);
+    e->r_sel = k.take<int32_t>((size_t)n_tok * c.n_dyn);
+    e->r_mask = k.take<int32_t>((size_t)n_tok * E);
+    e->counts = k.take<int32_t>(UMOE_MAXE);
+    e->offsets = k.take<int32_t>(UMOE_MAXE + 1);
+    e->slot_token = k.take<int32_t>((size_t)n_tok * c.n_real + 1);
+    e->slot_of = k.take<int32_t>((size_t)n_tok * c.n_real);
+    e->r_routing = k.take<float>((size_t)n_tok * c.n_dyn);
+    e->r_global = k.take<float>((size_t)n_tok * E);
+    e->r_moe = k.take<float>((size_t)n_tok * c.n_real);
+    e->all_mask = k.take<int32_t>((size_t)c.layers * c.rows * E);
+    e->all_topk = k.take<int64_t>((size_t)c.layers * c.rows);
+    return (k.off + 255) & ~(size_t)255;
+}
+
+static int ensure_workspace(umoe_engine* e, int n_tok) {
+    if (n_tok <= e->cap_tok) return 0;
+    // keep the small persistent scalars (valid_count, eng_state, kv_start) across a re-size: they are
+    // rewritten by prefill, which is the only caller that grows the workspace.
+    if (e->ws) UMOE_HIP(hipFree(e->ws));
+    e->ws = nullptr;
+    const size_t bytes = carve(e, n_tok, nullptr);
+    UMOE_HIP(hipMalloc(&e->ws, bytes));
+    UMOE_HIP(hipMemset(e->ws, 0, bytes));
+    carve(e, n_tok, e->ws);
+    e->ws_bytes = bytes;
+    e->cap_tok = n_tok;
+    e->groups_for_tok = -1;
+    return 0;
+}
+
+// group table for a pass over n_tok tokens
+static int build_groups(umoe_engine* e, int n_tok, hipStream_t s) {
+    if (e->groups_for_tok == n_tok) return 0;
+    const umoe_engine_cfg& c = e->c;
+    const int G = c.n_real + c.n_fix, GPL = e->groups_per_layer();
+    std::vector<umoe_group_t> h((size_t)c.layers * GPL + 1);
+    const int slots_routed = n_tok * c.n_real;
+    for (int l = 0; l < c.layers; ++l) {
+        const LayerDev& L = e->layers[l];
+        UMOE_REQUIRE(L.set, "umoe_engine: layer %d has no weights", l);
+        umoe_group_t* g = &h[(size_t)l * GPL];
+        memset(g, 0, sizeof(umoe_group_t) * GPL);
+        // qkv
+        g[0].w = L.w.qkv_w; g[0].bias = L.w.qkv_b; g[0].static_count = n_tok;
+        g[0].n_blocks = (c.heads + 2 * c.kv_heads) * c.head_dim / 16; g[0].k = c.hidden;
+        // o_proj
+        g[1].w = L.w.o_w; g[1].static_count = n_tok; g[1].n_blocks = c.hidden / 16; g[1].k = c.heads * c.head_dim;
+        umoe_group_t* gu = g + 2;
+        umoe_group_t* dn = g + 2 + G;
+        for (int x = 0; x < c.n_real; ++x) {
+            gu[x].w = L.exp_gu[x]; gu[x].rows = e->slot_token; gu[x].row_off = e->offsets + x; gu[x].count = e->counts + x;
+            gu[x].n_blocks = 2 * c.inter_dyn / 16; gu[x].k = c.hidden;
+            dn[x].w = L.exp_dn[x]; dn[x].row_off = e->offsets + x; dn[x].count = e->counts + x;
+            dn[x].n_blocks = c.hidden / 16; dn[x].k = c.inter_dyn;
+        }
+        for (int i = 0; i < c.n_fix; ++i) {
+            const int x = c.n_real + i;
+            gu[x].w = L.sh_gu[i]; gu[x].static_count = n_tok; gu[x].out_row_base = slots_routed + i * n_tok;
+            gu[x].n_blocks = 2 * c.inter_shared / 16; gu[x].k = c.hidden;
+            dn[x].w = L.sh_dn[i]; dn[x].static_count = n_tok; dn[x].a_row_base = slots_routed + i * n_tok;
+            dn[x].out_row_base = slots_routed + i * n_tok; dn[x].n_blocks = c.hidden / 16; dn[x].k = c.inter_shared;
+        }
+    }
+    umoe_group_t* hg = &h[(size_t)c.layers * GPL];
+    memset(hg, 0, sizeof(umoe_group_t));
+    hg->w = e->codec_head_w; hg->static_count = c.rows;
+    hg->n_blocks = ceil_div(c.codec_channels * c.codec_vocab, 16); hg->k = c.hidden;
+    UMOE_HIP(hipMemcpyAsync(e->d_groups, h.data(), h.size() * sizeof(umoe_group_t), hipMemcpyHostToDevice, s));
+    UMOE_HIP(hipStreamSynchronize(s));  // h is a stack-lifetime vector
+    e->groups_for_tok = n_tok;
+    return 0;
+}
+
+extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out) {
+    UMOE_REQUIRE(cfg && out, "umoe_engine_create: null argument");
+    UMOE_REQUIRE(cfg->head_dim == 128, "umoe_engine: head_dim must be 128 (got %d)", cfg->head_dim);
+    UMOE_REQUIRE(cfg->hidden % 128 == 0 && cfg->inter_dyn % 32 == 0 && cfg->inter_shared % 32 == 0,
+                 "umoe_engine: hidden %% 128 and intermediate sizes %% 32 must be 0");
+    UMOE_REQUIRE(cfg->rows > 0 && cfg->rows % 2 == 0 && cfg->rows / 2 <= 256, "umoe_engine: rows must be 2*batch, batch <= 256");
+    UMOE_REQUIRE(cfg->n_dyn + cfg->n_fix <= UMOE_MAXE && cfg->n_real <= cfg->n_dyn, "umoe_engine: bad expert counts");
+    UMOE_REQUIRE(cfg->ep_size <= 1, "umoe_engine: expert parallel runs through the Python EP path (ep_size=%d)", cfg->ep_size);
+    umoe_engine* e = new umoe_engine();
+    e->c = *cfg;
+    if (e->c.attn_splits < 1) e->c.attn_splits = 1;
+    e->layers.resize(cfg->layers);
+    const size_t kv = (size_t)cfg->layers * cfg->rows * cfg->kv_heads * cfg->Lmax * cfg->head_dim;
+    if (hipMalloc(&e->k_cache, kv * 2) != hipSuccess || hipMalloc(&e->v_cache, kv * 2) != hipSuccess ||
+        hipMalloc(&e->d_delay, sizeof(int32_t) * cfg->codec_channels) != hipSuccess ||
+        hipMalloc(&e->d_groups, sizeof(umoe_group_t) * ((size_t)cfg->layers * e->groups_per_layer() + 1)) != hipSuccess) {
+        umoe_set_error("umoe_engine_create: hipMalloc failed (KV cache %zu bytes)", kv * 4);
+        umoe_engine_destroy(e);
+        return -2;
+    }
+    hipMemset(e->k_cache, 0, kv * 2);
+    hipMemset(e->v_cache, 0, kv * 2);
+    if (ensure_workspace(e, cfg->rows)) {
+        umoe_engine_destroy(e);
+        return -2;
+    }
+    *out = e;
+    return 0;
+}
+
+extern "C" void umoe_engine_destroy(umoe_engine* e) {
+    if (!e) return;
+    if (e->exec) hipGraphExecDestroy(e->exec);
+    if (e->graph) hipGraphDestroy(e->graph);
+    if (e->ws) hipFree(e->ws);
+    if (e->k_cache) hipFree(e->k_cache);
+    if (e->v_cache) hipFree(e->v_cache);
+    if (e->d_delay) hipFree(e->d_delay);
+    if (e->d_groups) hipFree(e->d_groups);
+    delete e;
+}
+
+extern "C" int umoe_engine_set_layer(umoe_engine* e, int layer, const umoe_layer_weights* w) {
+    UMOE_REQUIRE(e && w && layer >= 0 && layer < e->c.layers, "umoe_engine_set_layer: bad layer %d", layer);
+    LayerDev& L = e->layers[layer];
+    L.w = *w;
+    L.exp_gu.assign(w->exp_gu, w->exp_gu + e->c.n_real);
+    L.exp_dn.assign(w->exp_dn, w->exp_dn + e->c.n_real);
+    L.sh_gu.assign(w->sh_gu, w->sh_gu + e->c.n_fix);
+    L.sh_dn.assign(w->sh_dn, w->sh_dn + e->c.n_fix);
+    L.set = true;
+    e->groups_for_tok = -1;
+    return 0;
+}
+
+extern "C" int umoe_engine_set_globals(umoe_engine* e, const uint16_t* final_norm, const uint16_t* codec_emb,
+                                       const uint16_t* codec_head_w, const uint16_t* cos_tab, const uint16_t* sin_tab,
+                                       int max_pos, const int32_t* delay_pattern_host) {
+    UMOE_REQUIRE(e && final_norm && codec_emb && codec_head_w && cos_tab && sin_tab && delay_pattern_host,
+                 "umoe_engine_set_globals: null argument");
+    e->final_norm = final_norm; e->codec_emb = codec_emb; e->codec_head_w = codec_head_w;
+    e->cos_tab = cos_tab; e->sin_tab = sin_tab; e->max_pos = max_pos;
+    UMOE_HIP(hipMemcpy(e->d_delay, delay_pattern_host, sizeof(int32_t) * e->c.codec_channels, hipMemcpyHostToDevice));
+    e->max_delay = 0;
+    for (int i = 0; i < e->c.codec_channels; ++i) e->max_delay = delay_pattern_host[i] > e->max_delay ? delay_pattern_host[i] : e->max_delay;
+    e->groups_for_tok = -1;
+    return 0;
+}
+
+extern "C" size_t umoe_engine_workspace_bytes(const umoe_engine* e) { return e ? e->ws_bytes : 0; }
+
+// ------------------------------------------------------------------------------------ one layer
+static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStream_t s) {
+    const umoe_engine_cfg& c = e->c;
+    const int D = c.hidden, HD = c.heads * c.head_dim, QKV = (c.heads + 2 * c.kv_heads) * c.head_dim;
+    const int G = c.n_real + c.n_fix, GPL = e->groups_per_layer(), E = c.n_dyn + c.n_fix;
+    const int Imax = c.inter_dyn > c.inter_shared ? c.inter_dyn : c.inter_shared;
+    const LayerDev& L = e->layers[l];
+    const umoe_group_t* g = e->d_groups + (size_t)l * GPL;
+    const size_t kv_l = (size_t)l * c.rows * c.kv_heads * c.Lmax * c.head_dim;
+    int rc;
+    // 1. RMSNorm + QKV (+bias)                                   model.py:227, Qwen2_5_VLAttention q/k/v_proj
+    umoe_gemm_args a{};
+    a.groups = g; a.num_groups = 1; a.max_rows = n_tok; a.max_n_blocks = QKV / 16; a.max_k = D;
+    a.a = e->x; a.lda = D; a.norm_w = L.w.in_norm; a.rms_eps = c.rms_eps; a.out = e->qkv; a.ldo = QKV; a.n_valid = QKV;
+    a.prologue = UMOE_PRO_RMSNORM; a.epilogue = UMOE_EPI_BF16;
+    if ((rc = umoe_grouped_gemm(&a, s))) return rc;
+    // 2. mRoPE + KV append
+    umoe_rope_args r{};
+    r.qkv = e->qkv; r.cos_tab = e->cos_tab; r.sin_tab = e->sin_tab; r.pos3 = e->pos3; r.kv_pos = e->kv_pos;
+    r.n_tok = n_tok; r.T = T; r.H = c.heads; r.KVH = c.kv_heads; r.hd = c.head_dim;
+    r.sec0 = c.mrope0; r.sec1 = c.mrope1; r.sec2 = c.mrope2; r.Lmax = c.Lmax;
+    r.q_out = e->q_r; r.k_cache = e->k_cache + kv_l; r.v_cache = e->v_cache + kv_l;
+    if ((rc = umoe_qkv_mrope_kvappend(&r, s))) return rc;
+    // 3. attention
+    umoe_attn_args t{};
+    t.q = e->q_r; t.k_cache = r.k_cache; t.v_cache = r.v_cache; t.kv_start = e->kv_start; t.q_pos0 = e->q_pos0;
+    t.rows = c.rows; t.nq = T; t.H = c.heads; t.KVH = c.kv_heads; t.hd = c.head_dim; t.Lmax = c.Lmax; t.splits = splits;
+    t.scale = 1.0f / sqrtf((float)c.head_dim); t.part_o = e->part_o; t.part_ml = e->part_ml; t.out = e->attn_out;
+    if ((rc = umoe_attn_decode(&t, s))) return rc;
+    // 4. o_proj + residual                                        model.py:238
+    umoe_gemm_args o{};
+    o.groups = g + 1; o.num_groups = 1; o.max_rows = n_tok; o.max_n_blocks = D / 16; o.max_k = HD;
+    o.a = e->attn_out; o.lda = HD; o.resid = e->x; o.out = e->x1; o.ldo = D; o.n_valid = D;
+    o.prologue = UMOE_PRO_PLAIN; o.epilogue = UMOE_EPI_BF16_RESID;
+    if ((rc = umoe_grouped_gemm(&o, s))) return rc;
+    // 5. RMSNorm + router                                         model.py:240, core.py:246-291
+    umoe_router_args ra{};
+    ra.x = e->x1; ra.gate_w = L.w.gate_w; ra.norm_w = L.w.post_norm; ra.h_out = e->h2; ra.S = n_tok; ra.D = D;
+    ra.n_dyn = c.n_dyn; ra.n_real = c.n_real; ra.n_fix = c.n_fix; ra.logits_bf16 = 1; ra.top_p = c.top_p;
+    ra.fixed_top_k = c.fixed_top_k; ra.jitter_eps = c.jitter_eps; ra.rms_eps = c.rms_eps;
+    ra.logits_out = e->r_logits; ra.top_k = e->r_topk; ra.sel = e->r_sel; ra.expert_mask = e->r_mask;
+    ra.routing_w = e->r_routing; ra.global_w = e->r_global; ra.moe_w = e->r_moe;
+    if (n_tok == c.rows) {  // keep per-layer statistics of decode steps for the parity tests
+        ra.expert_mask = e->all_mask + (size_t)l * c.rows * E;
+        ra.top_k = e->all_topk + (size_t)l * c.rows;
+    }
+    if ((rc = umoe_router_fwd(&ra, s))) return rc;
+    // 6. ragged dispatch tables
+    if ((rc = umoe_dispatch_build(ra.expert_mask, n_tok, E, c.n_real, e->counts, e->offsets, e->slot_token, e->slot_of, s)))
+        return rc;
+    // 7. gate/up SwiGLU: routed (gathered rows) + shared (all rows) in one launch
+    umoe_gemm_args gu{};
+    gu.groups = g + 2; gu.num_groups = G; gu.max_rows = n_tok; gu.max_n_blocks = 2 * Imax / 16; gu.max_k = D;
+    gu.a = e->h2; gu.lda = D; gu.out = e->hbuf; gu.ldo = Imax; gu.n_valid = Imax;
+    gu.prologue = UMOE_PRO_PLAIN; gu.epilogue = UMOE_EPI_SWIGLU;
+    if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
+    // 8. down projections
+    umoe_gemm_args dn{};
+    dn.groups = g + 2 + G; dn.num_groups = G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16; dn.max_k = Imax;
+    dn.a = e->hbuf; dn.lda = Imax; dn.out = e->ybuf; dn.ldo = D; dn.n_valid = D;
+    dn.prologue = UMOE_PRO_PLAIN; dn.epilogue = UMOE_EPI_BF16;
+    if ((rc = umoe_grouped_gemm(&dn, s))) return rc;
+    // 9. combine + residual -> next layer input                   core.py:488,342-351; model.py:242
+    umoe_combine_args cb{};
+    cb.y_slots = e->ybuf; cb.slot_of = e->slot_of; cb.moe_w = e->r_moe;
+    cb.y_shared = c.n_fix ? e->ybuf + (size_t)n_tok * c.n_real * D : nullptr; cb.global_w = e->r_global;
+    cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
+    return umoe_unpermute_combine_fwd(&cb, s);
+}
+
+// ------------------------------------------------------------------------------------ prefill
+extern "C" int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T,
+                                   umoe_stream_t stream) {
+    UMOE_REQUIRE(e && x && valid_host && T > 0, "umoe_engine_prefill: bad argument");
+    const umoe_engine_cfg& c = e->c;
+    UMOE_REQUIRE(T < c.Lmax, "umoe_engine_prefill: prompt length %d does not fit Lmax %d", T, c.Lmax);
+    UMOE_REQUIRE(e->final_norm, "umoe_engine_prefill: globals not set");
+    hipStream_t s = (hipStream_t)stream;
+    const int n_tok = c.rows * T;
+    int rc;
+    if ((rc = ensure_workspace(e, n_tok))) return rc;
+    if ((rc = build_groups(e, n_tok, s))) return rc;
+    // positions: cumsum(mask)-1, masked -> 1 (model.py:1113-1114); kv slot = t; first valid slot per row
+    std::vector<int32_t> pos((size_t)3 * n_tok), kvp(n_tok), start(c.rows), q0(c.rows, 0), vc(c.rows);
+    for (int r = 0; r < c.rows; ++r) {
+        int cnt = 0, first = T;
+        for (int t = 0; t < T; ++t) {
+            const int v = valid_host[(size_t)r * T + t] != 0;
+            cnt += v;
+            if (v && first == T) first = t;
+            const int p = v ? cnt - 1 : 1;
+            for (int k = 0; k < 3; ++k) pos[(size_t)k * n_tok + r * T + t] = p;
+            kvp[r * T + t] = t;
+        }
+        // left padding assumed (tokenizer padding_side="left", mod.py:104): valid keys are [first, L)
+        for (int t = first; t < T; ++t)
+            UMOE_REQUIRE(valid_host[(size_t)r * T + t], "umoe_engine_prefill: row %d is not left-padded", r);
+        start[r] = first;
+        vc[r] = cnt;
+        UMOE_REQUIRE(cnt + c.Lmax - T < e->max_pos, "umoe_engine_prefill: rope table too short");
+    }
+    UMOE_HIP(hipMemcpyAsync(e->pos3, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, s));
+    UMOE_HIP(hipMemcpyAsync(e->kv_pos, kvp.data(), kvp.size() * 4, hipMemcpyHostToDevice, s));
+    UMOE_HIP(hipMemcpyAsync(e->kv_start, start.data(), start.size() * 4, hipMemcpyHostToDevice, s));
+    UMOE_HIP(hipMemcpyAsync(e->q_pos0, q0.data(), q0.size() * 4, hipMemcpyHostToDevice, s));
+    UMOE_HIP(hipMemcpyAsync(e->valid_count, vc.data(), vc.size() * 4, hipMemcpyHostToDevice, s));
+    UMOE_HIP(hipMemcpyAsync(e->x, x, (size_t)n_tok * c.hidden * 2, hipMemcpyDeviceToDevice, s));
+    UMOE_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+    for (int l = 0; l < c.layers; ++l)
+        if ((rc = run_layer(e, l, n_tok, T, 1, s))) return rc;
+    e->T_prompt = T;
+    // switch the group table to decode shape now, outside any later graph capture
+    if ((rc = build_groups(e, c.rows, s))) return rc;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ decode step
+// tokens[b][step] -> tok_in (CFG row doubling, model.py:945), positions / cache slots from device state
+__global__ void step_prep_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ state, int B, int C,
+                                 int Tmax, int T_prompt, int Lmax, const int32_t* __restrict__ valid_count,
+                                 int32_t* tok_in, int32_t* pos3, int32_t* kv_pos, int32_t* q_pos0) {
+    const int row = blockIdx.x, b = row >> 1;
+    const int step = state[4 * B];
+    const int n_dec = step - state[4 * B + 4];  // state[4B+4] = dec_step of the first decode call
+    const int ts = min(max(step, 0), Tmax - 1);
+    if ((int)threadIdx.x < C) tok_in[row * C + threadIdx.x] = tokens[((size_t)b * Tmax + ts) * C + threadIdx.x];
+    if (threadIdx.x == 0) {
+        const int rows = 2 * B;
+        const int slot = min(T_prompt + n_dec, Lmax - 1);
+        const int p = valid_count[row] + n_dec;
+        pos3[row] = p;
+        pos3[rows + row] = p;
+        pos3[2 * rows + row] = p;
+        kv_pos[row] = slot;
+        q_pos0[row] = slot;
+    }
+}
+
+static int enqueue_step(umoe_engine* e, const umoe_decode_io* io, hipStream_t s) {
+    const umoe_engine_cfg& c = e->c;
+    const int B = c.rows / 2, C = c.codec_channels, V = c.codec_vocab;
+    int rc;
+    step_prep_kernel<<<dim3((unsigned)c.rows), 64, 0, s>>>(io->tokens, io->state, B, C, c.Tmax, e->T_prompt, c.Lmax,
+                                                           e->valid_count, e->tok_in, e->pos3, e->kv_pos, e->q_pos0);
+    UMOE_LAUNCH_CHECK();
+    if ((rc = umoe_codec_embed_sum(e->tok_in, e->codec_emb, c.rows, C, V, c.hidden, e->x, s))) return rc;
+    for (int l = 0; l < c.layers; ++l)
+        if ((rc = run_layer(e, l, c.rows, 1, c.attn_splits, s))) return rc;
+    // final norm + codec head -> fp32 logits                       model.py:428, 982-983
+    umoe_gemm_args h{};
+    h.groups = e->d_groups + (size_t)c.layers * e->groups_per_layer(); h.num_groups = 1; h.max_rows = c.rows;
+    h.max_n_blocks = ceil_div(C * V, 16); h.max_k = c.hidden; h.a = e->x; h.lda = c.hidden; h.norm_w = e->final_norm;
+    h.rms_eps = c.rms_eps; h.out = e->logits; h.ldo = C * V; h.n_valid = C * V;
+    h.prologue = UMOE_PRO_RMSNORM; h.epilogue = UMOE_EPI_F32;
+    if ((rc = umoe_grouped_gemm(&h, s))) return rc;
+    umoe_sample_args sa{};
+    sa.logits = e->logits; sa.B = B; sa.C = C; sa.V = V; sa.cfg_scale = io->cfg_scale; sa.temperature = io->temperature;
+    sa.top_p = io->top_p; sa.eos_mul = io->eos_mul; sa.top_k = io->top_k; sa.eos = c.eos; sa.min_tokens = io->min_tokens;
+    sa.step = io->state + 4 * B; sa.do_sample = io->do_sample; sa.seed = io->seed; sa.pred = e->pred;
+    if ((rc = umoe_codec_head_cfg_sample(&sa, s))) return rc;
+    return umoe_delay_step(e->pred, io->tokens, io->state, e->d_delay, B, C, c.Tmax, c.eos, c.pad, e->max_delay, s);
+}
+
+extern "C" int umoe_engine_decode_step(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream) {
+    UMOE_REQUIRE(e && io && io->tokens && io->state, "umoe_engine_decode_step: null argument");
+    UMOE_REQUIRE(e->T_prompt > 0, "umoe_engine_decode_step: prefill first");
+    return enqueue_step(e, io, (hipStream_t)stream);
+}
+
+extern "C" int umoe_engine_capture(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream) {
+    UMOE_REQUIRE(e && io && io->tokens && io->state, "umoe_engine_capture: null argument");
+    UMOE_REQUIRE(e->T_prompt > 0, "umoe_engine_capture: prefill first");
+    hipStream_t s = (hipStream_t)stream;
+    if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+    if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+    UMOE_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_step(e, io, s);
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s, &g);
+    if (rc) return rc;
+    UMOE_REQUIRE(ec == hipSuccess && g, "umoe_engine_capture: hipStreamEndCapture failed: %s", hipGetErrorString(ec));
+    e->graph = g;
+    UMOE_HIP(hipGraphInstantiate(&e->exec, e->graph, nullptr, nullptr, 0));
+    return 0;
+}
+
+extern "C" int umoe_engine_replay(umoe_engine* e, umoe_stream_t stream) {
+    UMOE_REQUIRE(e && e->exec, "umoe_engine_replay: no captured step");
+    UMOE_HIP(hipGraphLaunch(e->exec, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" const void* umoe_engine_buffer(umoe_engine* e, const char* name, size_t* bytes) {
+    if (!e || !name) return nullptr;
+    const umoe_engine_cfg& c = e->c;
+    const int E = c.n_dyn + c.n_fix;
+    struct Item { const char* n; const void* p; size_t b; };
+    const Item items[] = {
+        {"x", e->x, (size_t)c.rows * c.hidden * 2},
+        {"logits", e->logits, (size_t)c.rows * c.codec_channels * c.codec_vocab * 4},
+        {"pred", e->pred, (size_t)c.rows / 2 * c.codec_channels * 8},
+        {"all_mask", e->all_mask, (size_t)c.layers * c.rows * E * 4},
+        {"all_topk", e->all_topk, (size_t)c.layers * c.rows * 8},
+        {"router_logits", e->r_logits, (size_t)c.rows * E * 2},
+        {"k_cache", e->k_cache, (size_t)c.layers * c.rows * c.kv_heads * c.Lmax * c.head_dim * 2},
+        {"v_cache", e->v_cache, (size_t)c.layers * c.rows * c.kv_heads * c.Lmax * c.head_dim * 2},
+        {"counts", e->counts, (size_t)c.n_real * 4},
+    };
+    for (const Item& it : items)
+        if (!strcmp(it.n, name)) {
+            if (bytes) *bytes = it.b;
+            return it.p;
+        }
+    return nullptr;
+}

@@ -1,0 +1,299 @@
+// Weight-streaming grouped GEMM for M <= 16 rows per tile (decode) and ragged expert groups.
+//
+//   Y[rows(g), N(g)] = epilogue( prologue(A[rows(g), K(g)]) * W_g^T )
+//
+// Design (MI355X / gfx950):
+//  * weights are pre-packed (WP16, see include/umoe.h) so every wave-instruction reads one
+//    contiguous 1 KiB fragment straight into VGPRs -- no LDS round trip for the operand that is
+//    streamed once (cdna_hip_programming.md "GEMV / M <= 16 decode weights" row);
+//  * the 16-row activation tile is staged once per workgroup in LDS, 256-byte segments rotated by
+//    the row index so both the staging writes and the ds_read_b128 fragment reads are bank-conflict
+//    free (lane-group h reads K-quarter h: its bank offset is a multiple of 256 B);
+//  * v_mfma_f32_16x16x32_bf16 with the WEIGHTS as the A operand: each lane ends with 4 consecutive
+//    output features of one token -> one 8-byte store per lane;
+//  * the 4 waves of a workgroup split K; partial tiles are reduced through LDS in fixed order
+//    (bitwise reproducible, no atomics);
+//  * groups (routed experts with ragged row lists, shared experts, dense layers) share one launch:
+//    grid = (n-tiles, row-tiles, groups); row counts / offsets are read on device, so the host
+//    never synchronises on the router's result.
+// Roofline: HBM. Algorithmic bytes per launch = sum over groups hit of N*K*2 (+ activations).
+#include "umoe_common.h"
+
+// ------------------------------------------------------------------------------------ packing
+__global__ void pack_kernel(const uint16_t* __restrict__ Wa, const uint16_t* __restrict__ Wb, int N, int K, int KB,
+                            long total, uint16_t* __restrict__ out) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const long t = idx >> 6;
+    const int i = (int)(t % KB);
+    int nb = (int)(t / KB);
+    const uint16_t* W = Wa;
+    if (Wb) {  // interleaved gate/up blocks
+        W = (nb & 1) ? Wb : Wa;
+        nb >>= 1;
+    }
+    const int row = nb * 16 + (lane & 15);
+    const int col = (lane >> 4) * (K >> 2) + i * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < N) v = ld16(W + (size_t)row * K + col);
+    st16(out + idx * 8, v);
+}
+
+extern "C" size_t umoe_packed_elems(int N, int K) { return (size_t)ceil_div(N, 16) * 16 * (size_t)K; }
+
+extern "C" int umoe_pack_weight(const uint16_t* W, int N, int K, uint16_t* packed, umoe_stream_t stream) {
+    UMOE_REQUIRE(W && packed && N > 0 && K > 0 && K % 32 == 0, "umoe_pack_weight: need K %% 32 == 0 (N=%d K=%d)", N, K);
+    const int NB = ceil_div(N, 16), KB = K / 32;
+    const long total = (long)NB * KB * 64;
+    pack_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(W, nullptr, N, K, KB, total, packed);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int umoe_pack_gate_up(const uint16_t* Wg, const uint16_t* Wu, int I, int K, uint16_t* packed,
+                                 umoe_stream_t stream) {
+    UMOE_REQUIRE(Wg && Wu && packed && I > 0 && I % 16 == 0 && K % 32 == 0,
+                 "umoe_pack_gate_up: need I %% 16 == 0 and K %% 32 == 0 (I=%d K=%d)", I, K);
+    const int KB = K / 32;
+    const long total = (long)(2 * I / 16) * KB * 64;
+    pack_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(Wg, Wu, I, K, KB, total, packed);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ kernel
+__device__ __forceinline__ int lds_chunk_off(int QS, int h, int i, int m) {
+    // 16-byte chunk i of K-quarter h, row m: 256-byte segments, slot rotated by the row index
+    return h * QS + (i >> 4) * 256 + (((i & 15) + m) & 15) * 16;
+}
+
+template <int NT, int PRO, int EPI>
+__global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const umoe_group_t g = p.groups[blockIdx.z];
+    const int count = g.count ? *g.count : g.static_count;
+    const int row0 = blockIdx.y * 16;
+    if (row0 >= count) return;
+    const int nb0 = blockIdx.x * NT;
+    if (nb0 >= g.n_blocks) return;
+
+    const int K = g.k, KB = K >> 5;
+    const int QS = ((K >> 1) + 255) & ~255;  // bytes of one K-quarter of a row, padded to 256
+    const int RS = QS * 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int roff = g.row_off ? *g.row_off : 0;
+
+    // ---- stage the 16-row activation tile ------------------------------------------------
+    {
+        const int m = tid >> 4, sub = tid & 15;
+        const int r = row0 + m;
+        const bool valid = r < count;
+        long arow = 0;
+        if (valid) arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
+        const uint16_t* src = p.a + arow * (long)p.lda;
+        char* dst = smem + m * RS;
+        const int Q8 = KB;  // 16-byte chunks per quarter
+        float rs = 0.f;
+        if (PRO == UMOE_PRO_RMSNORM) {
+            float ss = 0.f;
+            if (valid)
+                for (int c = sub; c < 4 * Q8; c += 16) {
+                    float f[8];
+                    unpack8(ld16(src + c * 8), f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+                }
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            rs = rsqrtf(ss / (float)K + p.rms_eps);
+        }
+        for (int h = 0; h < 4; ++h)
+            for (int i = sub; i < Q8; i += 16) {
+                const int c = h * Q8 + i;
+                uint4 u = make_uint4(0, 0, 0, 0);
+                if (valid) {
+                    u = ld16(src + c * 8);
+                    if (PRO == UMOE_PRO_RMSNORM) {
+                        float f[8], w[8];
+                        unpack8(u, f);
+                        unpack8(ld16(p.norm_w + c * 8), w);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
+                        u = pack8(f);
+                    }
+                }
+                st16(dst + lds_chunk_off(QS, h, i, m), u);
+            }
+    }
+    __syncthreads();
+
+    // ---- stream weights, 4 waves split K ---------------------------------------------------
+    const int h = lane >> 4, mm = lane & 15;
+    const char* bbase = smem + mm * RS;
+    const int i0 = (KB * wave) >> 2, i1 = (KB * (wave + 1)) >> 2;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    f32x4_t acc[NT];
+    const u32x4_t* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        wp[t] = reinterpret_cast<const u32x4_t*>(g.w) + ((size_t)(nb0 + t) * KB) * 64 + lane;
+    }
+    constexpr int U = (NT == 1) ? 16 : 8;
+    for (int i = i0; i < i1; i += U) {
+        u32x4_t wv[NT][U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ii = min(i + u, i1 - 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wv[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)ii * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ii = i + u;
+            if (ii < i1) {
+                const uint4 bv = *reinterpret_cast<const uint4*>(bbase + lds_chunk_off(QS, h, ii, mm));
+                const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, bv);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[t][u]), bfrag,
+                                                                    acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- fixed-order cross-wave reduction --------------------------------------------------
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + 16 * RS);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x4_t s = red[t * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const f32x4_t v = red[(w * NT + t) * 64 + lane];
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+        acc[t] = s;
+    }
+
+    // ---- epilogue: lane (h, mm) owns features 4h..4h+3 of token row mm ---------------------
+    const int r = row0 + mm;
+    if (r >= count) return;
+    const long orow = (long)g.out_row_base + roff + r;
+    if (EPI == UMOE_EPI_SWIGLU) {
+        const int col = blockIdx.x * 16 + 4 * h;
+        uint16_t y[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gt = rbf(acc[0][j]);
+            const float up = rbf(acc[NT - 1][j]);
+            const float si = rbf(gt / (1.0f + expf(-gt)));
+            y[j] = f2bf(si * up);
+        }
+        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + col;
+        *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = (nb0 + t) * 16 + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[t][j] + ((g.bias && n + j < p.n_valid) ? g.bias[n + j] : 0.f);
+        if (EPI == UMOE_EPI_F32 || EPI == UMOE_EPI_F32_RAW) {
+            float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < p.n_valid) o[j] = (EPI == UMOE_EPI_F32) ? rbf(v[j]) : v[j];
+        } else {
+            uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + n;
+            uint16_t y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = rbf(v[j]);
+                if (EPI == UMOE_EPI_BF16_RESID && n + j < p.n_valid) x = bf2f(p.resid[orow * p.ldo + n + j]) + x;
+                y[j] = f2bf(x);
+            }
+            if (n + 3 < p.n_valid && (p.ldo & 3) == 0) {
+                *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < p.n_valid) o[j] = y[j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ launcher
+static size_t gemm_lds_bytes(int max_k, int NT) {
+    const size_t QS = (size_t)(((max_k >> 1) + 255) & ~255);
+    return 16 * 4 * QS + (size_t)4 * NT * 64 * 16;
+}
+
+template <int NT, int PRO, int EPI>
+static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
+    const size_t lds = gemm_lds_bytes(a->max_k, NT);
+    UMOE_REQUIRE(lds <= 160 * 1024, "umoe_grouped_gemm: K=%d needs %zu bytes of LDS (> 160 KiB)", a->max_k, lds);
+    static size_t configured = 0;  // per instantiation
+    if (lds > configured) {
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, PRO, EPI>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    dim3 grid((unsigned)ceil_div(a->max_n_blocks, NT), (unsigned)ceil_div(a->max_rows, 16), (unsigned)a->num_groups);
+    wstream_gemm<NT, PRO, EPI><<<grid, 256, lds, s>>>(*a);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->groups && a->a && a->out, "umoe_grouped_gemm: null argument");
+    UMOE_REQUIRE(a->num_groups > 0 && a->num_groups <= 65535, "umoe_grouped_gemm: bad num_groups %d", a->num_groups);
+    UMOE_REQUIRE(a->max_k > 0 && a->max_k % 32 == 0, "umoe_grouped_gemm: K must be a multiple of 32 (got %d)", a->max_k);
+    UMOE_REQUIRE(a->max_rows > 0 && a->max_n_blocks > 0, "umoe_grouped_gemm: empty problem");
+    UMOE_REQUIRE(ceil_div(a->max_rows, 16) <= 65535, "umoe_grouped_gemm: too many rows (%d)", a->max_rows);
+    UMOE_REQUIRE((a->lda & 7) == 0, "umoe_grouped_gemm: lda must be a multiple of 8 (16-byte rows)");
+    hipStream_t s = (hipStream_t)stream;
+    const int pro = a->prologue, epi = a->epilogue;
+    if (pro == UMOE_PRO_RMSNORM) {
+        UMOE_REQUIRE(a->norm_w, "umoe_grouped_gemm: RMSNorm prologue needs norm_w");
+        if (epi == UMOE_EPI_BF16) return launch_gemm<1, UMOE_PRO_RMSNORM, UMOE_EPI_BF16>(a, s);
+        if (epi == UMOE_EPI_F32) return launch_gemm<1, UMOE_PRO_RMSNORM, UMOE_EPI_F32>(a, s);
+        if (epi == UMOE_EPI_F32_RAW) return launch_gemm<1, UMOE_PRO_RMSNORM, UMOE_EPI_F32_RAW>(a, s);
+        UMOE_REQUIRE(false, "umoe_grouped_gemm: unsupported prologue/epilogue %d/%d", pro, epi);
+    }
+    UMOE_REQUIRE(pro == UMOE_PRO_PLAIN, "umoe_grouped_gemm: bad prologue %d", pro);
+    switch (epi) {
+        case UMOE_EPI_BF16: return launch_gemm<1, UMOE_PRO_PLAIN, UMOE_EPI_BF16>(a, s);
+        case UMOE_EPI_BF16_RESID:
+            UMOE_REQUIRE(a->resid, "umoe_grouped_gemm: residual epilogue needs resid");
+            return launch_gemm<1, UMOE_PRO_PLAIN, UMOE_EPI_BF16_RESID>(a, s);
+        case UMOE_EPI_SWIGLU:
+            UMOE_REQUIRE(a->max_n_blocks % 2 == 0, "umoe_grouped_gemm: SwiGLU needs gate/up block pairs");
+            return launch_gemm<2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
+        case UMOE_EPI_F32: return launch_gemm<1, UMOE_PRO_PLAIN, UMOE_EPI_F32>(a, s);
+        case UMOE_EPI_F32_RAW: return launch_gemm<1, UMOE_PRO_PLAIN, UMOE_EPI_F32_RAW>(a, s);
+    }
+    UMOE_REQUIRE(false, "umoe_grouped_gemm: bad epilogue %d", epi);
+}
+
+extern "C" int umoe_grouped_swiglu_fwd(const umoe_group_t* gateup_groups, const umoe_group_t* down_groups,
+                                       int num_groups, int max_rows, const uint16_t* x, int D, int I, uint16_t* h_ws,
+                                       uint16_t* y_slots, umoe_stream_t stream) {
+    umoe_gemm_args a{};
+    a.groups = gateup_groups; a.num_groups = num_groups; a.max_rows = max_rows; a.max_n_blocks = 2 * I / 16;
+    a.max_k = D; a.a = x; a.lda = D; a.out = h_ws; a.ldo = I; a.n_valid = I;
+    a.prologue = UMOE_PRO_PLAIN; a.epilogue = UMOE_EPI_SWIGLU;
+    int rc = umoe_grouped_gemm(&a, stream);
+    if (rc) return rc;
+    umoe_gemm_args b{};
+    b.groups = down_groups; b.num_groups = num_groups; b.max_rows = max_rows; b.max_n_blocks = D / 16;
+    b.max_k = I; b.a = h_ws; b.lda = I; b.out = y_slots; b.ldo = D; b.n_valid = D;
+    b.prologue = UMOE_PRO_PLAIN; b.epilogue = UMOE_EPI_BF16;
+    return umoe_grouped_gemm(&b, stream);
+}

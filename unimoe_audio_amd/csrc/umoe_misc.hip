@@ -1,0 +1,515 @@
+// Small fused kernels of the decode path: RMSNorm(+residual), unpermute+combine, codec embedding sum,
+// CFG + masks + sampler, on-device EOS/delay bookkeeping, RVQ lookup / nearest neighbour.
+// All are HBM/latency-bound elementwise or row-reduction kernels: 16-byte vector accesses, one
+// workgroup per row, no atomics, fixed summation orders.
+#include "umoe_common.h"
+
+static thread_local char g_err[512] = "";
+void umoe_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* umoe_last_error(void) { return g_err; }
+extern "C" int umoe_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------ block reduce
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------ rmsnorm
+// transformers Qwen2RMSNorm (reference model.py:206-207,307): w * bf16(x * rsqrt(mean(x^2) + eps))
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ r,
+                                                      const uint16_t* __restrict__ w, float eps, int D,
+                                                      uint16_t* __restrict__ sum_out, uint16_t* __restrict__ y) {
+    __shared__ float sh[4];
+    const size_t base = (size_t)blockIdx.x * D;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+        float f[8];
+        unpack8(ld16(x + base + c * 8), f);
+        if (r) {
+            float g[8];
+            unpack8(ld16(r + base + c * 8), g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = rbf(f[j] + g[j]);
+            if (sum_out) st16(sum_out + base + c * 8, pack8(f));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+    }
+    ss = block_sum_256(ss, sh);
+    const float rs = rsqrtf(ss / (float)D + eps);
+    for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+        float f[8], wv[8];
+        unpack8(ld16(x + base + c * 8), f);
+        if (r) {
+            float g[8];
+            unpack8(ld16(r + base + c * 8), g);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = rbf(f[j] + g[j]);
+        }
+        unpack8(ld16(w + c * 8), wv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = wv[j] * rbf(f[j] * rs);
+        st16(y + base + c * 8, pack8(f));
+    }
+}
+
+extern "C" int umoe_rmsnorm_residual_fwd(const uint16_t* x, const uint16_t* r, const uint16_t* w, float eps, int S,
+                                         int D, uint16_t* sum_out, uint16_t* y, umoe_stream_t stream) {
+    UMOE_REQUIRE(x && w && y && D % 8 == 0 && S >= 0, "umoe_rmsnorm_residual_fwd: bad argument (D=%d)", D);
+    if (S == 0) return 0;
+    rmsnorm_kernel<<<dim3((unsigned)S), 256, 0, (hipStream_t)stream>>>(x, r, w, eps, D, sum_out, y);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ combine
+// reference: einsum("se,sem->sm") core.py:488 (fp32 accumulate, one rounding), `final + current`
+// core.py:342, shared experts `expert(x) * w` then add core.py:349-351, residual model.py:242.
+__global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a) {
+    const int s = blockIdx.x;
+    const int E = a.n_dyn + a.n_fix;
+    for (int c = threadIdx.x; c < (a.D >> 3); c += 256) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int e = 0; e < a.n_real; ++e) {
+            const int slot = a.slot_of[(size_t)s * a.n_real + e];
+            if (slot >= 0) {
+                const float wgt = a.moe_w[(size_t)s * a.n_real + e];
+                float y[8];
+                unpack8(ld16(a.y_slots + (size_t)slot * a.D + c * 8), y);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += wgt * y[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j]);
+        if (a.y_shared)
+            for (int i = 0; i < a.n_fix; ++i) {
+                const float wgt = a.global_w[(size_t)s * E + a.n_dyn + i];
+                float y[8];
+                unpack8(ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8), y);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j] + rbf(y[j] * wgt));
+            }
+        if (a.resid) {
+            float r[8];
+            unpack8(ld16(a.resid + (size_t)s * a.D + c * 8), r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = r[j] + acc[j];
+        }
+        st16(a.out + (size_t)s * a.D + c * 8, pack8(acc));
+    }
+}
+
+extern "C" int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->y_slots && a->slot_of && a->moe_w && a->out && a->D % 8 == 0,
+                 "umoe_unpermute_combine_fwd: bad argument");
+    UMOE_REQUIRE(!a->y_shared || a->global_w, "umoe_unpermute_combine_fwd: shared experts need global_w");
+    if (a->S == 0) return 0;
+    combine_kernel<<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(*a);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ codec embedding
+__global__ __launch_bounds__(256) void codec_embed_kernel(const int32_t* __restrict__ tok, const uint16_t* __restrict__ emb,
+                                                          int C, int V, int D, uint16_t* __restrict__ out) {
+    const int r = blockIdx.x;
+    for (int c8 = threadIdx.x; c8 < (D >> 3); c8 += 256) {
+        float acc[8];
+        for (int ch = 0; ch < C; ++ch) {
+            int t = tok[(size_t)r * C + ch];
+            t = min(max(t, 0), V - 1);
+            float e[8];
+            unpack8(ld16(emb + ((size_t)ch * V + t) * D + c8 * 8), e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = (ch == 0) ? e[j] : rbf(acc[j] + e[j]);
+        }
+        st16(out + (size_t)r * D + c8 * 8, pack8(acc));
+    }
+}
+
+extern "C" int umoe_codec_embed_sum(const int32_t* tok, const uint16_t* emb, int rows, int C, int V, int D,
+                                    uint16_t* out, umoe_stream_t stream) {
+    UMOE_REQUIRE(tok && emb && out && D % 8 == 0 && C > 0, "umoe_codec_embed_sum: bad argument");
+    if (rows == 0) return 0;
+    codec_embed_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(tok, emb, C, V, D, out);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ CFG + sampler
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+// one workgroup per (b, c) row of V logits; dynamic LDS: 3 * V floats
+__global__ __launch_bounds__(256) void cfg_sample_kernel(const umoe_sample_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float shf[4];
+    __shared__ int shi[4];
+    __shared__ float bc_f;
+    __shared__ int bc_i;
+    float* x = reinterpret_cast<float*>(smem);
+    float* pr = x + a.V;
+    float* tmp = pr + a.V;
+    const int b = blockIdx.x / a.C, c = blockIdx.x - b * a.C, tid = threadIdx.x;
+    const int V = a.V, eos = a.eos;
+    const int step = a.step ? *a.step : 0;
+    const bool enable_eos = a.step ? (a.min_tokens < 0 || step >= a.min_tokens) : (a.enable_eos != 0);
+    const float* un = a.logits + ((size_t)(2 * b) * a.C + c) * V;
+    const float* co = a.logits + ((size_t)(2 * b + 1) * a.C + c) * V;
+    for (int v = tid; v < V; v += 256) {
+        float g = (a.cfg_scale != 0.f) ? co[v] + a.cfg_scale * (co[v] - un[v]) : co[v];
+        if (enable_eos) {
+            if (v > eos || (c >= 1 && v >= eos)) g = -INFINITY;
+        } else if (v >= eos) {
+            g = -INFINITY;
+        }
+        if (c == 0 && v == eos) g *= a.eos_mul;
+        x[v] = g;
+    }
+    __syncthreads();
+    auto block_argmax = [&](const float* arr) -> int {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int v = tid; v < V; v += 256) {
+            const float t = arr[v];
+            if (t > bv || (t == bv && v < bi)) {
+                bv = t;
+                bi = v;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            shf[tid >> 6] = bv;
+            shi[tid >> 6] = bi;
+        }
+        __syncthreads();
+        float rv = shf[0];
+        int ri = shi[0];
+        for (int w = 1; w < 4; ++w)
+            if (shf[w] > rv || (shf[w] == rv && shi[w] < ri)) {
+                rv = shf[w];
+                ri = shi[w];
+            }
+        __syncthreads();
+        return ri;
+    };
+    if (!a.do_sample || a.temperature == 0.0f) {
+        const int am = block_argmax(x);
+        if (tid == 0) a.pred[(size_t)b * a.C + c] = am;
+        return;
+    }
+    // temperature, EOS-unless-arg-max (model.py:884-891)
+    for (int v = tid; v < V; v += 256) x[v] = x[v] / a.temperature;
+    __syncthreads();
+    if (eos >= 0) {
+        const int top = block_argmax(x);
+        if (tid == 0 && top != eos) x[eos] = -INFINITY;
+        __syncthreads();
+    }
+    // top-k by rank (ties: lower index first) (model.py:893-897)
+    if (a.top_k > 0) {
+        for (int v = tid; v < V; v += 256) {
+            const float t = x[v];
+            int rank = 0;
+            for (int j = 0; j < V; ++j) {
+                const float u = x[j];
+                rank += (u > t) || (u == t && j < v);
+            }
+            tmp[v] = (rank < a.top_k) ? t : -INFINITY;
+        }
+        __syncthreads();
+        for (int v = tid; v < V; v += 256) x[v] = tmp[v];
+        __syncthreads();
+    }
+    auto block_softmax = [&](const float* in, float* out) {
+        float mx = -INFINITY;
+        for (int v = tid; v < V; v += 256) mx = fmaxf(mx, in[v]);
+        mx = wave_max(mx);
+        if ((tid & 63) == 0) shf[tid >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(shf[0], shf[1]), fmaxf(shf[2], shf[3]));
+        __syncthreads();
+        float sm = 0.f;
+        for (int v = tid; v < V; v += 256) {
+            const float e = expf(in[v] - mx);
+            out[v] = e;
+            sm += e;
+        }
+        sm = block_sum_256(sm, shf);
+        for (int v = tid; v < V; v += 256) out[v] = out[v] / sm;
+        __syncthreads();
+    };
+    if (a.top_p < 1.0f) {  // model.py:899-910
+        block_softmax(x, pr);
+        for (int v = tid; v < V; v += 256) {
+            const float t = pr[v];
+            float before = 0.f;
+            for (int j = 0; j < V; ++j) {
+                const float u = pr[j];
+                if ((u > t) || (u == t && j < v)) before += u;
+            }
+            tmp[v] = (before > a.top_p) ? -INFINITY : x[v];
+        }
+        __syncthreads();
+        for (int v = tid; v < V; v += 256) x[v] = tmp[v];
+        __syncthreads();
+    }
+    block_softmax(x, pr);
+    if (a.probs_out)
+        for (int v = tid; v < V; v += 256) a.probs_out[((size_t)b * a.C + c) * V + v] = pr[v];
+    // inverse-CDF draw in index order
+    if (tid == 0) {
+        const uint64_t h = mix64(a.seed ^ mix64(((uint64_t)(uint32_t)step << 32) | (uint32_t)blockIdx.x));
+        const float u = (float)((h >> 40) + 0.5) * (1.0f / 16777216.0f);
+        float cum = 0.f;
+        int pick = -1, last = 0;
+        for (int v = 0; v < V; ++v) {
+            const float p = pr[v];
+            if (p > 0.f) {
+                last = v;
+                cum += p;
+                if (cum > u) {
+                    pick = v;
+                    break;
+                }
+            }
+        }
+        a.pred[(size_t)b * a.C + c] = pick >= 0 ? pick : last;
+    }
+}
+
+extern "C" int umoe_codec_head_cfg_sample(const umoe_sample_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->logits && a->pred && a->B > 0 && a->C > 0 && a->V > 1, "umoe_codec_head_cfg_sample: bad argument");
+    UMOE_REQUIRE(a->eos >= 0 && a->eos < a->V, "umoe_codec_head_cfg_sample: eos %d outside vocabulary %d", a->eos, a->V);
+    const size_t lds = (size_t)3 * a->V * sizeof(float);
+    UMOE_REQUIRE(lds <= 60 * 1024, "umoe_codec_head_cfg_sample: vocabulary %d too large for the LDS sampler", a->V);
+    cfg_sample_kernel<<<dim3((unsigned)(a->B * a->C)), 256, lds, (hipStream_t)stream>>>(*a);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ delay / EOS step
+// state layout: eos_detected[B], countdown[B], finished[B], prefill_step[B], {step, max_tokens, all_done, bos_over}
+__global__ __launch_bounds__(256) void delay_step_kernel(int64_t* pred, int32_t* tokens, int32_t* state,
+                                                         const int32_t* __restrict__ delay, int B, int C, int Tmax,
+                                                         int eos, int pad, int md) {
+    int32_t* eos_det = state;
+    int32_t* countdown = state + B;
+    int32_t* finished = state + 2 * B;
+    const int32_t* prefill = state + 3 * B;
+    int32_t* sc = state + 4 * B;
+    __shared__ int s_all_done, s_bos_over;
+    const int tid = threadIdx.x;
+    const int dec_step = sc[0], max_tokens = sc[1];
+    // the reference checks `(eos_countdown == 0).all()` and `dec_step < max_tokens` at the loop head
+    if (tid == 0) {
+        int done = 1;
+        for (int b = 0; b < B; ++b) done &= (countdown[b] == 0);
+        s_all_done = done || (dec_step >= max_tokens);
+        s_bos_over = sc[3];
+    }
+    __syncthreads();
+    if (s_all_done) {
+        if (tid == 0) sc[2] = 1;
+        return;
+    }
+    const int cur = dec_step + 1;
+    __syncthreads();
+    if (tid < B) {  // per-sample EOS logic (model.py:1173-1183)
+        const int b = tid;
+        const int cd = countdown[b];
+        const bool active = cd != 0;
+        const bool trig = active && ((!eos_det[b] && pred[(size_t)b * C] == eos) || (cur >= max_tokens - md));
+        if (trig) eos_det[b] = 1;
+        if (trig && cd < 0) {
+            countdown[b] = md;
+            finished[b] = cur;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < B * C; i += blockDim.x) {  // forced EOS / PAD by delay pattern (model.py:1185-1196)
+        const int b = i / C, c = i - b * C;
+        const int cd = countdown[b];
+        if (cd > 0) {
+            const int after = md - cd;
+            if (after == delay[c]) pred[i] = eos;
+            else if (after > delay[c]) pred[i] = pad;
+        }
+    }
+    __syncthreads();
+    if (tid < B && countdown[tid] > 0) countdown[tid] -= 1;
+    if (tid == 0 && !s_bos_over) {  // model.py:1199-1200
+        int over = 1;
+        for (int b = 0; b < B; ++b) over &= (cur - prefill[b] >= md);
+        sc[3] = over;
+    }
+    __syncthreads();
+    // DecoderOutput.update_one (utils.py:290-298): keep prompt/BOS entries, fill the -1 ones
+    if (cur < Tmax)
+        for (int i = tid; i < B * C; i += blockDim.x) {
+            const int b = i / C, c = i - b * C;
+            int32_t* t = tokens + ((size_t)b * Tmax + cur) * C + c;
+            if (*t == -1) *t = (int32_t)pred[i];
+        }
+    __syncthreads();
+    if (tid == 0) {
+        sc[0] = dec_step + 1;
+        int done = 1;
+        for (int b = 0; b < B; ++b) done &= (countdown[b] == 0);
+        sc[2] = (done || (dec_step + 1 >= max_tokens)) ? 1 : 0;
+    }
+}
+
+extern "C" int umoe_delay_step(int64_t* pred, int32_t* tokens, int32_t* state, const int32_t* delay, int B, int C,
+                               int Tmax, int eos, int pad, int max_delay, umoe_stream_t stream) {
+    UMOE_REQUIRE(pred && tokens && state && delay && B > 0 && B <= 256 && C > 0, "umoe_delay_step: bad argument (B=%d)", B);
+    delay_step_kernel<<<1, 256, 0, (hipStream_t)stream>>>(pred, tokens, state, delay, B, C, Tmax, eos, pad, max_delay);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ RVQ
+// from_codes: z[d][t] = sum_q ( out_w[q][d][:] . codebook[q][codes[q][t]][:] + out_b[q][d] )
+// third-party descript-audio-codec 1.0.0 ResidualVectorQuantize.from_codes (reference call site
+// utils/UniMoE_Audio_utils.py:123).  codes [NQ][T], codebooks [NQ][CB][cd], out_w [NQ][Dl][cd], z [Dl][T].
+__global__ __launch_bounds__(256) void rvq_from_codes_kernel(const int32_t* __restrict__ codes, const float* __restrict__ cb,
+                                                             const float* __restrict__ ow, const float* __restrict__ ob,
+                                                             int NQ, int CB, int cd, int Dl, int T, float* __restrict__ z) {
+    const int t = blockIdx.x;
+    for (int d = threadIdx.x; d < Dl; d += blockDim.x) {
+        float acc = 0.f;
+        for (int q = 0; q < NQ; ++q) {
+            int code = codes[(size_t)q * T + t];
+            code = min(max(code, 0), CB - 1);
+            const float* e = cb + ((size_t)q * CB + code) * cd;
+            const float* w = ow + ((size_t)q * Dl + d) * cd;
+            float s = ob ? ob[(size_t)q * Dl + d] : 0.f;
+            for (int j = 0; j < cd; ++j) s += w[j] * e[j];
+            acc += s;
+        }
+        z[(size_t)d * T + t] = acc;
+    }
+}
+
+extern "C" int umoe_rvq_from_codes(const int32_t* codes, const float* codebooks, const float* out_w, const float* out_b,
+                                   int NQ, int CB, int cd, int Dl, int T, float* z, umoe_stream_t stream) {
+    UMOE_REQUIRE(codes && codebooks && out_w && z && NQ > 0 && CB > 0 && cd > 0 && Dl > 0, "umoe_rvq_from_codes: bad argument");
+    if (T == 0) return 0;
+    rvq_from_codes_kernel<<<dim3((unsigned)T), 256, 0, (hipStream_t)stream>>>(codes, codebooks, out_w, out_b, NQ, CB, cd, Dl, T, z);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// nearest: per level q: e = in_proj_q(resid) [cd]; code = argmax_j <normalize(e), normalize(cb_j)> (== arg-min of the
+// L2 distance between the normalised vectors; ties: lowest index); resid -= out_proj_q(cb[code]).
+// One workgroup per frame t; resid_ws [T][Dl] fp32 scratch.  z [Dl][T].
+__global__ __launch_bounds__(256) void rvq_nearest_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                          const float* __restrict__ iw, const float* __restrict__ ib,
+                                                          const float* __restrict__ ow, const float* __restrict__ ob,
+                                                          int NQ, int CB, int cd, int Dl, int T, int32_t* __restrict__ codes,
+                                                          float* __restrict__ resid_ws) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float shf[4];
+    __shared__ int shi[4];
+    float* e = reinterpret_cast<float*>(smem);  // [cd]
+    const int t = blockIdx.x, tid = threadIdx.x;
+    float* res = resid_ws + (size_t)t * Dl;
+    for (int d = tid; d < Dl; d += 256) res[d] = z[(size_t)d * T + t];
+    __syncthreads();
+    for (int q = 0; q < NQ; ++q) {
+        for (int j = tid; j < cd; j += 256) {
+            const float* w = iw + ((size_t)q * cd + j) * Dl;
+            float s = ib ? ib[(size_t)q * cd + j] : 0.f;
+            for (int d = 0; d < Dl; ++d) s += w[d] * res[d];
+            e[j] = s;
+        }
+        __syncthreads();
+        float en = 0.f;
+        for (int j = 0; j < cd; ++j) en += e[j] * e[j];
+        en = fmaxf(sqrtf(en), 1e-12f);
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = tid; j < CB; j += 256) {
+            const float* cj = cb + ((size_t)q * CB + j) * cd;
+            float dot = 0.f, cn = 0.f;
+            for (int i = 0; i < cd; ++i) {
+                dot += (e[i] / en) * cj[i];
+                cn += cj[i] * cj[i];
+            }
+            cn = fmaxf(sqrtf(cn), 1e-12f);
+            // -(|a|^2 - 2 a.b + |b|^2) with a, b normalised
+            const float sc = -(1.0f - 2.0f * dot / cn + 1.0f);
+            if (sc > bv || (sc == bv && j < bi)) {
+                bv = sc;
+                bi = j;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if ((tid & 63) == 0) {
+            shf[tid >> 6] = bv;
+            shi[tid >> 6] = bi;
+        }
+        __syncthreads();
+        float rv = shf[0];
+        int ri = shi[0];
+        for (int w = 1; w < 4; ++w)
+            if (shf[w] > rv || (shf[w] == rv && shi[w] < ri)) {
+                rv = shf[w];
+                ri = shi[w];
+            }
+        if (tid == 0) codes[(size_t)q * T + t] = ri;
+        const float* cq = cb + ((size_t)q * CB + ri) * cd;
+        for (int d = tid; d < Dl; d += 256) {
+            const float* w = ow + ((size_t)q * Dl + d) * cd;
+            float s = ob ? ob[(size_t)q * Dl + d] : 0.f;
+            for (int j = 0; j < cd; ++j) s += w[j] * cq[j];
+            res[d] -= s;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int umoe_rvq_nearest(const float* z, const float* codebooks, const float* in_w, const float* in_b,
+                                const float* out_w, const float* out_b, int NQ, int CB, int cd, int Dl, int T,
+                                int32_t* codes, float* resid_ws, umoe_stream_t stream) {
+    UMOE_REQUIRE(z && codebooks && in_w && out_w && codes && resid_ws && NQ > 0 && CB > 0 && cd > 0 && Dl > 0,
+                 "umoe_rvq_nearest: bad argument");
+    if (T == 0) return 0;
+    rvq_nearest_kernel<<<dim3((unsigned)T), 256, (size_t)cd * sizeof(float), (hipStream_t)stream>>>(
+        z, codebooks, in_w, in_b, out_w, out_b, NQ, CB, cd, Dl, T, codes, resid_ws);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}

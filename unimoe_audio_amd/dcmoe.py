@@ -1,0 +1,244 @@
+"""Drop-in mirror of the reference DCMoE module API, running on the HIP C-ABI.
+
+Same constructor config fields, sub-module / parameter names and 6-tuple return as the reference
+`UniMoEAudioSparseMoeBlock` (reference utils/UniMoE_Audio_core.py:196-358), so reference state dicts load
+unchanged:
+    gate.weight
+    fixed_real_moe.{i}.{gate,up,down}_proj.weight
+    dynamic_real_moe.deepspeed_moe.experts.deepspeed_experts.{e}.{gate,up,down}_proj.weight
+forward(hidden_states[B,T,D], attention_mask[B,T] | None, aux_balance_weight[B,T] | None)
+    -> (final_hidden_states, full_router_logits, dynamic_top_k, expert_mask, global_weight, aux_loss)
+
+The arithmetic runs in libumoe_hip.so (router -> ragged dispatch -> grouped SwiGLU GEMMs -> combine); there is
+no CPU implementation here: CPU tensors raise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+
+class _SwiGLUMLP(nn.Module):
+    def __init__(self, hidden_size: int, intermediate_size: int):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.intermediate_size = intermediate_size
+        self.gate_proj = nn.Linear(hidden_size, intermediate_size, bias=False)
+        self.up_proj = nn.Linear(hidden_size, intermediate_size, bias=False)
+        self.down_proj = nn.Linear(intermediate_size, hidden_size, bias=False)
+
+
+class AudioSharedExpertMLP(_SwiGLUMLP):
+    """reference core.py:16-31"""
+
+    def __init__(self, config):
+        super().__init__(config.hidden_size, config.shared_intermediate_size)
+
+
+class AudioDynamicExpertMLP(_SwiGLUMLP):
+    """reference core.py:34-49"""
+
+    def __init__(self, config):
+        super().__init__(config.hidden_size, config.dynamic_intermediate_size)
+
+
+class AudioExperts(nn.Module):
+    """reference core.py:392-416 (parameter container; the math runs in the grouped GEMM)."""
+
+    def __init__(self, config, num_local_experts: int, expert_group_name: Optional[str] = None):
+        super().__init__()
+        self.deepspeed_experts = nn.ModuleList([AudioDynamicExpertMLP(config) for _ in range(num_local_experts)])
+        self.num_local_experts = num_local_experts
+        for expert in self.deepspeed_experts:
+            for _, p in expert.named_parameters():
+                p.allreduce = False                       # core.py:401-404: reduce over the expert-DP group only
+                p.group_name = expert_group_name
+
+
+class AudioMOELayer(nn.Module):
+    """reference core.py:419-493 (dispatch/exchange/combine live in the HIP path and unimoe_audio_amd.ep)."""
+
+    def __init__(self, experts: nn.Module, ep_group_name, ep_size, num_local_experts: int):
+        super().__init__()
+        self.experts = experts
+        self.ep_group = None
+        self.ep_size = ep_size
+        self.ep_group_name = ep_group_name
+        self.num_local_experts = num_local_experts
+
+    def _set_ep_group(self, ep_group):
+        self.ep_group = ep_group
+
+
+class UniMoEAudioMoE(nn.Module):
+    """reference core.py:496-523"""
+
+    def __init__(self, config, num_experts: int, ep_size: int, moe_name_prefix: str = "ep_size"):
+        super().__init__()
+        self.enable_expert_tensor_parallelism = getattr(config, "enable_expert_tensor_parallelism", False)
+        self.ep_size = ep_size
+        self.num_experts = num_experts
+        self.expert_group_name = f"{moe_name_prefix}_{self.ep_size}"
+        self.num_local_experts = num_experts // ep_size
+        self.deepspeed_moe = AudioMOELayer(AudioExperts(config, self.num_local_experts, self.expert_group_name),
+                                           self.expert_group_name, ep_size, self.num_local_experts)
+
+    def set_deepspeed_parallelism(self, use_data_before_expert_parallel_=False, ep_group=None):
+        """The reference asks DeepSpeed for the expert-parallel group (core.py:510-520); here the caller passes a
+        torch.distributed group (RCCL on ROCm)."""
+        self.deepspeed_moe._set_ep_group(ep_group)
+
+
+class UniMoEAudioSparseMoeBlock(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.hidden_dim = config.hidden_size
+        self.mlp_dynamic_expert_num = config.mlp_dynamic_expert_num + config.mlp_dynamic_null_expert_num
+        self.mlp_dynamic_real_expert_num = config.mlp_dynamic_expert_num
+        self.mlp_dynamic_null_expert_num = config.mlp_dynamic_null_expert_num
+        self.mlp_dynamic_top_p = config.mlp_dynamic_top_p
+        self.mlp_dynamic_top_k = config.mlp_dynamic_top_k
+        self.mlp_fixed_expert_num = config.mlp_fixed_expert_num
+        self.num_experts = self.mlp_dynamic_expert_num + self.mlp_fixed_expert_num
+        self.ignore_differentiable_router = config.ignore_differentiable_router
+        self.gate = nn.Linear(self.hidden_dim, self.num_experts, bias=False)
+        self.fixed_real_moe = nn.ModuleList([AudioSharedExpertMLP(config) for _ in range(self.mlp_fixed_expert_num)])
+        self.dynamic_real_moe = UniMoEAudioMoE(config, self.mlp_dynamic_real_expert_num, config.ep_size)
+        self.router_jitter_noise = config.router_jitter_noise
+        self.input_jitter_noise = config.input_jitter_noise
+        self.min_capacity = config.min_capacity
+        self.capacity_factor = config.capacity_factor
+        self.token_drop = config.token_drop
+        self.drop_policy = config.drop_policy
+        self.avg_hidden_states_last = config.avg_hidden_states_last
+        self.drop_token_num_print = config.drop_token_num_print
+        self.fp32_gate = config.fp32_gate
+        self.dynamic_intermediate_size = config.dynamic_intermediate_size
+        self.shared_intermediate_size = config.shared_intermediate_size
+        if self.drop_policy not in ("probs", "position"):
+            raise ValueError(f"Invalid drop_policy: {self.drop_policy}")      # core.py:325
+        self._packed = None
+        self._packed_key = None
+
+    # ---- weight pre-packing (MFMA operand order, once per weight version) -------------------------------
+    def _experts(self):
+        return self.dynamic_real_moe.deepspeed_moe.experts.deepspeed_experts
+
+    def prepare(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        ex, sh = self._experts(), self.fixed_real_moe
+        for p in self.parameters():
+            if p.dtype != torch.bfloat16 or not p.is_cuda:
+                raise L.UmoeError("UniMoEAudioSparseMoeBlock runs on the HIP path only: parameters must be bf16 on a ROCm "
+                                  "device (call .to('cuda', torch.bfloat16)); there is no CPU implementation")
+        pk = dict(
+            exp_gu=[ops.pack_gate_up(m.gate_proj.weight.data, m.up_proj.weight.data) for m in ex],
+            exp_dn=[ops.pack_weight(m.down_proj.weight.data) for m in ex],
+            sh_gu=[ops.pack_gate_up(m.gate_proj.weight.data, m.up_proj.weight.data) for m in sh],
+            sh_dn=[ops.pack_weight(m.down_proj.weight.data) for m in sh],
+        )
+        self._packed, self._packed_key = pk, key
+        return pk
+
+    # ---- forward ------------------------------------------------------------------------------------------
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                aux_balance_weight: Optional[torch.Tensor] = None):
+        if not hidden_states.is_cuda:
+            raise L.UmoeError("UniMoEAudioSparseMoeBlock.forward needs device tensors; the CPU restatement lives in "
+                              "oracle/ and is test infrastructure only")
+        B, T, D = hidden_states.shape
+        S = B * T
+        x = hidden_states.reshape(S, D).contiguous()
+        if x.dtype != torch.bfloat16:
+            raise L.UmoeError("hidden_states must be bfloat16")
+        pk = self.prepare()
+        n_dyn, n_real, n_fix = self.mlp_dynamic_expert_num, self.mlp_dynamic_real_expert_num, self.mlp_fixed_expert_num
+        fp32_gate = bool(self.training and self.fp32_gate)                     # core.py:240-249
+        if self.training and self.input_jitter_noise > 0:
+            raise NotImplementedError("input_jitter_noise > 0 in training is not on the HIP path yet")
+        r = ops.router_fwd(x, self.gate.weight.data, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix,
+                           top_p=float(self.mlp_dynamic_top_p), fixed_top_k=int(self.mlp_dynamic_top_k),
+                           jitter_eps=float(self.router_jitter_noise), attn_mask=attention_mask,
+                           logits_bf16=not fp32_gate)
+        logits, expert_mask = r["logits"], r["expert_mask"]
+        top_k = r["top_k"] if self.mlp_dynamic_top_p != 0 else r["top_k"].to(torch.int32)
+        aux = aux_loss(expert_mask, n_dyn, logits, aux_balance_weight)         # core.py:293
+        global_w, moe_w = r["global_weight"], r["moe_weight"]
+        if self.token_drop:
+            expert_mask, global_w, moe_w = self._token_drop(logits, expert_mask, r["routing_weights"], S)
+        disp = ops.dispatch_build(expert_mask, n_real)
+        I_d, I_s = self.dynamic_intermediate_size, self.shared_intermediate_size
+        Imax = max(I_d, I_s if n_fix else 0)
+        slots = S * n_real
+        groups_gu, groups_dn = [], []
+        for e in range(n_real):
+            off, cnt = disp["offsets"][e:e + 1], disp["counts"][e:e + 1]
+            groups_gu.append(dict(w=pk["exp_gu"][e], rows=disp["slot_token"], row_off=off, count=cnt,
+                                  n_blocks=2 * I_d // 16, k=D))
+            groups_dn.append(dict(w=pk["exp_dn"][e], row_off=off, count=cnt, n_blocks=D // 16, k=I_d))
+        for i in range(n_fix):
+            groups_gu.append(dict(w=pk["sh_gu"][i], static_count=S, out_row_base=slots + i * S, n_blocks=2 * I_s // 16, k=D))
+            groups_dn.append(dict(w=pk["sh_dn"][i], static_count=S, a_row_base=slots + i * S, out_row_base=slots + i * S,
+                                  n_blocks=D // 16, k=I_s))
+        hbuf = torch.empty((slots + n_fix * S, Imax), dtype=torch.bfloat16, device=x.device)
+        ybuf = torch.empty((slots + n_fix * S, D), dtype=torch.bfloat16, device=x.device)
+        ops.grouped_gemm(ops.GroupTable(groups_gu, x.device), x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Imax)
+        ops.grouped_gemm(ops.GroupTable(groups_dn, x.device), hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D)
+        out = ops.combine(ybuf, disp["slot_of"], moe_w, ybuf[slots:] if n_fix else None, global_w, None, n_dyn, n_fix)
+        out = out.reshape(B, T, D)
+        if (not self.training) and self.avg_hidden_states_last:               # core.py:355-356
+            import torch.distributed as dist
+            grp = self.dynamic_real_moe.deepspeed_moe.ep_group
+            if dist.is_initialized():
+                dist.all_reduce(out, op=dist.ReduceOp.AVG, group=grp)
+        return out, logits, top_k, expert_mask, global_w.to(hidden_states.dtype), aux
+
+    # ---- rarely used branch, device torch ops (shipped config: token_drop = false) ------------------------
+    def _token_drop(self, logits, expert_mask, routing_w, num_tokens):
+        n_dyn = self.mlp_dynamic_expert_num
+        dt = logits.dtype
+        cap = int(torch.ceil(torch.tensor(num_tokens / n_dyn) * torch.tensor(self.capacity_factor)).to(torch.int64))
+        cap = max(cap, int(self.min_capacity))
+        dyn_logits = logits[:, :n_dyn]
+        mdt = expert_mask.dtype
+        if self.drop_policy == "probs":
+            cap = min(cap, dyn_logits.shape[0])
+            dm = expert_mask[:, :n_dyn].bool()
+            filled = dyn_logits.masked_fill(~dm, torch.finfo(dt).min)
+            _, idx = torch.topk(filled, k=cap, dim=0, sorted=False)
+            keep = torch.zeros_like(expert_mask).scatter(0, idx, 1)
+            keep[:, n_dyn:] = 1
+            expert_mask = torch.logical_and(expert_mask, keep).to(mdt)
+        else:
+            loc = torch.cumsum(expert_mask, dim=0) - 1
+            expert_mask = (expert_mask * torch.lt(loc, cap)).to(mdt)
+        rw = routing_w.to(dt).masked_fill(~(expert_mask[:, :n_dyn].bool()), 0.0)
+        rw = rw / (rw.sum(dim=-1, keepdim=True) + 1e-6)
+        gw = torch.softmax(logits.masked_fill(expert_mask == 0, float("-inf")), dim=-1)
+        gdyn = rw * gw[:, :n_dyn].sum(-1, keepdim=True)
+        global_w = torch.cat((gdyn, gw[:, n_dyn:]), dim=-1).float()
+        moe_w = (global_w[:, : self.mlp_dynamic_real_expert_num] * expert_mask[:, : self.mlp_dynamic_real_expert_num]).contiguous()
+        return expert_mask.contiguous(), global_w.contiguous(), moe_w
+
+
+def aux_loss(expert_mask, n_dyn, full_logits, aux_balance_weight=None):
+    """reference audio_load_balancing_loss_func, core.py:361-389 (small device reductions)."""
+    lowest = torch.finfo(full_logits.dtype).min
+    prob = torch.softmax(full_logits.masked_fill(expert_mask == 0, lowest)[:, :n_dyn], dim=-1)
+    m = expert_mask[:, :n_dyn]
+    if aux_balance_weight is None:
+        frac, mean_prob = m.float().mean(dim=0), prob.mean(dim=0)
+    else:
+        b, t = aux_balance_weight.shape
+        layers = prob.shape[0] // (b * t)
+        w = aux_balance_weight[None, :, :, None].expand(layers, b, t, n_dyn).reshape(-1, n_dyn).to(prob.device)
+        frac = (m.float() * w).sum(0) / w.sum(0)
+        mean_prob = (prob * w).sum(0) / w.sum(0)
+    return (frac * mean_prob).sum() * n_dyn

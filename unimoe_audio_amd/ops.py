@@ -1,0 +1,255 @@
+"""Tensor-level wrappers over the C-ABI (PyTorch-ROCm tensors are containers only).
+
+Every function requires device tensors and launches on torch's current HIP stream.  No function
+here computes on the CPU: a missing library or a CPU tensor is an error, never a silent fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+PRO_PLAIN, PRO_RMSNORM = 0, 1
+EPI_BF16, EPI_BF16_RESID, EPI_SWIGLU, EPI_F32, EPI_F32_RAW = 0, 1, 2, 3, 4
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.UmoeError("umoe ops need device tensors (there is no CPU path in the product)")
+    if not t.is_contiguous():
+        raise L.UmoeError("umoe ops need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def _bf(t):
+    assert t.dtype == torch.bfloat16, t.dtype
+    return t
+
+
+# ----------------------------------------------------------------------------- packing
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [N, K] bf16 -> WP16 packed (see include/umoe.h)."""
+    _bf(w)
+    N, K = w.shape
+    out = torch.empty(L.lib().umoe_packed_elems(N, K), dtype=torch.bfloat16, device=w.device)
+    L.check(L.lib().umoe_pack_weight(_p(w.contiguous()), N, K, _p(out), _stream()), "umoe_pack_weight")
+    return out
+
+
+def pack_gate_up(wg: torch.Tensor, wu: torch.Tensor) -> torch.Tensor:
+    _bf(wg), _bf(wu)
+    I, K = wg.shape
+    assert wu.shape == wg.shape
+    out = torch.empty(2 * I * K, dtype=torch.bfloat16, device=wg.device)
+    L.check(L.lib().umoe_pack_gate_up(_p(wg.contiguous()), _p(wu.contiguous()), I, K, _p(out), _stream()), "umoe_pack_gate_up")
+    return out
+
+
+# ----------------------------------------------------------------------------- router
+def router_fwd(x: Optional[torch.Tensor], gate_w: Optional[torch.Tensor], *, n_dyn: int, n_real: int, n_fix: int,
+               top_p: float, fixed_top_k: int = 0, jitter_eps: float = 0.01, logits_in: Optional[torch.Tensor] = None,
+               attn_mask: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None, rms_eps: float = 1e-6,
+               want_h: bool = False, logits_bf16: Optional[bool] = None) -> dict:
+    E = n_dyn + n_fix
+    if logits_in is not None:
+        S = logits_in.shape[0]
+        dev = logits_in.device
+        is_bf16 = logits_in.dtype == torch.bfloat16
+        D = 0
+    else:
+        S, D = x.shape
+        dev = x.device
+        is_bf16 = True if logits_bf16 is None else logits_bf16
+    o = dict(
+        logits=torch.empty((S, E), dtype=torch.bfloat16 if is_bf16 else torch.float32, device=dev),
+        top_k=torch.empty((S,), dtype=torch.int64, device=dev),
+        sel=torch.empty((S, n_dyn), dtype=torch.int32, device=dev),
+        expert_mask=torch.empty((S, E), dtype=torch.int32, device=dev),
+        routing_weights=torch.empty((S, n_dyn), dtype=torch.float32, device=dev),
+        global_weight=torch.empty((S, E), dtype=torch.float32, device=dev),
+        moe_weight=torch.empty((S, n_real), dtype=torch.float32, device=dev),
+    )
+    h = torch.empty((S, D), dtype=torch.bfloat16, device=dev) if (want_h and x is not None) else None
+    am = None
+    if attn_mask is not None:
+        am = attn_mask.reshape(-1).to(torch.uint8).contiguous()
+    a = L.RouterArgs(
+        x=_p(x), gate_w=_p(gate_w), norm_w=_p(norm_w), h_out=_p(h), logits_in=_p(logits_in), attn_mask=_p(am), S=S, D=D,
+        n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, logits_bf16=int(is_bf16), top_p=top_p, fixed_top_k=int(fixed_top_k),
+        jitter_eps=jitter_eps, rms_eps=rms_eps, logits_out=_p(o["logits"]), top_k=_p(o["top_k"]), sel=_p(o["sel"]),
+        expert_mask=_p(o["expert_mask"]), routing_w=_p(o["routing_weights"]), global_w=_p(o["global_weight"]),
+        moe_w=_p(o["moe_weight"]))
+    L.check(L.lib().umoe_router_fwd(C.byref(a), _stream()), "umoe_router_fwd")
+    if h is not None:
+        o["h"] = h
+    return o
+
+
+def dispatch_build(expert_mask: torch.Tensor, n_real: int) -> dict:
+    S, ld = expert_mask.shape
+    dev = expert_mask.device
+    o = dict(counts=torch.zeros(16, dtype=torch.int32, device=dev), offsets=torch.zeros(17, dtype=torch.int32, device=dev),
+             slot_token=torch.zeros(max(1, S * n_real), dtype=torch.int32, device=dev),
+             slot_of=torch.empty((S, n_real), dtype=torch.int32, device=dev))
+    L.check(L.lib().umoe_dispatch_build(_p(expert_mask), S, ld, n_real, _p(o["counts"]), _p(o["offsets"]),
+                                        _p(o["slot_token"]), _p(o["slot_of"]), _stream()), "umoe_dispatch_build")
+    return o
+
+
+def permute_fwd(x: torch.Tensor, disp: dict, n_real: int) -> torch.Tensor:
+    S, D = x.shape
+    out = torch.zeros((S * n_real, D), dtype=x.dtype, device=x.device)
+    L.check(L.lib().umoe_permute_fwd(_p(x), D, _p(disp["slot_token"]), _p(disp["offsets"][n_real:n_real + 1].contiguous()),
+                                     S * n_real, _p(out), _stream()), "umoe_permute_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------- grouped GEMM
+class GroupTable:
+    """Device-resident array of umoe_group_t built from Python dicts (kept alive with its tensors)."""
+
+    def __init__(self, groups: Sequence[dict], device):
+        arr = (L.Group * len(groups))()
+        self.keep = []
+        for i, g in enumerate(groups):
+            for k in ("w", "bias", "rows", "row_off", "count"):
+                t = g.get(k)
+                if t is not None:
+                    self.keep.append(t)
+                    setattr(arr[i], k, t.data_ptr())
+            arr[i].static_count = int(g.get("static_count", 0))
+            arr[i].a_row_base = int(g.get("a_row_base", 0))
+            arr[i].out_row_base = int(g.get("out_row_base", 0))
+            arr[i].n_blocks = int(g["n_blocks"])
+            arr[i].k = int(g["k"])
+        raw = bytes(arr)
+        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+        self.n = len(groups)
+        self.max_n_blocks = max(int(g["n_blocks"]) for g in groups)
+        self.max_k = max(int(g["k"]) for g in groups)
+
+
+def grouped_gemm(table: GroupTable, a: torch.Tensor, out: torch.Tensor, *, max_rows: int, prologue=PRO_PLAIN,
+                 epilogue=EPI_BF16, norm_w=None, rms_eps=1e-6, resid=None, n_valid=None):
+    args = L.GemmArgs(groups=_p(table.dev), num_groups=table.n, max_rows=max_rows, max_n_blocks=table.max_n_blocks,
+                      max_k=table.max_k, a=_p(a), lda=a.stride(0), norm_w=_p(norm_w), rms_eps=rms_eps, resid=_p(resid),
+                      out=_p(out), ldo=out.stride(0), n_valid=out.shape[1] if n_valid is None else n_valid,
+                      prologue=prologue, epilogue=epilogue)
+    L.check(L.lib().umoe_grouped_gemm(C.byref(args), _stream()), "umoe_grouped_gemm")
+    return out
+
+
+def linear(x: torch.Tensor, w_packed: torch.Tensor, N: int, *, bias: Optional[torch.Tensor] = None, norm_w=None,
+           rms_eps=1e-6, resid=None, out_f32=False) -> torch.Tensor:
+    """y = [rmsnorm](x) @ W^T (+bias) (+resid): one dense group."""
+    S, K = x.shape
+    tab = GroupTable([dict(w=w_packed, bias=bias, static_count=S, n_blocks=(N + 15) // 16, k=K)], x.device)
+    out = torch.empty((S, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    epi = EPI_F32 if out_f32 else (EPI_BF16_RESID if resid is not None else EPI_BF16)
+    return grouped_gemm(tab, x, out, max_rows=S, prologue=PRO_RMSNORM if norm_w is not None else PRO_PLAIN, epilogue=epi,
+                        norm_w=norm_w, rms_eps=rms_eps, resid=resid, n_valid=N)
+
+
+def combine(y_slots, slot_of, moe_w, y_shared, global_w, resid, n_dyn: int, n_fix: int) -> torch.Tensor:
+    S, n_real = slot_of.shape
+    D = y_slots.shape[1]
+    out = torch.empty((S, D), dtype=torch.bfloat16, device=y_slots.device)
+    a = L.CombineArgs(y_slots=_p(y_slots), slot_of=_p(slot_of), moe_w=_p(moe_w), y_shared=_p(y_shared), global_w=_p(global_w),
+                      resid=_p(resid), out=_p(out), S=S, D=D, n_real=n_real, n_dyn=n_dyn, n_fix=n_fix)
+    L.check(L.lib().umoe_unpermute_combine_fwd(C.byref(a), _stream()), "umoe_unpermute_combine_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------- norm / rope / attention
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, resid: Optional[torch.Tensor] = None):
+    S, D = x.shape
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if resid is not None else None
+    L.check(L.lib().umoe_rmsnorm_residual_fwd(_p(x), _p(resid), _p(w), eps, S, D, _p(s), _p(y), _stream()), "umoe_rmsnorm")
+    return (y, s) if resid is not None else y
+
+
+def rope_tables(max_pos: int, head_dim: int, theta: float, device) -> tuple:
+    """cos/sin [max_pos][hd/2] bf16, built with the same torch ops as Qwen2_5_VLRotaryEmbedding (fp32 -> bf16)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    fr = torch.arange(max_pos, dtype=torch.float)[:, None] * inv[None, :]
+    return fr.cos().to(torch.bfloat16).to(device), fr.sin().to(torch.bfloat16).to(device)
+
+
+def qkv_mrope_kvappend(qkv, cos_tab, sin_tab, pos3, kv_pos, T, H, KVH, hd, sections, k_cache, v_cache):
+    n_tok = qkv.shape[0]
+    q = torch.empty((n_tok, H * hd), dtype=torch.bfloat16, device=qkv.device)
+    a = L.RopeArgs(qkv=_p(qkv), cos_tab=_p(cos_tab), sin_tab=_p(sin_tab), pos3=_p(pos3), kv_pos=_p(kv_pos), n_tok=n_tok, T=T,
+                   H=H, KVH=KVH, hd=hd, sec0=sections[0], sec1=sections[1], sec2=sections[2], Lmax=k_cache.shape[2],
+                   q_out=_p(q), k_cache=_p(k_cache), v_cache=_p(v_cache))
+    L.check(L.lib().umoe_qkv_mrope_kvappend(C.byref(a), _stream()), "umoe_qkv_mrope_kvappend")
+    return q
+
+
+def attention(q, k_cache, v_cache, kv_start, q_pos0, nq, H, splits=1):
+    rows, KVH, Lmax, hd = k_cache.shape
+    n = q.shape[0]
+    po = torch.empty((n, H, splits, hd), dtype=torch.float32, device=q.device)
+    pm = torch.empty((n, H, splits, 2), dtype=torch.float32, device=q.device)
+    out = torch.empty((n, H * hd), dtype=torch.bfloat16, device=q.device)
+    a = L.AttnArgs(q=_p(q), k_cache=_p(k_cache), v_cache=_p(v_cache), kv_start=_p(kv_start), q_pos0=_p(q_pos0), rows=rows,
+                   nq=nq, H=H, KVH=KVH, hd=hd, Lmax=Lmax, splits=splits, scale=float(hd) ** -0.5, part_o=_p(po),
+                   part_ml=_p(pm), out=_p(out))
+    L.check(L.lib().umoe_attn_decode(C.byref(a), _stream()), "umoe_attn_decode")
+    return out
+
+
+# ----------------------------------------------------------------------------- codec side
+def codec_embed_sum(tok: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
+    rows, Cc = tok.shape
+    _, V, D = emb.shape
+    out = torch.empty((rows, D), dtype=torch.bfloat16, device=emb.device)
+    L.check(L.lib().umoe_codec_embed_sum(_p(tok.to(torch.int32).contiguous()), _p(emb), rows, Cc, V, D, _p(out), _stream()),
+            "umoe_codec_embed_sum")
+    return out
+
+
+def cfg_sample(logits: torch.Tensor, B: int, Cc: int, V: int, *, cfg_scale, temperature, top_p, top_k, eos, eos_mul,
+               enable_eos=True, do_sample=True, seed=0, want_probs=False):
+    pred = torch.empty((B, Cc), dtype=torch.int64, device=logits.device)
+    probs = torch.empty((B * Cc, V), dtype=torch.float32, device=logits.device) if want_probs else None
+    a = L.SampleArgs(logits=_p(logits), B=B, C=Cc, V=V, cfg_scale=cfg_scale, temperature=temperature, top_p=top_p,
+                     eos_mul=eos_mul, top_k=-1 if top_k is None else top_k, eos=eos, enable_eos=int(enable_eos), min_tokens=-1,
+                     step=None, do_sample=int(do_sample), seed=seed, pred=_p(pred), probs_out=_p(probs))
+    L.check(L.lib().umoe_codec_head_cfg_sample(C.byref(a), _stream()), "umoe_codec_head_cfg_sample")
+    return (pred, probs) if want_probs else pred
+
+
+def delay_step(pred, tokens, state, delay, eos, pad):
+    B, Tmax, Cc = tokens.shape
+    L.check(L.lib().umoe_delay_step(_p(pred), _p(tokens), _p(state), _p(delay), B, Cc, Tmax, eos, pad,
+                                    int(delay.max().item()), _stream()), "umoe_delay_step")
+
+
+def rvq_from_codes(codes, codebooks, out_w, out_b):
+    NQ, T = codes.shape
+    _, CB, cd = codebooks.shape
+    Dl = out_w.shape[1]
+    z = torch.empty((Dl, T), dtype=torch.float32, device=codes.device)
+    L.check(L.lib().umoe_rvq_from_codes(_p(codes.to(torch.int32).contiguous()), _p(codebooks), _p(out_w), _p(out_b), NQ, CB,
+                                        cd, Dl, T, _p(z), _stream()), "umoe_rvq_from_codes")
+    return z
+
+
+def rvq_nearest(z, codebooks, in_w, in_b, out_w, out_b):
+    Dl, T = z.shape
+    NQ, CB, cd = codebooks.shape
+    codes = torch.empty((NQ, T), dtype=torch.int32, device=z.device)
+    ws = torch.empty((T, Dl), dtype=torch.float32, device=z.device)
+    L.check(L.lib().umoe_rvq_nearest(_p(z), _p(codebooks), _p(in_w), _p(in_b), _p(out_w), _p(out_b), NQ, CB, cd, Dl, T,
+                                     _p(codes), _p(ws), _stream()), "umoe_rvq_nearest")
+    return codes
