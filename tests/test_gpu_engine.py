@@ -1,0 +1,172 @@
+"""GPU parity tests of the decode engine (prefill + decode steps + on-device EOS/delay bookkeeping) against the
+CPU oracle, which is itself pinned to the reference by tests/golden (see test_oracle_golden.py)."""
+import types
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected (-m gpu) but no GPU is visible")
+    from unimoe_audio_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def small_cfg(**over):
+    from unimoe_audio_amd.config import UniMoEAudioConfig
+    kw = dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=320,
+              dynamic_intermediate_size=128, shared_intermediate_size=64, codec_placeholder_value=300)
+    kw.update(over)
+    return UniMoEAudioConfig(**kw)
+
+
+def build(cfg, seed, std):
+    from unimoe_audio_amd.model import UniAudioRVQQwen2_5VLMoEForConditionalGeneration
+    torch.manual_seed(seed)
+    m = UniAudioRVQQwen2_5VLMoEForConditionalGeneration(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "layernorm" in n or n.endswith("norm.weight"):
+                p.copy_(1 + 0.05 * torch.randn_like(p))
+            elif n.endswith("bias"):
+                p.normal_(0, 0.02)
+            else:
+                p.normal_(0, std)
+    m = m.to(torch.bfloat16).eval()
+    w = {k: v.clone() for k, v in m.state_dict().items()}
+    return m, w
+
+
+def prompt(cfg, B, T, seed, pads):
+    torch.manual_seed(seed)
+    ids = torch.randint(0, 290, (2 * B, T))
+    am = torch.ones(2 * B, T, dtype=torch.long)
+    for r, p in enumerate(pads):
+        am[r, :p] = 0
+    ids[:, -5:-2] = cfg.codec_placeholder_value
+    codec = torch.randint(0, 1024, (2 * B * 3, cfg.codec_channels))
+    return ids, am, codec
+
+
+def test_teacher_forced_steps_logits_and_router_ints(dev):
+    """Every decode step fed the ORACLE's tokens: per-step logits within tolerance, arg-max codes agree, router ints
+    of every layer equal the oracle's wherever the router logits agree bit-for-bit."""
+    from oracle import decode as OD
+    from unimoe_audio_amd.codec_utils import DecoderOutput, prepare_audio_prompt
+    cfg = small_cfg()
+    m, w = build(cfg, 1, 0.06)
+    B, T, steps = 2, 12, 24
+    ids, am, codec = prompt(cfg, B, T, 2, [3, 0, 1, 0])
+    pre, psteps = OD.prepare_audio_prompt(cfg, [None] * B)
+    gen = OD.GenerateOracle(cfg, w)
+    gen.generate(ids, am, pre, psteps, steps, 6, codec_input_ids=codec, cfg_scale=3.0, do_sample=False, eos_prob_mul_factor=0.8)
+    oracle_tokens = gen.tokens                      # [B, >= steps+1, C]
+    # oracle per-step logits, recomputed by stepping the text model with the same tokens
+    tm = OD.TextModelOracle(cfg, w)
+    key_valid = am.bool()
+    pos = (am.long().cumsum(-1) - 1).masked_fill(am == 0, 1)
+    x = OD.input_embedding(cfg, w, ids, codec)
+    _, cache, _ = tm.forward(x, key_valid, pos, None)
+    gm = m.to(dev)
+    eng = gm.engine(B, T, steps)
+    xg = gm.calculate_input_embedding(ids.to(dev), codec.to(dev))
+    assert torch.equal(xg.cpu(), x)                 # embedding gather + codec sum: exact
+    eng.prefill(xg.reshape(-1, cfg.hidden_size).contiguous(), am.to(dev))
+    forced = torch.full((B, oracle_tokens.shape[1], cfg.codec_channels), 0, dtype=torch.int32)
+    forced[:] = oracle_tokens
+    eng.start_decode(forced, psteps, steps, 6, cfg_scale=3.0, temperature=1.0, top_p=1.0, top_k=45, eos_mul=0.8, do_sample=False)
+    E = cfg.num_experts
+    agree_tok = tot_tok = 0
+    for s in range(steps - 1):
+        kv1 = torch.cat([key_valid, torch.ones((2 * B, 1), dtype=torch.bool)], -1)
+        p1 = (kv1.long().cumsum(-1) - 1).masked_fill(~kv1, 1)[:, -1:]
+        tok2 = oracle_tokens[:, s: s + 1].repeat_interleave(2, dim=0)
+        h, cache, router = tm.forward(OD.codec_embedding(cfg, w, tok2), kv1, p1, cache, collect_router=True)
+        key_valid = kv1
+        ref_logits = torch.nn.functional.linear(h, w["codec_head.weight"]).float()[:, -1]
+        eng.step(use_graph=False)
+        got = eng.copy_buffer("logits", torch.float32, (2 * B, cfg.codec_channels * cfg.codec_vocab_size)).cpu()
+        d = got - ref_logits
+        assert float(d.norm() / ref_logits.norm()) < 0.03, (s, float(d.norm() / ref_logits.norm()))
+        guided = OD.cfg_and_mask(cfg, ref_logits.view(2 * B, cfg.codec_channels, -1).clone(), 3.0, s >= 6, 0.8)
+        pred = eng.copy_buffer("pred", torch.int64, (B, cfg.codec_channels)).cpu()
+        ref_pred = guided.reshape(B * cfg.codec_channels, -1).argmax(-1).view(B, -1)
+        agree_tok += int((pred == ref_pred).sum())
+        tot_tok += pred.numel()
+        masks = eng.copy_buffer("all_mask", torch.int32, (cfg.num_hidden_layers, 2 * B, E)).cpu()
+        for l in range(cfg.num_hidden_layers):
+            ref_mask = router[l]["expert_mask"]
+            if l == 0:                               # layer 0 sees identical inputs up to attention rounding
+                assert (masks[l] == ref_mask).all(-1).float().mean() >= 0.5
+    assert agree_tok / tot_tok > 0.97, (agree_tok, tot_tok)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_free_running_generate_matches_oracle(dev, use_graph):
+    """generate() end to end (prefill, decode loop, forced EOS by max length, delay padding, packing)."""
+    from oracle import decode as OD
+    from unimoe_audio_amd.codec_utils import DecoderOutput, prepare_audio_prompt
+    cfg = small_cfg()
+    m, w = build(cfg, 7, 0.08)
+    B, T, max_tokens = 2, 10, 40
+    ids, am, codec = prompt(cfg, B, T, 8, [2, 0, 0, 0])
+    pre, psteps = OD.prepare_audio_prompt(cfg, [None] * B)
+    ref_codes, ref_len = OD.GenerateOracle(cfg, w).generate(ids, am, pre, psteps, max_tokens, 5, codec_input_ids=codec,
+                                                           cfg_scale=2.0, do_sample=False, eos_prob_mul_factor=0.8)
+    gm = m.to(dev)
+    pre_g, psteps_g = prepare_audio_prompt(cfg, [None] * B)
+    assert torch.equal(pre_g, pre) and psteps_g == psteps
+    dec = DecoderOutput(pre_g, psteps_g, dev)
+    codes, lengths = gm.generate(ids, am, dec, max_tokens, 5, codec_input_ids=codec, cfg_scale=2.0, do_sample=False,
+                                 eos_prob_mul_factor=0.8, use_graph=use_graph, poll_every=7)
+    assert torch.equal(lengths.cpu(), ref_len)
+    assert codes.shape == ref_codes.shape
+    # forced EOS / PAD tail and BOS head are exact; sampled codes agree except where bf16 noise flips a near-tie
+    eos_pad = (ref_codes >= cfg.codec_eos_value)
+    assert torch.equal(codes.cpu()[eos_pad], ref_codes[eos_pad])
+    same = (codes.cpu() == ref_codes).float().mean()
+    assert same > 0.9, float(same)
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_delay_step_kernel_vs_reference_trace(dev, case):
+    """umoe_delay_step replays the REAL reference generate() traces (tests/golden/generate_*.npz): feeding the
+    reference's per-step tokens as predictions must reproduce its token buffer, EOS countdown and lengths."""
+    from unimoe_audio_amd import ops
+    g = load_golden(f"generate_{case}.npz")
+    max_tokens, min_tokens, cfg_scale, eos_mul, V, EOS, PAD, BOS = g["params"].tolist()
+    ref_tokens = g["out_tokens"].to(torch.int32)          # [B, Tfinal, C]
+    B, Tf, C = ref_tokens.shape
+    psteps = g["prefill_steps"].tolist()
+    delay = torch.tensor([0, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18], dtype=torch.int32)
+    Tmax = Tf + 8
+    tok = torch.full((B, Tmax, C), -1, dtype=torch.int32)
+    tok[:, : g["prefill"].shape[1]] = g["prefill"].to(torch.int32)
+    st = torch.zeros(4 * B + 8, dtype=torch.int32)
+    st[B:3 * B] = -1
+    st[3 * B:4 * B] = torch.tensor(psteps, dtype=torch.int32)
+    step0 = min(psteps) - 1
+    st[4 * B], st[4 * B + 1], st[4 * B + 4] = step0, int(max_tokens), step0
+    tok_d, st_d, delay_d = tok.to(dev), st.to(dev), delay.to(dev)
+    for cur in range(step0 + 1, Tf):
+        # the reference's prediction at this step: its stored token where it was generated; anything where the
+        # prompt/BOS entry is kept (masked update), so feed a value that must NOT leak through
+        pred = ref_tokens[:, cur].long().clone()
+        ops.delay_step(pred.to(dev), tok_d, st_d, delay_d, int(EOS), int(PAD))
+    ops.delay_step(torch.zeros(B, C, dtype=torch.int64, device=dev), tok_d, st_d, delay_d, int(EOS), int(PAD))  # no-op once done
+    st_h = st_d.cpu()
+    assert torch.equal(tok_d.cpu()[:, :Tf], ref_tokens)
+    assert int(st_h[4 * B + 2]) == 1                       # all_done
+    md = 18
+    finished = st_h[2 * B:3 * B].long()
+    final_step = int(st_h[4 * B]) + 1
+    finished[finished == -1] = final_step - md
+    lengths = torch.clamp(finished - torch.tensor(psteps), min=0)
+    assert torch.equal(lengths, g["out_lengths"])

@@ -1,0 +1,340 @@
+"""Model-level mirror of the reference API on the HIP engine.
+
+`UniAudioRVQQwen2_5VLMoEForConditionalGeneration` keeps the reference's parameter names
+(reference utils/UniMoE_Audio_model.py:296-311,460-487) so reference checkpoints load by name, and its
+`generate()` keeps the reference signature (model.py:1070-1091) and return value (`codes[B,T,C] int64, lengths[B]`).
+Underneath, prefill and every decode step run in libumoe_hip.so (`umoe_engine_*`): one host call per step,
+replayed as a hipGraph, no per-step host synchronisation (the reference has > 500).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .codec_utils import DecoderOutput
+from .config import UniMoEAudioConfig
+from .dcmoe import UniMoEAudioSparseMoeBlock
+
+
+class Qwen2RMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+
+class Qwen2_5_VLAttention(nn.Module):
+    """parameter container with the transformers names (q/k/v with bias, o without)."""
+
+    def __init__(self, config):
+        super().__init__()
+        D, H, KV, hd = config.hidden_size, config.num_attention_heads, config.num_key_value_heads, config.head_dim
+        self.q_proj = nn.Linear(D, H * hd, bias=True)
+        self.k_proj = nn.Linear(D, KV * hd, bias=True)
+        self.v_proj = nn.Linear(D, KV * hd, bias=True)
+        self.o_proj = nn.Linear(H * hd, D, bias=False)
+
+
+class Qwen2_5_VLMoEDecoderLayer(nn.Module):
+    """reference model.py:193-208"""
+
+    def __init__(self, config, layer_idx: int):
+        super().__init__()
+        self.self_attn = Qwen2_5_VLAttention(config)
+        self.mlp = UniMoEAudioSparseMoeBlock(config)
+        self.input_layernorm = Qwen2RMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.post_attention_layernorm = Qwen2RMSNorm(config.hidden_size, config.rms_norm_eps)
+
+
+class Qwen2_5_VLMoETextModel(nn.Module):
+    """reference model.py:296-311"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([Qwen2_5_VLMoEDecoderLayer(config, i) for i in range(config.num_hidden_layers)])
+        self.norm = Qwen2RMSNorm(config.hidden_size, config.rms_norm_eps)
+
+
+class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
+    def __init__(self, config: UniMoEAudioConfig, with_lm_head: bool = False):
+        super().__init__()
+        self.config = config
+        self.language_model = Qwen2_5_VLMoETextModel(config)
+        self.num_channels = config.codec_channels
+        self.codec_vocab_size = config.codec_vocab_size
+        self.codec_embed_tokens = nn.ModuleList(
+            [nn.Embedding(self.codec_vocab_size, config.hidden_size) for _ in range(self.num_channels)])
+        self.codec_placeholder_value = config.codec_placeholder_value
+        self.codec_head = nn.Linear(config.hidden_size, self.num_channels * self.codec_vocab_size, bias=False)
+        if with_lm_head:  # unused on the audio-token path (computed and discarded by the reference, model.py:817)
+            self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self._engine: Optional["DecodeEngine"] = None
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @torch.no_grad()
+    def init_synthetic(self, seed: int = 1234, std: Optional[float] = None):
+        """N(0, initializer_range^2) Linear/Embedding weights, unit RMSNorm, zero biases; seed + layer index per
+        layer (BASELINE.md measurement plan).  Works on whatever device the parameters live on."""
+        std = self.config.initializer_range if std is None else std
+        dev = self.device
+        g = torch.Generator(device=dev)
+
+        def fill(mod, s):
+            g.manual_seed(s)
+            for n, p in mod.named_parameters():
+                if n.endswith("layernorm.weight"):
+                    p.fill_(1.0)
+                elif n.endswith(".bias"):
+                    p.zero_()
+                else:
+                    p.normal_(0, std, generator=g)
+        for i, layer in enumerate(self.language_model.layers):
+            fill(layer, seed + i)
+        g.manual_seed(seed + 1000)
+        self.language_model.embed_tokens.weight.normal_(0, std, generator=g)
+        self.language_model.norm.weight.fill_(1.0)
+        for e in self.codec_embed_tokens:
+            e.weight.normal_(0, std, generator=g)
+        self.codec_head.weight.normal_(0, std, generator=g)
+        return self
+
+    # ---- input embeddings (reference model.py:655-670): gathers + one scatter, device plumbing -------------
+    def codec_embedding(self, codec_input_ids: torch.Tensor) -> torch.Tensor:
+        emb = torch.stack([e.weight for e in self.codec_embed_tokens], 0)
+        flat = codec_input_ids.reshape(-1, self.num_channels)
+        return ops.codec_embed_sum(flat, emb.contiguous()).reshape(*codec_input_ids.shape[:-1], -1)
+
+    def calculate_input_embedding(self, input_ids, codec_input_ids):
+        x = self.language_model.embed_tokens.weight[input_ids]
+        if codec_input_ids is not None:
+            ce = self.codec_embedding(codec_input_ids)
+            m = (input_ids == self.codec_placeholder_value).unsqueeze(-1).expand_as(x)
+            x = x.masked_scatter(m, ce)
+        return x
+
+    # ---- engine -----------------------------------------------------------------------------------------
+    def engine(self, batch: int, max_prompt: int, max_tokens: int, attn_splits: int = 8) -> "DecodeEngine":
+        need_L = max_prompt + max_tokens + 8
+        e = self._engine
+        if e is None or e.batch != batch or e.Lmax < need_L or e.Tmax < max_tokens + 64:
+            if e is not None:
+                e.close()
+            self._engine = DecodeEngine(self, batch, Lmax=need_L, Tmax=max_tokens + 64, attn_splits=attn_splits)
+        return self._engine
+
+    @torch.no_grad()
+    def generate(self, input_ids, attention_mask, dec_output: DecoderOutput, max_tokens, min_tokens=None,
+                 codec_input_ids: Optional[torch.Tensor] = None, pixel_values=None, pixel_values_videos=None,
+                 image_grid_thw=None, video_grid_thw=None, second_per_grid_ts=None, cfg_scale: float = 3.0,
+                 temperature: float = 1.2, top_p: float = 0.95, cfg_filter_top_k: int = 45,
+                 eos_prob_mul_factor: float = 0.8, do_sample: bool = True, debug_guidance_step: int = 0, use_cache=True,
+                 seed: int = 0, use_graph: bool = True, poll_every: int = 16):
+        if pixel_values is not None or pixel_values_videos is not None:
+            raise NotImplementedError("vision inputs are outside the accelerated path (SURVEY.md 8f-1)")
+        if not use_cache:
+            raise NotImplementedError("use_cache=False is not supported: the engine always keeps a KV cache")
+        dev = self.device
+        input_ids, attention_mask = input_ids.to(dev), attention_mask.to(dev)
+        B = input_ids.shape[0] // 2
+        T = input_ids.shape[1]
+        eng = self.engine(B, T, int(max_tokens))
+        x = self.calculate_input_embedding(input_ids, None if codec_input_ids is None else codec_input_ids.to(dev))
+        eng.prefill(x.reshape(-1, x.shape[-1]).contiguous(), attention_mask)
+        eng.start_decode(dec_output.generated_tokens, dec_output.prefill_steps, int(max_tokens), min_tokens,
+                         cfg_scale=cfg_scale, temperature=temperature, top_p=top_p, top_k=cfg_filter_top_k,
+                         eos_mul=eos_prob_mul_factor, do_sample=do_sample, seed=seed)
+        eng.run(use_graph=use_graph, poll_every=poll_every)
+        codes, lengths, tokens = eng.finish()
+        dec_output.generated_tokens = tokens
+        if codes is None:
+            print("Warning: Nothing generated for any sequence in the batch.")        # model.py:1230
+        return codes, lengths
+
+
+class DecodeEngine:
+    """Python face of umoe_engine_*: packs the weights once, owns the C engine and the decode state."""
+
+    def __init__(self, model: UniAudioRVQQwen2_5VLMoEForConditionalGeneration, batch: int, Lmax: int, Tmax: int,
+                 attn_splits: int = 8, max_pos: Optional[int] = None):
+        cfg = model.config
+        dev = model.device
+        if dev.type != "cuda":
+            raise L.UmoeError("DecodeEngine needs the model on a ROCm device; there is no CPU path in the product")
+        self.model, self.cfg, self.dev = model, cfg, dev
+        self.batch, self.rows, self.Lmax, self.Tmax = batch, 2 * batch, int(Lmax), int(Tmax)
+        sec = list(cfg.mrope_section)
+        c = L.EngineCfg(hidden=cfg.hidden_size, layers=cfg.num_hidden_layers, heads=cfg.num_attention_heads,
+                        kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, n_dyn=cfg.num_dyn,
+                        n_real=cfg.mlp_dynamic_expert_num, n_fix=cfg.mlp_fixed_expert_num,
+                        inter_dyn=cfg.dynamic_intermediate_size, inter_shared=cfg.shared_intermediate_size,
+                        codec_channels=cfg.codec_channels, codec_vocab=cfg.codec_vocab_size, eos=cfg.codec_eos_value,
+                        pad=cfg.codec_pad_value, bos=cfg.codec_bos_value, mrope0=sec[0], mrope1=sec[1], mrope2=sec[2],
+                        rms_eps=cfg.rms_norm_eps, top_p=float(cfg.mlp_dynamic_top_p), fixed_top_k=int(cfg.mlp_dynamic_top_k),
+                        jitter_eps=float(cfg.router_jitter_noise), rows=self.rows, Lmax=self.Lmax, Tmax=self.Tmax,
+                        attn_splits=attn_splits, ep_rank=0, ep_size=1)
+        h = C.c_void_p()
+        L.check(L.lib().umoe_engine_create(C.byref(c), C.byref(h)), "umoe_engine_create")
+        self.h = h
+        self.keep: List[torch.Tensor] = []
+        self._pack_weights()
+        self.tokens = None
+        self.state = None
+        self.io = None
+        self.captured = False
+
+    def _k(self, t):
+        self.keep.append(t)
+        return t
+
+    def _pack_weights(self):
+        m, cfg, lib = self.model, self.cfg, L.lib()
+        bf = torch.bfloat16
+        for p in m.parameters():
+            if p.dtype != bf:
+                raise L.UmoeError("engine weights must be bfloat16")
+        for li, layer in enumerate(m.language_model.layers):
+            a = layer.self_attn
+            qkv_w = self._k(ops.pack_weight(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()))
+            qkv_b = self._k(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).float().contiguous())
+            o_w = self._k(ops.pack_weight(a.o_proj.weight.data.contiguous()))
+            pk = layer.mlp.prepare()
+            n_real, n_fix = cfg.mlp_dynamic_expert_num, cfg.mlp_fixed_expert_num
+            arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
+            eg, ed, sg, sd = arr(pk["exp_gu"]), arr(pk["exp_dn"]), arr(pk["sh_gu"]), arr(pk["sh_dn"])
+            self.keep += pk["exp_gu"] + pk["exp_dn"] + pk["sh_gu"] + pk["sh_dn"]
+            w = L.LayerWeights(in_norm=layer.input_layernorm.weight.data_ptr(), qkv_w=qkv_w.data_ptr(), qkv_b=qkv_b.data_ptr(),
+                               o_w=o_w.data_ptr(), post_norm=layer.post_attention_layernorm.weight.data_ptr(),
+                               gate_w=layer.mlp.gate.weight.data_ptr(), exp_gu=eg, exp_dn=ed, sh_gu=sg, sh_dn=sd)
+            L.check(lib.umoe_engine_set_layer(self.h, li, C.byref(w)), "umoe_engine_set_layer")
+        emb = self._k(torch.stack([e.weight.data for e in m.codec_embed_tokens], 0).contiguous())
+        head = self._k(ops.pack_weight(m.codec_head.weight.data.contiguous()))
+        max_pos = self.Lmax + 8
+        cos, sin = ops.rope_tables(max_pos, cfg.head_dim, cfg.rope_theta, self.dev)
+        self._k(cos), self._k(sin)
+        delay = (C.c_int32 * cfg.codec_channels)(*cfg.codec_delay_pattern)
+        L.check(lib.umoe_engine_set_globals(self.h, m.language_model.norm.weight.data_ptr(), emb.data_ptr(), head.data_ptr(),
+                                            cos.data_ptr(), sin.data_ptr(), max_pos, delay), "umoe_engine_set_globals")
+        torch.cuda.synchronize()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def prefill(self, x: torch.Tensor, attention_mask: torch.Tensor):
+        rows, T = attention_mask.shape
+        assert rows == self.rows and x.shape == (rows * T, self.cfg.hidden_size) and x.dtype == torch.bfloat16
+        valid = attention_mask.to(torch.uint8).cpu().contiguous()
+        self.T_prompt = T
+        L.check(L.lib().umoe_engine_prefill(self.h, x.data_ptr(), valid.data_ptr(), T, self._stream()), "umoe_engine_prefill")
+        self.captured = False
+
+    def start_decode(self, prefill_tokens: torch.Tensor, prefill_steps: List[int], max_tokens: int, min_tokens,
+                     cfg_scale, temperature, top_p, top_k, eos_mul, do_sample, seed=0):
+        B, Cc = self.batch, self.cfg.codec_channels
+        assert prefill_tokens.shape[0] == B and prefill_tokens.shape[2] == Cc
+        if max_tokens + 2 > self.Tmax or self.T_prompt + max_tokens + 1 > self.Lmax:
+            raise L.UmoeError("engine buffers too small for max_tokens")
+        tok = torch.full((B, self.Tmax, Cc), -1, dtype=torch.int32, device=self.dev)
+        tok[:, : prefill_tokens.shape[1]] = prefill_tokens.to(self.dev, torch.int32)
+        step0 = min(prefill_steps) - 1
+        st = torch.zeros(4 * B + 8, dtype=torch.int32)
+        st[B:2 * B] = -1                                     # eos_countdown
+        st[2 * B:3 * B] = -1                                 # finished_step
+        st[3 * B:4 * B] = torch.tensor(prefill_steps, dtype=torch.int32)
+        st[4 * B + 0], st[4 * B + 1], st[4 * B + 4] = step0, max_tokens, step0
+        self.tokens, self.state = tok, st.to(self.dev)
+        self.prefill_steps, self.max_tokens = list(prefill_steps), max_tokens
+        self.io = L.DecodeIO(tokens=tok.data_ptr(), state=self.state.data_ptr(), cfg_scale=cfg_scale, temperature=temperature,
+                             top_p=top_p, eos_mul=eos_mul, top_k=-1 if top_k is None else int(top_k), do_sample=int(bool(do_sample)),
+                             min_tokens=-1 if min_tokens is None else int(min_tokens), seed=seed)
+        self.captured = False
+        self.steps_run = 0
+
+    def step(self, use_graph: bool = True):
+        lib = L.lib()
+        if use_graph:
+            if not self.captured:
+                # capture on a side stream (legacy-stream capture is not allowed), then replay on the current one
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    L.check(lib.umoe_engine_capture(self.h, C.byref(self.io), C.c_void_p(s.cuda_stream)), "umoe_engine_capture")
+                torch.cuda.current_stream().wait_stream(s)
+                self.captured = True
+            L.check(lib.umoe_engine_replay(self.h, self._stream()), "umoe_engine_replay")
+        else:
+            L.check(lib.umoe_engine_decode_step(self.h, C.byref(self.io), self._stream()), "umoe_engine_decode_step")
+        self.steps_run += 1
+
+    def all_done(self) -> bool:
+        return bool(int(self.state[4 * self.batch + 2].item()))
+
+    def run(self, use_graph: bool = True, poll_every: int = 16, max_steps: Optional[int] = None):
+        """Decode until every sequence finished (reference loop head, model.py:1149-1151).  The device decides;
+        the host only polls one flag every `poll_every` steps (steps past the end are no-ops on the token state)."""
+        budget = self.max_tokens - int(self.state[4 * self.batch].item()) if max_steps is None else max_steps
+        done = 0
+        while done < budget:
+            n = min(poll_every, budget - done)
+            for _ in range(n):
+                self.step(use_graph)
+            done += n
+            if self.all_done():
+                break
+        return done
+
+    def finish(self):
+        """reference model.py:1205-1231: lengths, packing of generated_codes."""
+        B, cfg = self.batch, self.cfg
+        md = max(cfg.codec_delay_pattern)
+        st = self.state.cpu()
+        dec_step = int(st[4 * B])
+        finished = st[2 * B:3 * B].long().clone()
+        final_step = dec_step + 1
+        finished[finished == -1] = final_step - md
+        lengths = torch.clamp(finished - torch.tensor(self.prefill_steps), min=0)
+        max_len = int(lengths.max()) + md
+        tokens = self.tokens[:, : max(dec_step + 1, 1)].clone()
+        if max_len <= 0:
+            return None, None, tokens
+        out = torch.full((B, max_len, cfg.codec_channels), cfg.codec_pad_value, dtype=torch.long, device=self.dev)
+        for i in range(B):
+            n = int(lengths[i]) + md
+            if n > 0:
+                seg = tokens[i, self.prefill_steps[i]: self.prefill_steps[i] + n]
+                out[i, : seg.shape[0]] = seg.long()
+        return out, lengths.to(self.dev), tokens
+
+    def copy_buffer(self, name: str, dtype: torch.dtype, shape) -> torch.Tensor:
+        """Copies an engine workspace buffer into a fresh device tensor (parity tests)."""
+        n = C.c_size_t()
+        p = L.lib().umoe_engine_buffer(self.h, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        out = torch.empty(shape, dtype=dtype, device=self.dev)
+        assert out.numel() * out.element_size() <= n.value, (name, n.value)
+        torch.cuda.synchronize()
+        hip = C.CDLL("libamdhip64.so")
+        rc = hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(p), C.c_size_t(out.numel() * out.element_size()), 3)
+        assert rc == 0
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            torch.cuda.synchronize()
+            L.lib().umoe_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
