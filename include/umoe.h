@@ -298,6 +298,10 @@ int umoe_engine_decode_step(umoe_engine* e, const umoe_decode_io* io, umoe_strea
 /* graph capture of one decode step; replays read all step-dependent scalars from device memory */
 int umoe_engine_capture(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream);
 int umoe_engine_replay(umoe_engine* e, umoe_stream_t stream);
+/* one eager step with a hipEvent (on `stream`) after every kernel class; accumulates into ms[13] / launches[13]:
+ * {qkv, rope, attn, oproj, router, dispatch, gateup, down, combine, embed, head, sample, delay} */
+int umoe_engine_profile_step(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream, float* ms, int* launches,
+                             int n);
 /* introspection for parity tests: device pointers into the workspace */
 const void* umoe_engine_buffer(umoe_engine* e, const char* name, size_t* bytes);
 

@@ -99,7 +99,7 @@ EXPORTS = [
     "umoe_codec_embed_sum", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
     "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
-    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer",
+    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step",
 ]
 
 
@@ -141,6 +141,7 @@ def lib():
         L.umoe_engine_decode_step.argtypes = [vp, C.POINTER(DecodeIO), vp]
         L.umoe_engine_capture.argtypes = [vp, C.POINTER(DecodeIO), vp]
         L.umoe_engine_replay.argtypes = [vp, vp]
+        L.umoe_engine_profile_step.argtypes = [vp, C.POINTER(DecodeIO), vp, C.POINTER(f32), C.POINTER(i32), i32]
         _lib = L
     return _lib
 

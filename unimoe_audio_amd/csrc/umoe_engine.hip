@@ -67,6 +67,11 @@ struct umoe_engine {
     int T_prompt = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // optional per-kernel-class timing of one eager step (hipEvents on the launch stream)
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_kind;
+    size_t ev_used = 0;
     int groups_per_layer() const { return 2 + 2 * (c.n_real + c.n_fix); }
 };
 
@@ -207,6 +212,7 @@ extern "C" void umoe_engine_destroy(umoe_engine* e) {
     if (!e) return;
     if (e->exec) hipGraphExecDestroy(e->exec);
     if (e->graph) hipGraphDestroy(e->graph);
+    for (hipEvent_t x : e->ev) hipEventDestroy(x);
     if (e->ws) hipFree(e->ws);
     if (e->k_cache) hipFree(e->k_cache);
     if (e->v_cache) hipFree(e->v_cache);
@@ -244,6 +250,23 @@ extern "C" int umoe_engine_set_globals(umoe_engine* e, const uint16_t* final_nor
 
 extern "C" size_t umoe_engine_workspace_bytes(const umoe_engine* e) { return e ? e->ws_bytes : 0; }
 
+// kernel classes reported by umoe_engine_profile_step
+enum { K_QKV = 0, K_ROPE, K_ATTN, K_OPROJ, K_ROUTER, K_DISPATCH, K_GATEUP, K_DOWN, K_COMBINE, K_EMBED, K_HEAD, K_SAMPLE,
+       K_DELAY, K_NUM };
+
+static void prof_mark(umoe_engine* e, int kind, hipStream_t s) {
+    if (!e->prof) return;
+    if (e->ev_used == e->ev.size()) {
+        hipEvent_t x;
+        if (hipEventCreate(&x) != hipSuccess) return;
+        e->ev.push_back(x);
+        e->ev_kind.push_back(0);
+    }
+    e->ev_kind[e->ev_used] = kind;
+    (void)hipEventRecord(e->ev[e->ev_used++], s);
+}
+#define PROF(kind) prof_mark(e, kind, s)
+
 // ------------------------------------------------------------------------------------ one layer
 static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStream_t s) {
     const umoe_engine_cfg& c = e->c;
@@ -259,7 +282,9 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     a.groups = g; a.num_groups = 1; a.max_rows = n_tok; a.max_n_blocks = QKV / 16; a.max_k = D;
     a.a = e->x; a.lda = D; a.norm_w = L.w.in_norm; a.rms_eps = c.rms_eps; a.out = e->qkv; a.ldo = QKV; a.n_valid = QKV;
     a.prologue = UMOE_PRO_RMSNORM; a.epilogue = UMOE_EPI_BF16;
+    PROF(-1);
     if ((rc = umoe_grouped_gemm(&a, s))) return rc;
+    PROF(K_QKV);
     // 2. mRoPE + KV append
     umoe_rope_args r{};
     r.qkv = e->qkv; r.cos_tab = e->cos_tab; r.sin_tab = e->sin_tab; r.pos3 = e->pos3; r.kv_pos = e->kv_pos;
@@ -267,18 +292,21 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     r.sec0 = c.mrope0; r.sec1 = c.mrope1; r.sec2 = c.mrope2; r.Lmax = c.Lmax;
     r.q_out = e->q_r; r.k_cache = e->k_cache + kv_l; r.v_cache = e->v_cache + kv_l;
     if ((rc = umoe_qkv_mrope_kvappend(&r, s))) return rc;
+    PROF(K_ROPE);
     // 3. attention
     umoe_attn_args t{};
     t.q = e->q_r; t.k_cache = r.k_cache; t.v_cache = r.v_cache; t.kv_start = e->kv_start; t.q_pos0 = e->q_pos0;
     t.rows = c.rows; t.nq = T; t.H = c.heads; t.KVH = c.kv_heads; t.hd = c.head_dim; t.Lmax = c.Lmax; t.splits = splits;
     t.scale = 1.0f / sqrtf((float)c.head_dim); t.part_o = e->part_o; t.part_ml = e->part_ml; t.out = e->attn_out;
     if ((rc = umoe_attn_decode(&t, s))) return rc;
+    PROF(K_ATTN);
     // 4. o_proj + residual                                        model.py:238
     umoe_gemm_args o{};
     o.groups = g + 1; o.num_groups = 1; o.max_rows = n_tok; o.max_n_blocks = D / 16; o.max_k = HD;
     o.a = e->attn_out; o.lda = HD; o.resid = e->x; o.out = e->x1; o.ldo = D; o.n_valid = D;
     o.prologue = UMOE_PRO_PLAIN; o.epilogue = UMOE_EPI_BF16_RESID;
     if ((rc = umoe_grouped_gemm(&o, s))) return rc;
+    PROF(K_OPROJ);
     // 5. RMSNorm + router                                         model.py:240, core.py:246-291
     umoe_router_args ra{};
     ra.x = e->x1; ra.gate_w = L.w.gate_w; ra.norm_w = L.w.post_norm; ra.h_out = e->h2; ra.S = n_tok; ra.D = D;
@@ -291,27 +319,33 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         ra.top_k = e->all_topk + (size_t)l * c.rows;
     }
     if ((rc = umoe_router_fwd(&ra, s))) return rc;
+    PROF(K_ROUTER);
     // 6. ragged dispatch tables
     if ((rc = umoe_dispatch_build(ra.expert_mask, n_tok, E, c.n_real, e->counts, e->offsets, e->slot_token, e->slot_of, s)))
         return rc;
+    PROF(K_DISPATCH);
     // 7. gate/up SwiGLU: routed (gathered rows) + shared (all rows) in one launch
     umoe_gemm_args gu{};
     gu.groups = g + 2; gu.num_groups = G; gu.max_rows = n_tok; gu.max_n_blocks = 2 * Imax / 16; gu.max_k = D;
     gu.a = e->h2; gu.lda = D; gu.out = e->hbuf; gu.ldo = Imax; gu.n_valid = Imax;
     gu.prologue = UMOE_PRO_PLAIN; gu.epilogue = UMOE_EPI_SWIGLU;
     if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
+    PROF(K_GATEUP);
     // 8. down projections
     umoe_gemm_args dn{};
     dn.groups = g + 2 + G; dn.num_groups = G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16; dn.max_k = Imax;
     dn.a = e->hbuf; dn.lda = Imax; dn.out = e->ybuf; dn.ldo = D; dn.n_valid = D;
     dn.prologue = UMOE_PRO_PLAIN; dn.epilogue = UMOE_EPI_BF16;
     if ((rc = umoe_grouped_gemm(&dn, s))) return rc;
+    PROF(K_DOWN);
     // 9. combine + residual -> next layer input                   core.py:488,342-351; model.py:242
     umoe_combine_args cb{};
     cb.y_slots = e->ybuf; cb.slot_of = e->slot_of; cb.moe_w = e->r_moe;
     cb.y_shared = c.n_fix ? e->ybuf + (size_t)n_tok * c.n_real * D : nullptr; cb.global_w = e->r_global;
     cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
-    return umoe_unpermute_combine_fwd(&cb, s);
+    rc = umoe_unpermute_combine_fwd(&cb, s);
+    PROF(K_COMBINE);
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------ prefill
@@ -386,10 +420,12 @@ static int enqueue_step(umoe_engine* e, const umoe_decode_io* io, hipStream_t s)
     const umoe_engine_cfg& c = e->c;
     const int B = c.rows / 2, C = c.codec_channels, V = c.codec_vocab;
     int rc;
+    PROF(-1);
     step_prep_kernel<<<dim3((unsigned)c.rows), 64, 0, s>>>(io->tokens, io->state, B, C, c.Tmax, e->T_prompt, c.Lmax,
                                                            e->valid_count, e->tok_in, e->pos3, e->kv_pos, e->q_pos0);
     UMOE_LAUNCH_CHECK();
     if ((rc = umoe_codec_embed_sum(e->tok_in, e->codec_emb, c.rows, C, V, c.hidden, e->x, s))) return rc;
+    PROF(K_EMBED);
     for (int l = 0; l < c.layers; ++l)
         if ((rc = run_layer(e, l, c.rows, 1, c.attn_splits, s))) return rc;
     // final norm + codec head -> fp32 logits                       model.py:428, 982-983
@@ -399,18 +435,45 @@ static int enqueue_step(umoe_engine* e, const umoe_decode_io* io, hipStream_t s)
     h.rms_eps = c.rms_eps; h.out = e->logits; h.ldo = C * V; h.n_valid = C * V;
     h.prologue = UMOE_PRO_RMSNORM; h.epilogue = UMOE_EPI_F32;
     if ((rc = umoe_grouped_gemm(&h, s))) return rc;
+    PROF(K_HEAD);
     umoe_sample_args sa{};
     sa.logits = e->logits; sa.B = B; sa.C = C; sa.V = V; sa.cfg_scale = io->cfg_scale; sa.temperature = io->temperature;
     sa.top_p = io->top_p; sa.eos_mul = io->eos_mul; sa.top_k = io->top_k; sa.eos = c.eos; sa.min_tokens = io->min_tokens;
     sa.step = io->state + 4 * B; sa.do_sample = io->do_sample; sa.seed = io->seed; sa.pred = e->pred;
     if ((rc = umoe_codec_head_cfg_sample(&sa, s))) return rc;
-    return umoe_delay_step(e->pred, io->tokens, io->state, e->d_delay, B, C, c.Tmax, c.eos, c.pad, e->max_delay, s);
+    PROF(K_SAMPLE);
+    rc = umoe_delay_step(e->pred, io->tokens, io->state, e->d_delay, B, C, c.Tmax, c.eos, c.pad, e->max_delay, s);
+    PROF(K_DELAY);
+    return rc;
 }
 
 extern "C" int umoe_engine_decode_step(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream) {
     UMOE_REQUIRE(e && io && io->tokens && io->state, "umoe_engine_decode_step: null argument");
     UMOE_REQUIRE(e->T_prompt > 0, "umoe_engine_decode_step: prefill first");
     return enqueue_step(e, io, (hipStream_t)stream);
+}
+
+// One eager decode step with a hipEvent after every kernel class; ms[K_NUM] accumulates the elapsed time between
+// consecutive events (kernel + the launch gap in front of it), launches[K_NUM] the number of intervals.
+extern "C" int umoe_engine_profile_step(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream, float* ms,
+                                        int* launches, int n) {
+    UMOE_REQUIRE(e && io && ms && launches && n >= K_NUM, "umoe_engine_profile_step: need %d output slots", K_NUM);
+    hipStream_t s = (hipStream_t)stream;
+    e->prof = true;
+    e->ev_used = 0;
+    const int rc = enqueue_step(e, io, s);
+    e->prof = false;
+    if (rc) return rc;
+    UMOE_HIP(hipStreamSynchronize(s));
+    for (size_t i = 1; i < e->ev_used; ++i) {
+        const int k = e->ev_kind[i];
+        if (k < 0) continue;
+        float t = 0.f;
+        UMOE_HIP(hipEventElapsedTime(&t, e->ev[i - 1], e->ev[i]));
+        ms[k] += t;
+        launches[k] += 1;
+    }
+    return 0;
 }
 
 extern "C" int umoe_engine_capture(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream) {

@@ -274,6 +274,17 @@ class DecodeEngine:
             L.check(lib.umoe_engine_decode_step(self.h, C.byref(self.io), self._stream()), "umoe_engine_decode_step")
         self.steps_run += 1
 
+    KINDS = ["qkv", "rope", "attn", "oproj", "router", "dispatch", "gateup", "down", "combine", "embed", "head", "sample", "delay"]
+
+    def profile_steps(self, n: int = 4) -> dict:
+        """n eager steps with HIP events after every kernel class -> {class: (ms per launch incl. gap, launches/step)}."""
+        ms = (C.c_float * 13)()
+        cnt = (C.c_int * 13)()
+        for _ in range(n):
+            L.check(L.lib().umoe_engine_profile_step(self.h, C.byref(self.io), self._stream(), ms, cnt, 13), "umoe_engine_profile_step")
+            self.steps_run += 1
+        return {k: (ms[i] / max(cnt[i], 1), cnt[i] // n) for i, k in enumerate(self.KINDS)}
+
     def all_done(self) -> bool:
         return bool(int(self.state[4 * self.batch + 2].item()))
 
