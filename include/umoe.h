@@ -83,6 +83,10 @@ int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 int umoe_dispatch_build(const int32_t* expert_mask, int S, int ld_mask, int n_real, int32_t* counts,
                         int32_t* offsets, int32_t* slot_token, int32_t* slot_of, umoe_stream_t stream);
 
+/* router + dispatch tables in one call: a single fused launch when S <= 16 (decode), two launches otherwise */
+int umoe_router_dispatch_fwd(const umoe_router_args* a, int32_t* counts, int32_t* offsets, int32_t* slot_token,
+                             int32_t* slot_of, umoe_stream_t stream);
+
 /* permute: out[slot] = x[slot_token[slot]]  (the gather half of compress_matrix);
  * bwd of unpermute.  rows = offsets[n_real] read on device. */
 int umoe_permute_fwd(const uint16_t* x, int D, const int32_t* slot_token, const int32_t* total_slots, int max_slots,
@@ -129,6 +133,7 @@ typedef struct {
     int ldo;
     int n_valid;              /* columns >= n_valid are not stored (N not multiple of 16) */
     int prologue, epilogue;
+    int nt;                   /* n-blocks per workgroup: 0 = auto, else 1/2/4/8 (tuning knob) */
 } umoe_gemm_args;
 int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream);
 
@@ -150,6 +155,9 @@ typedef struct {
     const uint16_t* resid;    /* [S][D] or NULL */
     uint16_t* out;            /* [S][D] */
     int S, D, n_real, n_dyn, n_fix;
+    const uint16_t* norm_w;   /* optional [D]: also write norm_out = RMSNorm(out) * norm_w (next layer's input norm) */
+    uint16_t* norm_out;       /* [S][D] */
+    float rms_eps;
 } umoe_combine_args;
 int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_stream_t stream);
 

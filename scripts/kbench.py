@@ -1,0 +1,119 @@
+"""Kernel micro-benchmarks at the decode shapes (16 rows, full utils/config.json sizes).  Weights rotate over several
+distinct copies so every launch streams cold from HBM (the Infinity Cache holds 256 MiB).  Not a test."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unimoe_audio_amd import ops
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+D, Id, Is, S = 2048, 2752, 1376, 16
+
+
+def timeit(fn, iters=60, warm=5):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(iters):
+        fn(i)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+
+def rnd(*s):
+    return (torch.randn(*s, device=dev) * 0.02).to(torch.bfloat16)
+
+
+res = {}
+which = sys.argv[1:] or ["dense", "experts", "router", "attn", "sample"]
+x = rnd(S, D) * 50
+
+if "dense" in which:
+    for name, N, K, norm, resid, f32 in [("qkv", 2560, 2048, True, False, False), ("oproj", 2048, 2048, False, True, False),
+                                          ("head", 12324, 2048, True, False, True)]:
+        R = 12
+        ws = [ops.pack_weight(rnd(N, K)) for _ in range(R)]
+        nw = torch.ones(K, device=dev, dtype=torch.bfloat16)
+        r = rnd(S, N)
+        xin = rnd(S, K)
+        tabs = [ops.GroupTable([dict(w=w, static_count=S, n_blocks=(N + 15) // 16, k=K)], dev) for w in ws]
+        out = torch.empty((S, N), dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
+        epi = ops.EPI_F32 if f32 else (ops.EPI_BF16_RESID if resid else ops.EPI_BF16)
+        for nt in (1, 2, 4, 8):
+            t = timeit(lambda i: ops.grouped_gemm(tabs[i % R], xin, out, max_rows=S, prologue=ops.PRO_RMSNORM if norm else ops.PRO_PLAIN,
+                                                  epilogue=epi, norm_w=nw if norm else None, resid=r if resid else None, n_valid=N, nt=nt))
+            res[f"{name}_nt{nt}"] = round(t, 2)
+            print(name, "nt", nt, f"{t:.2f} us  {N*K*2/t/1e3:.0f} GB/s", flush=True)
+
+if "experts" in which:
+    R = 4
+    mask = (torch.rand(S, 11, device=dev) < 0.45).to(torch.int32)
+    mask[:, 9:] = 1
+    disp = ops.dispatch_build(mask, 8)
+    slots = S * 8
+    sets = []
+    for _ in range(R):
+        gu = [ops.pack_gate_up(rnd(Id, D), rnd(Id, D)) for _ in range(8)] + [ops.pack_gate_up(rnd(Is, D), rnd(Is, D)) for _ in range(2)]
+        dn = [ops.pack_weight(rnd(D, Id)) for _ in range(8)] + [ops.pack_weight(rnd(D, Is)) for _ in range(2)]
+        g1, g2 = [], []
+        for e in range(8):
+            off, cnt = disp["offsets"][e:e + 1], disp["counts"][e:e + 1]
+            g1.append(dict(w=gu[e], rows=disp["slot_token"], row_off=off, count=cnt, n_blocks=2 * Id // 16, k=D))
+            g2.append(dict(w=dn[e], row_off=off, count=cnt, n_blocks=D // 16, k=Id))
+        for i in range(2):
+            g1.append(dict(w=gu[8 + i], static_count=S, out_row_base=slots + i * S, n_blocks=2 * Is // 16, k=D))
+            g2.append(dict(w=dn[8 + i], static_count=S, a_row_base=slots + i * S, out_row_base=slots + i * S, n_blocks=D // 16, k=Is))
+        sets.append((ops.GroupTable(g1, dev), ops.GroupTable(g2, dev)))
+    hbuf = torch.zeros(slots + 2 * S, Id, device=dev, dtype=torch.bfloat16)
+    ybuf = torch.zeros(slots + 2 * S, D, device=dev, dtype=torch.bfloat16)
+    gub = (8 * 2 * Id * D + 2 * 2 * Is * D) * 2
+    dnb = (8 * Id * D + 2 * Is * D) * 2
+    for nt in (2, 4, 8):
+        t = timeit(lambda i: ops.grouped_gemm(sets[i % R][0], x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=nt))
+        res[f"gateup_nt{nt}"] = round(t, 2)
+        print("gateup nt", nt, f"{t:.2f} us  {gub/t/1e3:.0f} GB/s", flush=True)
+    for nt in (1, 2, 4, 8):
+        t = timeit(lambda i: ops.grouped_gemm(sets[i % R][1], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=nt))
+        res[f"down_nt{nt}"] = round(t, 2)
+        print("down nt", nt, f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
+
+if "router" in which:
+    gw = rnd(11, D)
+    nw = torch.ones(D, device=dev, dtype=torch.bfloat16)
+    t = timeit(lambda i: ops.router_fwd(x, gw, n_dyn=9, n_real=8, n_fix=2, top_p=0.7, norm_w=nw, want_h=True))
+    res["router"] = round(t, 2)
+    print("router+alloc", f"{t:.2f} us", flush=True)
+    t = timeit(lambda i: ops.router_dispatch_fwd(x, gw, n_dyn=9, n_real=8, n_fix=2, top_p=0.7, norm_w=nw))
+    print("router_dispatch fused + alloc", f"{t:.2f} us", flush=True)
+    lg = (torch.randn(S, 11, device=dev) * 0.9).to(torch.bfloat16)
+    t = timeit(lambda i: ops.router_fwd(None, None, n_dyn=9, n_real=8, n_fix=2, top_p=0.7, logits_in=lg))
+    print("router logits-only + alloc", f"{t:.2f} us", flush=True)
+    e = torch.empty(16, device=dev)
+    t = timeit(lambda i: [torch.empty((S, 11), device=dev) for _ in range(8)])
+    print("8 torch.empty allocs", f"{t:.2f} us", flush=True)
+    gws = [rnd(11, D) for _ in range(64)]
+    t = timeit(lambda i: ops.router_fwd(x, gws[i % 64], n_dyn=9, n_real=8, n_fix=2, top_p=0.7, norm_w=nw, want_h=True))
+    print("router cold gate_w + alloc", f"{t:.2f} us", flush=True)
+
+if "attn" in which:
+    rows, KVH, H, hd, Lmax, L = 16, 2, 16, 128, 1024, 550
+    kc, vc = rnd(rows, KVH, Lmax, hd) * 50, rnd(rows, KVH, Lmax, hd) * 50
+    q = rnd(rows, H * hd) * 50
+    ks = torch.zeros(rows, dtype=torch.int32, device=dev)
+    q0 = torch.full((rows,), L, dtype=torch.int32, device=dev)
+    for splits in (1, 2, 4, 8, 16):
+        t = timeit(lambda i: ops.attention(q, kc, vc, ks, q0, 1, H, splits=splits))
+        res[f"attn_s{splits}"] = round(t, 2)
+        print("attn splits", splits, f"{t:.2f} us (2 launches + 3 allocs)", flush=True)
+
+if "sample" in which:
+    lg = torch.randn(16, 12 * 1027, device=dev)
+    t = timeit(lambda i: ops.cfg_sample(lg, 8, 12, 1027, cfg_scale=3.0, temperature=1.2, top_p=0.95, top_k=45, eos=1024, eos_mul=0.8, seed=i), iters=20)
+    res["sample"] = round(t, 2)
+    print("sample", f"{t:.2f} us", flush=True)
+    t = timeit(lambda i: ops.cfg_sample(lg, 8, 12, 1027, cfg_scale=3.0, temperature=1.2, top_p=0.95, top_k=45, eos=1024, eos_mul=0.8, do_sample=False), iters=20)
+    print("argmax", f"{t:.2f} us", flush=True)
+print(json.dumps(res))

@@ -144,6 +144,29 @@ def test_router_fused_gate_and_norm(dev):
     assert mism <= S * 0.03, f"index mismatch rate from logit rounding too high: {mism}/{S}"
 
 
+@pytest.mark.parametrize("S,nd,nf", [(16, 9, 2), (5, 9, 2), (16, 8, 2), (7, 6, 1), (40, 9, 2)])
+def test_router_dispatch_fused_equals_two_step(dev, S, nd, nf):
+    """The single-launch decode path (S <= 16) must equal router_fwd + dispatch_build bit for bit, and the oracle."""
+    from oracle import router as OR
+    from unimoe_audio_amd import ops
+    torch.manual_seed(S + nd)
+    D, nr = 256, min(8, nd)
+    x = torch.randn(S, D).to(torch.bfloat16).to(dev)
+    gw = (torch.randn(nd + nf, D) * 0.06).to(torch.bfloat16).to(dev)
+    nw = (1 + 0.05 * torch.randn(D)).to(torch.bfloat16).to(dev)
+    f = ops.router_dispatch_fwd(x, gw, n_dyn=nd, n_real=nr, n_fix=nf, top_p=0.7, norm_w=nw)
+    r = ops.router_fwd(x, gw, n_dyn=nd, n_real=nr, n_fix=nf, top_p=0.7, norm_w=nw, want_h=True)
+    d = ops.dispatch_build(r["expert_mask"], nr)
+    for k in ("logits", "top_k", "sel", "expert_mask", "routing_weights", "global_weight", "moe_weight", "h"):
+        assert torch.equal(f[k], r[k]), k
+    tot = int(d["offsets"][nr])
+    assert torch.equal(f["counts"][:nr], d["counts"][:nr]) and torch.equal(f["offsets"][:nr + 1], d["offsets"][:nr + 1])
+    assert torch.equal(f["slot_of"], d["slot_of"]) and torch.equal(f["slot_token"][:tot], d["slot_token"][:tot])
+    o = OR.route(f["logits"].cpu(), nd, nr, nf, 0.7, 0, 0.01, None)
+    assert torch.equal(f["expert_mask"].cpu(), o["expert_mask"]) and torch.equal(f["sel"].cpu(), o["sel"])
+    assert torch.equal(f["global_weight"].cpu(), o["global_weight"].float())
+
+
 @pytest.mark.parametrize("S", [0, 1, 16, 257, 6240])
 def test_dispatch_tables_exact(dev, S):
     from oracle import router as OR

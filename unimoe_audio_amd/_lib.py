@@ -47,12 +47,13 @@ class Group(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("groups", vp), ("num_groups", i32), ("max_rows", i32), ("max_n_blocks", i32), ("max_k", i32),
                 ("a", vp), ("lda", i32), ("norm_w", vp), ("rms_eps", f32), ("resid", vp), ("out", vp), ("ldo", i32),
-                ("n_valid", i32), ("prologue", i32), ("epilogue", i32)]
+                ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32)]
 
 
 class CombineArgs(C.Structure):
     _fields_ = [("y_slots", vp), ("slot_of", vp), ("moe_w", vp), ("y_shared", vp), ("global_w", vp), ("resid", vp),
-                ("out", vp), ("S", i32), ("D", i32), ("n_real", i32), ("n_dyn", i32), ("n_fix", i32)]
+                ("out", vp), ("S", i32), ("D", i32), ("n_real", i32), ("n_dyn", i32), ("n_fix", i32), ("norm_w", vp),
+                ("norm_out", vp), ("rms_eps", f32)]
 
 
 class RopeArgs(C.Structure):
@@ -94,7 +95,7 @@ class DecodeIO(C.Structure):
 
 EXPORTS = [
     "umoe_last_error", "umoe_abi_version", "umoe_packed_elems", "umoe_pack_weight", "umoe_pack_gate_up",
-    "umoe_router_fwd", "umoe_dispatch_build", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd",
+    "umoe_router_fwd", "umoe_router_dispatch_fwd", "umoe_dispatch_build", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd",
     "umoe_unpermute_combine_fwd", "umoe_rmsnorm_residual_fwd", "umoe_qkv_mrope_kvappend", "umoe_attn_decode",
     "umoe_codec_embed_sum", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
@@ -123,6 +124,7 @@ def lib():
         L.umoe_pack_gate_up.argtypes = [vp, vp, i32, i32, vp, vp]
         L.umoe_router_fwd.argtypes = [C.POINTER(RouterArgs), vp]
         L.umoe_dispatch_build.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]
+        L.umoe_router_dispatch_fwd.argtypes = [C.POINTER(RouterArgs), vp, vp, vp, vp, vp]
         L.umoe_permute_fwd.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.umoe_grouped_gemm.argtypes = [C.POINTER(GemmArgs), vp]
         L.umoe_unpermute_combine_fwd.argtypes = [C.POINTER(CombineArgs), vp]

@@ -38,12 +38,17 @@ __host__ __device__ __forceinline__ float bf2f(uint16_t h) {
     return c.f;
 }
 __host__ __device__ __forceinline__ uint16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN; MI355X_MICROARCH.md)
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+#else
     union { uint32_t u; float f; } c;
     c.f = f;
     uint32_t u = c.u;
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
+#endif
 }
 __host__ __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ float round_t(float v, int is_bf16) { return is_bf16 ? rbf(v) : v; }

@@ -51,7 +51,7 @@ struct umoe_engine {
     umoe_group_t* d_groups = nullptr;  // per layer: [qkv 1][o 1][gateup G][down G]; then [head 1]
     int groups_for_tok = -1;
     // carved buffers
-    uint16_t *x = nullptr, *x1 = nullptr, *h2 = nullptr, *qkv = nullptr, *q_r = nullptr, *attn_out = nullptr,
+    uint16_t *x = nullptr, *hin = nullptr, *x1 = nullptr, *h2 = nullptr, *qkv = nullptr, *q_r = nullptr, *attn_out = nullptr,
              *hbuf = nullptr, *ybuf = nullptr;
     float *part_o = nullptr, *part_ml = nullptr, *logits = nullptr;
     int32_t *pos3 = nullptr, *kv_pos = nullptr, *q_pos0 = nullptr, *kv_start = nullptr, *tok_in = nullptr,
@@ -85,6 +85,7 @@ static size_t carve(umoe_engine* e, int n_tok, char* base) {
     Carver k;
     k.base = base;
     e->x = k.take<uint16_t>((size_t)n_tok * D);
+    e->hin = k.take<uint16_t>((size_t)n_tok * D);
     e->x1 = k.take<uint16_t>((size_t)n_tok * D);
     e->h2 = k.take<uint16_t>((size_t)n_tok * D);
     e->qkv = k.take<uint16_t>((size_t)n_tok * QKV);
@@ -280,8 +281,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // 1. RMSNorm + QKV (+bias)                                   model.py:227, Qwen2_5_VLAttention q/k/v_proj
     umoe_gemm_args a{};
     a.groups = g; a.num_groups = 1; a.max_rows = n_tok; a.max_n_blocks = QKV / 16; a.max_k = D;
-    a.a = e->x; a.lda = D; a.norm_w = L.w.in_norm; a.rms_eps = c.rms_eps; a.out = e->qkv; a.ldo = QKV; a.n_valid = QKV;
-    a.prologue = UMOE_PRO_RMSNORM; a.epilogue = UMOE_EPI_BF16;
+    a.a = e->hin; a.lda = D; a.out = e->qkv; a.ldo = QKV; a.n_valid = QKV;   // hin = RMSNorm(x) from the previous combine
+    a.prologue = UMOE_PRO_PLAIN; a.epilogue = UMOE_EPI_BF16;
     PROF(-1);
     if ((rc = umoe_grouped_gemm(&a, s))) return rc;
     PROF(K_QKV);
@@ -318,12 +319,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         ra.expert_mask = e->all_mask + (size_t)l * c.rows * E;
         ra.top_k = e->all_topk + (size_t)l * c.rows;
     }
-    if ((rc = umoe_router_fwd(&ra, s))) return rc;
+    if ((rc = umoe_router_dispatch_fwd(&ra, e->counts, e->offsets, e->slot_token, e->slot_of, s))) return rc;
     PROF(K_ROUTER);
-    // 6. ragged dispatch tables
-    if ((rc = umoe_dispatch_build(ra.expert_mask, n_tok, E, c.n_real, e->counts, e->offsets, e->slot_token, e->slot_of, s)))
-        return rc;
-    PROF(K_DISPATCH);
     // 7. gate/up SwiGLU: routed (gathered rows) + shared (all rows) in one launch
     umoe_gemm_args gu{};
     gu.groups = g + 2; gu.num_groups = G; gu.max_rows = n_tok; gu.max_n_blocks = 2 * Imax / 16; gu.max_k = D;
@@ -343,6 +340,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     cb.y_slots = e->ybuf; cb.slot_of = e->slot_of; cb.moe_w = e->r_moe;
     cb.y_shared = c.n_fix ? e->ybuf + (size_t)n_tok * c.n_real * D : nullptr; cb.global_w = e->r_global;
     cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
+    // fused RMSNorm for the consumer of x: the next layer's input_layernorm, or the final norm in front of the head
+    cb.norm_w = (l + 1 < c.layers) ? e->layers[l + 1].w.in_norm : e->final_norm; cb.norm_out = e->hin; cb.rms_eps = c.rms_eps;
     rc = umoe_unpermute_combine_fwd(&cb, s);
     PROF(K_COMBINE);
     return rc;
@@ -386,6 +385,8 @@ extern "C" int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint
     UMOE_HIP(hipMemcpyAsync(e->valid_count, vc.data(), vc.size() * 4, hipMemcpyHostToDevice, s));
     UMOE_HIP(hipMemcpyAsync(e->x, x, (size_t)n_tok * c.hidden * 2, hipMemcpyDeviceToDevice, s));
     UMOE_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+    if ((rc = umoe_rmsnorm_residual_fwd(e->x, nullptr, e->layers[0].w.in_norm, c.rms_eps, n_tok, c.hidden, nullptr, e->hin, s)))
+        return rc;
     for (int l = 0; l < c.layers; ++l)
         if ((rc = run_layer(e, l, n_tok, T, 1, s))) return rc;
     e->T_prompt = T;
@@ -425,15 +426,17 @@ static int enqueue_step(umoe_engine* e, const umoe_decode_io* io, hipStream_t s)
                                                            e->valid_count, e->tok_in, e->pos3, e->kv_pos, e->q_pos0);
     UMOE_LAUNCH_CHECK();
     if ((rc = umoe_codec_embed_sum(e->tok_in, e->codec_emb, c.rows, C, V, c.hidden, e->x, s))) return rc;
+    if ((rc = umoe_rmsnorm_residual_fwd(e->x, nullptr, e->layers[0].w.in_norm, c.rms_eps, c.rows, c.hidden, nullptr, e->hin, s)))
+        return rc;
     PROF(K_EMBED);
     for (int l = 0; l < c.layers; ++l)
         if ((rc = run_layer(e, l, c.rows, 1, c.attn_splits, s))) return rc;
     // final norm + codec head -> fp32 logits                       model.py:428, 982-983
     umoe_gemm_args h{};
     h.groups = e->d_groups + (size_t)c.layers * e->groups_per_layer(); h.num_groups = 1; h.max_rows = c.rows;
-    h.max_n_blocks = ceil_div(C * V, 16); h.max_k = c.hidden; h.a = e->x; h.lda = c.hidden; h.norm_w = e->final_norm;
-    h.rms_eps = c.rms_eps; h.out = e->logits; h.ldo = C * V; h.n_valid = C * V;
-    h.prologue = UMOE_PRO_RMSNORM; h.epilogue = UMOE_EPI_F32;
+    h.max_n_blocks = ceil_div(C * V, 16); h.max_k = c.hidden; h.a = e->hin; h.lda = c.hidden;   // hin = final norm(x)
+    h.out = e->logits; h.ldo = C * V; h.n_valid = C * V;
+    h.prologue = UMOE_PRO_PLAIN; h.epilogue = UMOE_EPI_F32;
     if ((rc = umoe_grouped_gemm(&h, s))) return rc;
     PROF(K_HEAD);
     umoe_sample_args sa{};

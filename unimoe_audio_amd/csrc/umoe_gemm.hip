@@ -68,9 +68,10 @@ __device__ __forceinline__ int lds_chunk_off(int QS, int h, int i, int m) {
     return h * QS + (i >> 4) * 256 + (((i & 15) + m) & 15) * 16;
 }
 
-template <int NT, int PRO, int EPI>
+template <int NT, int U, int PRO, int EPI>
 __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     const umoe_group_t g = p.groups[blockIdx.z];
     const int count = g.count ? *g.count : g.static_count;
     const int row0 = blockIdx.y * 16;
@@ -84,7 +85,28 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int roff = g.row_off ? *g.row_off : 0;
 
-    // ---- stage the 16-row activation tile ------------------------------------------------
+    // ---- weight stream set-up; the first chunk is requested BEFORE the activation tile is staged -----------
+    const int i0 = (KB * wave) >> 2, i1 = (KB * (wave + 1)) >> 2;
+    f32x4_t acc[NT];
+    const u32x4_t* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const int nb = min(nb0 + t, g.n_blocks - 1);  // tail tiles re-read the last block; never stored
+        wp[t] = reinterpret_cast<const u32x4_t*>(g.w) + ((size_t)nb * KB) * 64 + lane;
+    }
+    u32x4_t w0[NT][U], w1[NT][U];
+    auto load_chunk = [&](u32x4_t (&dst)[NT][U], int ibase) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ii = min(ibase + u, i1 - 1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dst[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)ii * 64);
+        }
+    };
+    if (i0 < i1) load_chunk(w0, i0);
+
+    // ---- stage the 16-row activation tile ----------------------------------------------------------------
     {
         const int m = tid >> 4, sub = tid & 15;
         const int r = row0 + m;
@@ -94,27 +116,31 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
         const uint16_t* src = p.a + arow * (long)p.lda;
         char* dst = smem + m * RS;
         const int Q8 = KB;  // 16-byte chunks per quarter
-        float rs = 0.f;
-        if (PRO == UMOE_PRO_RMSNORM) {
+        if (PRO == UMOE_PRO_RMSNORM && 4 * Q8 <= 256) {
+            // single pass: the row slice lives in registers between the sum of squares and the scaling
+            uint4 buf[16];
             float ss = 0.f;
-            if (valid)
-                for (int c = sub; c < 4 * Q8; c += 16) {
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int c = sub + 16 * n;
+                buf[n] = make_uint4(0, 0, 0, 0);
+                if (valid && c < 4 * Q8) {
+                    buf[n] = ld16(src + c * 8);
                     float f[8];
-                    unpack8(ld16(src + c * 8), f);
+                    unpack8(buf[n], f);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
                 }
+            }
 #pragma unroll
             for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            rs = rsqrtf(ss / (float)K + p.rms_eps);
-        }
-        for (int h = 0; h < 4; ++h)
-            for (int i = sub; i < Q8; i += 16) {
-                const int c = h * Q8 + i;
-                uint4 u = make_uint4(0, 0, 0, 0);
-                if (valid) {
-                    u = ld16(src + c * 8);
-                    if (PRO == UMOE_PRO_RMSNORM) {
+            const float rs = rsqrtf(ss / (float)K + p.rms_eps);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int c = sub + 16 * n;
+                if (c < 4 * Q8) {
+                    uint4 u = buf[n];
+                    if (valid) {
                         float f[8], w[8];
                         unpack8(u, f);
                         unpack8(ld16(p.norm_w + c * 8), w);
@@ -122,88 +148,115 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
                         for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
                         u = pack8(f);
                     }
+                    const int h = c / Q8, i = c - h * Q8;
+                    st16(dst + lds_chunk_off(QS, h, i, m), u);
                 }
-                st16(dst + lds_chunk_off(QS, h, i, m), u);
             }
+        } else {
+            float rs = 0.f;
+            if (PRO == UMOE_PRO_RMSNORM) {
+                float ss = 0.f;
+                if (valid)
+                    for (int c = sub; c < 4 * Q8; c += 16) {
+                        float f[8];
+                        unpack8(ld16(src + c * 8), f);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+                    }
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                rs = rsqrtf(ss / (float)K + p.rms_eps);
+            }
+            for (int h = 0; h < 4; ++h)
+                for (int i = sub; i < Q8; i += 16) {
+                    const int c = h * Q8 + i;
+                    uint4 u = make_uint4(0, 0, 0, 0);
+                    if (valid) {
+                        u = ld16(src + c * 8);
+                        if (PRO == UMOE_PRO_RMSNORM) {
+                            float f[8], w[8];
+                            unpack8(u, f);
+                            unpack8(ld16(p.norm_w + c * 8), w);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
+                            u = pack8(f);
+                        }
+                    }
+                    st16(dst + lds_chunk_off(QS, h, i, m), u);
+                }
+        }
     }
     __syncthreads();
 
-    // ---- stream weights, 4 waves split K ---------------------------------------------------
+    // ---- stream weights (double-buffered in registers), 4 waves split K -------------------------------------
     const int h = lane >> 4, mm = lane & 15;
     const char* bbase = smem + mm * RS;
-    const int i0 = (KB * wave) >> 2, i1 = (KB * (wave + 1)) >> 2;
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    f32x4_t acc[NT];
-    const u32x4_t* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        wp[t] = reinterpret_cast<const u32x4_t*>(g.w) + ((size_t)(nb0 + t) * KB) * 64 + lane;
-    }
-    constexpr int U = (NT == 1) ? 16 : 8;
-    for (int i = i0; i < i1; i += U) {
-        u32x4_t wv[NT][U];
+    auto compute_chunk = [&](const u32x4_t (&src)[NT][U], int ibase) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int ii = min(i + u, i1 - 1);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) wv[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)ii * 64);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ii = i + u;
+            const int ii = ibase + u;
             if (ii < i1) {
                 const uint4 bv = *reinterpret_cast<const uint4*>(bbase + lds_chunk_off(QS, h, ii, mm));
                 const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, bv);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[t][u]), bfrag,
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, src[t][u]), bfrag,
                                                                     acc[t], 0, 0, 0);
             }
         }
+    };
+    for (int i = i0; i < i1; i += 2 * U) {
+        if (i + U < i1) load_chunk(w1, i + U);
+        compute_chunk(w0, i);
+        if (i + 2 * U < i1) load_chunk(w0, i + 2 * U);
+        if (i + U < i1) compute_chunk(w1, i + U);
     }
 
-    // ---- fixed-order cross-wave reduction --------------------------------------------------
-    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem + 16 * RS);
+    // ---- fixed-order cross-wave reduction through the (now free) staging area -------------------------------
+    __syncthreads();
+    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
 #pragma unroll
     for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[t];
     __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    auto reduced = [&](int t) -> f32x4_t {
         f32x4_t s = red[t * 64 + lane];
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
             const f32x4_t v = red[(w * NT + t) * 64 + lane];
             s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         }
-        acc[t] = s;
-    }
+        return s;
+    };
 
-    // ---- epilogue: lane (h, mm) owns features 4h..4h+3 of token row mm ---------------------
+    // ---- epilogue: lane (h, mm) owns features 4h..4h+3 of token row mm; tiles are spread over the waves -----
     const int r = row0 + mm;
     if (r >= count) return;
     const long orow = (long)g.out_row_base + roff + r;
     if (EPI == UMOE_EPI_SWIGLU) {
-        const int col = blockIdx.x * 16 + 4 * h;
-        uint16_t y[4];
+        for (int q = wave; q < NT / 2; q += 4) {
+            if (nb0 + 2 * q >= g.n_blocks) break;
+            const f32x4_t ga = reduced(2 * q), ua = reduced(2 * q + 1);
+            const int col = (nb0 / 2 + q) * 16 + 4 * h;
+            uint16_t y[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gt = rbf(acc[0][j]);
-            const float up = rbf(acc[NT - 1][j]);
-            const float si = rbf(gt / (1.0f + expf(-gt)));
-            y[j] = f2bf(si * up);
+            for (int j = 0; j < 4; ++j) {
+                const float gt = rbf(ga[j]);
+                const float up = rbf(ua[j]);
+                const float si = rbf(gt / (1.0f + expf(-gt)));
+                y[j] = f2bf(si * up);
+            }
+            uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + col;
+            *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
         }
-        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + col;
-        *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
         return;
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = wave; t < NT; t += 4) {
+        if (nb0 + t >= g.n_blocks) break;
+        const f32x4_t a4 = reduced(t);
         const int n = (nb0 + t) * 16 + 4 * h;
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[t][j] + ((g.bias && n + j < p.n_valid) ? g.bias[n + j] : 0.f);
+        for (int j = 0; j < 4; ++j) v[j] = a4[j] + ((g.bias && n + j < p.n_valid) ? g.bias[n + j] : 0.f);
         if (EPI == UMOE_EPI_F32 || EPI == UMOE_EPI_F32_RAW) {
             float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + n;
 #pragma unroll
@@ -232,23 +285,48 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
 // ------------------------------------------------------------------------------------ launcher
 static size_t gemm_lds_bytes(int max_k, int NT) {
     const size_t QS = (size_t)(((max_k >> 1) + 255) & ~255);
-    return 16 * 4 * QS + (size_t)4 * NT * 64 * 16;
+    const size_t a = 16 * 4 * QS, red = (size_t)4 * NT * 64 * 16;
+    return a > red ? a : red;
 }
 
-template <int NT, int PRO, int EPI>
+template <int NT, int U, int PRO, int EPI>
 static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
     const size_t lds = gemm_lds_bytes(a->max_k, NT);
     UMOE_REQUIRE(lds <= 160 * 1024, "umoe_grouped_gemm: K=%d needs %zu bytes of LDS (> 160 KiB)", a->max_k, lds);
     static size_t configured = 0;  // per instantiation
     if (lds > configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, PRO, EPI>),
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, U, PRO, EPI>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
     dim3 grid((unsigned)ceil_div(a->max_n_blocks, NT), (unsigned)ceil_div(a->max_rows, 16), (unsigned)a->num_groups);
-    wstream_gemm<NT, PRO, EPI><<<grid, 256, lds, s>>>(*a);
+    wstream_gemm<NT, U, PRO, EPI><<<grid, 256, lds, s>>>(*a);
     UMOE_LAUNCH_CHECK();
     return 0;
+}
+
+// n-blocks per workgroup: more blocks amortise the activation staging, fewer blocks give more workgroups
+template <int PRO, int EPI>
+static int launch_gemm_nt(const umoe_gemm_args* a, int nt, hipStream_t s) {
+    switch (nt) {
+        case 1: return launch_gemm<1, 8, PRO, EPI>(a, s);
+        case 2: return launch_gemm<2, 8, PRO, EPI>(a, s);
+        case 4: return launch_gemm<4, 4, PRO, EPI>(a, s);
+        case 8: return launch_gemm<8, 2, PRO, EPI>(a, s);
+    }
+    UMOE_REQUIRE(false, "umoe_grouped_gemm: nt must be 1, 2, 4 or 8 (got %d)", nt);
+}
+
+static int auto_nt(const umoe_gemm_args* a, bool swiglu) {
+    if (a->nt) return a->nt;
+    const long row_tiles = ceil_div(a->max_rows, 16);
+    const long blocks = (long)a->max_n_blocks * a->num_groups * row_tiles;
+    // measured on MI355X at 16 rows (scripts/kbench.py): gate/up 344-block groups and the 128-block down groups are
+    // fastest at 8 blocks per workgroup (staging amortised 8x); small dense layers keep one block per workgroup
+    if (swiglu) return blocks >= 1024 ? 8 : (blocks >= 512 ? 4 : 2);
+    if (blocks >= 1024) return 8;
+    if (blocks >= 512) return 2;
+    return 1;
 }
 
 extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) {
@@ -262,22 +340,27 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
     const int pro = a->prologue, epi = a->epilogue;
     if (pro == UMOE_PRO_RMSNORM) {
         UMOE_REQUIRE(a->norm_w, "umoe_grouped_gemm: RMSNorm prologue needs norm_w");
-        if (epi == UMOE_EPI_BF16) return launch_gemm<1, UMOE_PRO_RMSNORM, UMOE_EPI_BF16>(a, s);
-        if (epi == UMOE_EPI_F32) return launch_gemm<1, UMOE_PRO_RMSNORM, UMOE_EPI_F32>(a, s);
-        if (epi == UMOE_EPI_F32_RAW) return launch_gemm<1, UMOE_PRO_RMSNORM, UMOE_EPI_F32_RAW>(a, s);
+        const int nt = auto_nt(a, false);
+        if (epi == UMOE_EPI_BF16) return launch_gemm_nt<UMOE_PRO_RMSNORM, UMOE_EPI_BF16>(a, nt, s);
+        if (epi == UMOE_EPI_F32) return launch_gemm_nt<UMOE_PRO_RMSNORM, UMOE_EPI_F32>(a, nt, s);
         UMOE_REQUIRE(false, "umoe_grouped_gemm: unsupported prologue/epilogue %d/%d", pro, epi);
     }
     UMOE_REQUIRE(pro == UMOE_PRO_PLAIN, "umoe_grouped_gemm: bad prologue %d", pro);
     switch (epi) {
-        case UMOE_EPI_BF16: return launch_gemm<1, UMOE_PRO_PLAIN, UMOE_EPI_BF16>(a, s);
+        case UMOE_EPI_BF16: return launch_gemm_nt<UMOE_PRO_PLAIN, UMOE_EPI_BF16>(a, auto_nt(a, false), s);
         case UMOE_EPI_BF16_RESID:
             UMOE_REQUIRE(a->resid, "umoe_grouped_gemm: residual epilogue needs resid");
-            return launch_gemm<1, UMOE_PRO_PLAIN, UMOE_EPI_BF16_RESID>(a, s);
-        case UMOE_EPI_SWIGLU:
+            return launch_gemm_nt<UMOE_PRO_PLAIN, UMOE_EPI_BF16_RESID>(a, auto_nt(a, false), s);
+        case UMOE_EPI_SWIGLU: {
             UMOE_REQUIRE(a->max_n_blocks % 2 == 0, "umoe_grouped_gemm: SwiGLU needs gate/up block pairs");
-            return launch_gemm<2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
-        case UMOE_EPI_F32: return launch_gemm<1, UMOE_PRO_PLAIN, UMOE_EPI_F32>(a, s);
-        case UMOE_EPI_F32_RAW: return launch_gemm<1, UMOE_PRO_PLAIN, UMOE_EPI_F32_RAW>(a, s);
+            const int nt = auto_nt(a, true);
+            UMOE_REQUIRE(nt >= 2, "umoe_grouped_gemm: SwiGLU needs nt >= 2");
+            if (nt == 2) return launch_gemm<2, 8, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
+            if (nt == 4) return launch_gemm<4, 4, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
+            return launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
+        }
+        case UMOE_EPI_F32: return launch_gemm_nt<UMOE_PRO_PLAIN, UMOE_EPI_F32>(a, auto_nt(a, false), s);
+        case UMOE_EPI_F32_RAW: return launch_gemm_nt<UMOE_PRO_PLAIN, UMOE_EPI_F32_RAW>(a, auto_nt(a, false), s);
     }
     UMOE_REQUIRE(false, "umoe_grouped_gemm: bad epilogue %d", epi);
 }

@@ -76,8 +76,10 @@ extern "C" int umoe_rmsnorm_residual_fwd(const uint16_t* x, const uint16_t* r, c
 // reference: einsum("se,sem->sm") core.py:488 (fp32 accumulate, one rounding), `final + current`
 // core.py:342, shared experts `expert(x) * w` then add core.py:349-351, residual model.py:242.
 __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a) {
+    __shared__ float sh[4];
     const int s = blockIdx.x;
     const int E = a.n_dyn + a.n_fix;
+    float ss = 0.f;
     for (int c = threadIdx.x; c < (a.D >> 3); c += 256) {
         float acc[8];
 #pragma unroll
@@ -108,7 +110,25 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = r[j] + acc[j];
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] = rbf(acc[j]);
+            ss += acc[j] * acc[j];
+        }
         st16(a.out + (size_t)s * a.D + c * 8, pack8(acc));
+    }
+    if (!a.norm_w) return;
+    // fused RMSNorm of the row just produced (input_layernorm of the NEXT layer / final norm): saves every QKV
+    // workgroup from recomputing it (model.py:227,428)
+    ss = block_sum_256(ss, sh);
+    const float rs = rsqrtf(ss / (float)a.D + a.rms_eps);
+    for (int c = threadIdx.x; c < (a.D >> 3); c += 256) {
+        float f[8], w[8];
+        unpack8(ld16(a.out + (size_t)s * a.D + c * 8), f);   // this thread's own stores
+        unpack8(ld16(a.norm_w + c * 8), w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
+        st16(a.norm_out + (size_t)s * a.D + c * 8, pack8(f));
     }
 }
 
@@ -231,6 +251,140 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(const umoe_sample_args 
         if (tid == 0 && top != eos) x[eos] = -INFINITY;
         __syncthreads();
     }
+    // ---- fast path (0 < top_k <= 64): radix-select the k-th largest, then everything on <= 64 candidates -------
+    if (a.top_k > 0 && a.top_k <= 64) {
+        __shared__ unsigned hist[256];
+        __shared__ unsigned sel_prefix, sel_remaining;
+        __shared__ int wsum[4];
+        __shared__ float cand_val[64];
+        __shared__ int cand_idx[64];
+        __shared__ int n_cand;
+        auto key_of = [](float f) -> unsigned {  // monotonic: larger float -> larger key
+            unsigned u = __float_as_uint(f);
+            return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        };
+        constexpr int PER = 8;  // contiguous indices per thread (V <= 2048)
+        const int v0 = tid * PER;
+        unsigned keys[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) keys[j] = (v0 + j < V) ? key_of(x[v0 + j]) : 0u;
+        if (tid == 0) {
+            sel_prefix = 0u;
+            sel_remaining = (unsigned)min(a.top_k, V);
+        }
+        for (int pass = 3; pass >= 0; --pass) {
+            hist[tid] = 0u;
+            __syncthreads();
+            const unsigned prefix = sel_prefix, himask = (pass == 3) ? 0u : (0xffffffffu << (8 * (pass + 1)));
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (v0 + j < V && (keys[j] & himask) == prefix) atomicAdd(&hist[(keys[j] >> (8 * pass)) & 255u], 1u);
+            __syncthreads();
+            if (tid < 64) {  // wave 0: suffix counts over the 256 bins, 4 bins per lane
+                const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                unsigned above = c0 + c1 + c2 + c3;  // inclusive suffix sum over lanes >= tid
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned t = __shfl_down(above, o, 64);
+                    if (tid + o < 64) above += t;
+                }
+                const unsigned rem = sel_remaining;
+                const unsigned higher = above - (c0 + c1 + c2 + c3);  // elements in bins of higher lanes
+                if (above >= rem && higher < rem) {  // the k-th largest lives in one of this lane's bins
+                    unsigned acc2 = higher;
+                    int d = 3;
+                    const unsigned cs[4] = {c0, c1, c2, c3};
+                    for (; d >= 0; --d) {
+                        if (acc2 + cs[d] >= rem) break;
+                        acc2 += cs[d];
+                    }
+                    sel_prefix = prefix | ((unsigned)(4 * tid + d) << (8 * pass));
+                    sel_remaining = rem - acc2;  // how many of the selected bin are still needed
+                }
+            }
+            __syncthreads();
+        }
+        const unsigned tkey = sel_prefix;     // key of the k-th largest value
+        const int need_eq = (int)sel_remaining;  // number of == tkey elements to keep (lowest indices first)
+        // exclusive scans over threads (index order): equal-to-threshold count, then kept count
+        auto block_excl = [&](int v) -> int {
+            int inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if ((tid & 63) >= o) inc += t;
+            }
+            if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+            __syncthreads();
+            int base = 0;
+            for (int w2 = 0; w2 < (tid >> 6); ++w2) base += wsum[w2];
+            __syncthreads();
+            return base + inc - v;
+        };
+        int eq = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) eq += (v0 + j < V && keys[j] == tkey);
+        int eq_before = block_excl(eq);
+        int keep = 0;
+        bool kj[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const bool in = v0 + j < V;
+            const bool is_eq = in && keys[j] == tkey;
+            kj[j] = in && (keys[j] > tkey || (is_eq && eq_before < need_eq));
+            eq_before += is_eq;
+            keep += kj[j];
+        }
+        int pos = block_excl(keep);
+        if (tid == 255) n_cand = pos + keep;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (kj[j]) {
+                if (pos < 64) {
+                    cand_val[pos] = x[v0 + j];
+                    cand_idx[pos] = v0 + j;
+                }
+                ++pos;
+            }
+        if (a.probs_out)
+            for (int v = tid; v < V; v += 256) a.probs_out[((size_t)b * a.C + c) * V + v] = 0.f;
+        __syncthreads();
+        if (tid >= 64) return;
+        // ---- wave 0: lane = candidate, candidates are in index order ----------------------------------------
+        const int n = min(n_cand, 64);
+        float val = (tid < n) ? cand_val[tid] : -INFINITY;
+        auto lane_softmax64 = [&](float vv) -> float {
+            const float mx = wave_max(vv);
+            const float e = (vv == -INFINITY) ? 0.f : expf(vv - mx);
+            return e / wave_sum(e);
+        };
+        if (a.top_p < 1.0f) {  // model.py:899-910 restricted to the survivors of top-k
+            const float pme = lane_softmax64(val);
+            float before = 0.f;
+            for (int j = 0; j < n; ++j) {
+                const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pme), j));
+                if (pj > pme || (pj == pme && j < tid)) before += pj;
+            }
+            if (before > a.top_p) val = -INFINITY;
+        }
+        const float pr_me = lane_softmax64(val);
+        if (a.probs_out && tid < n) a.probs_out[((size_t)b * a.C + c) * V + cand_idx[tid]] = pr_me;
+        const uint64_t hsh = mix64(a.seed ^ mix64(((uint64_t)(uint32_t)step << 32) | (uint32_t)blockIdx.x));
+        const float u = (float)((hsh >> 40) + 0.5) * (1.0f / 16777216.0f);
+        float cum = pr_me;  // inclusive prefix in index order
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float t = __shfl_up(cum, o, 64);
+            if (tid >= o) cum += t;
+        }
+        const unsigned long long hitm = __ballot(pr_me > 0.f && cum > u);
+        const unsigned long long posm = __ballot(pr_me > 0.f);
+        int pick;
+        if (hitm) pick = __ffsll((long long)hitm) - 1;
+        else pick = posm ? 63 - __clzll((long long)posm) : 0;
+        if (tid == 0) a.pred[(size_t)b * a.C + c] = cand_idx[pick];
+        return;
+    }
     // top-k by rank (ties: lower index first) (model.py:893-897)
     if (a.top_k > 0) {
         for (int v = tid; v < V; v += 256) {
@@ -307,7 +461,7 @@ extern "C" int umoe_codec_head_cfg_sample(const umoe_sample_args* a, umoe_stream
     UMOE_REQUIRE(a && a->logits && a->pred && a->B > 0 && a->C > 0 && a->V > 1, "umoe_codec_head_cfg_sample: bad argument");
     UMOE_REQUIRE(a->eos >= 0 && a->eos < a->V, "umoe_codec_head_cfg_sample: eos %d outside vocabulary %d", a->eos, a->V);
     const size_t lds = (size_t)3 * a->V * sizeof(float);
-    UMOE_REQUIRE(lds <= 60 * 1024, "umoe_codec_head_cfg_sample: vocabulary %d too large for the LDS sampler", a->V);
+    UMOE_REQUIRE(lds <= 60 * 1024 && a->V <= 2048, "umoe_codec_head_cfg_sample: vocabulary %d too large for the LDS sampler", a->V);
     cfg_sample_kernel<<<dim3((unsigned)(a->B * a->C)), 256, lds, (hipStream_t)stream>>>(*a);
     UMOE_LAUNCH_CHECK();
     return 0;

@@ -17,32 +17,98 @@
 // Roofline: latency-bound at decode (S = 16); HBM-bound on [S,D] reads for large S.
 #include "umoe_common.h"
 
-struct RouterDev {
-    umoe_router_args a;
-};
+// ---- uniform gathers: lane j's value read into a scalar with v_readlane (no LDS crossbar traffic) -------------
+#define RLF(v, j) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (j)))
+#define RLI(v, j) __builtin_amdgcn_readlane((v), (j))
 
-// broadcast helpers: value held by lane `src` (lanes 0..15 hold router columns)
-__device__ __forceinline__ float bcast(float v, int src) { return __shfl(v, src, 64); }
-
-// softmax over lanes [0, n): sequential fp32 sum in index order, reciprocal multiply, round to T
-__device__ __forceinline__ float lane_softmax(float x, int n, int lane, int is_bf16) {
-    float xm = (lane < n) ? x : -INFINITY;
-    float m = xm;
+// all[j] = value of lane j for j < n, `fill` otherwise (j is a compile-time constant after unrolling).
+// NC > 0: n is the compile-time constant NC (no guards, NC readlanes); NC == 0: runtime n, 16-wide with guards.
+template <int NC>
+__device__ __forceinline__ void gather16(float v, int n, float fill, float (&all)[UMOE_MAXE]) {
 #pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));  // lanes 0..15 (16..63 hold -inf too)
-    m = __shfl(m, 0, 64);
-    const float e = (lane < n) ? umoe_exp_det(xm - m) : 0.f;
-    float s = bcast(e, 0);
-    for (int j = 1; j < n; ++j) s = s + bcast(e, j);
+    for (int j = 0; j < UMOE_MAXE; ++j) {
+        if (NC > 0) all[j] = (j < NC) ? RLF(v, j) : fill;
+        else all[j] = (j < n) ? RLF(v, j) : fill;
+    }
+}
+#define LIM(NC, n) ((NC) > 0 ? (NC) : (n))
+
+// softmax over lanes [0, n): max, deterministic exp, SEQUENTIAL fp32 sum in index order, reciprocal multiply,
+// round to T -- the arithmetic contract shared with oracle/router_oracle.c
+template <int NC, int TB>
+__device__ __forceinline__ float lane_softmax(float x, int n, int lane) {
+    const float xm = (lane < LIM(NC, n)) ? x : -INFINITY;
+    float xs[UMOE_MAXE];
+    gather16<NC>(xm, n, -INFINITY, xs);
+    float m = xs[0];
+#pragma unroll
+    for (int j = 1; j < UMOE_MAXE; ++j)
+        if (NC == 0 || j < NC) m = (xs[j] > m) ? xs[j] : m;
+    const float e = (lane < LIM(NC, n)) ? umoe_exp_det(xm - m) : 0.f;
+    float es[UMOE_MAXE];
+    gather16<NC>(e, n, 0.f, es);
+    float s = es[0];
+#pragma unroll
+    for (int j = 1; j < UMOE_MAXE; ++j)
+        if (j < LIM(NC, n)) s = s + es[j];
     const float r = 1.0f / s;
-    return round_t(e * r, is_bf16);
+    return TB ? rbf(e * r) : e * r;
 }
 
-__global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
-    const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= a.S) return;
-    const int E = a.n_dyn + a.n_fix, n_dyn = a.n_dyn, T = a.logits_bf16;
+// sum over the 64 lanes of 16 per-lane accumulators in 17 exchanges (reduce-scatter, then 2 butterfly steps).
+// Returns, on lane e < 16, the total of acc[e].  Fixed tree => run-to-run deterministic.
+__device__ __forceinline__ float reduce16_to_lanes(float (&acc)[UMOE_MAXE], int lane) {
+    {
+        const bool hi = lane & 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float send = hi ? acc[j] : acc[j + 8];
+            const float keep = hi ? acc[j + 8] : acc[j];
+            acc[j] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool hi = lane & 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float send = hi ? acc[j] : acc[j + 4];
+            const float keep = hi ? acc[j + 4] : acc[j];
+            acc[j] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool hi = lane & 8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float send = hi ? acc[j] : acc[j + 2];
+            const float keep = hi ? acc[j + 2] : acc[j];
+            acc[j] = keep + __shfl_xor(send, 8, 64);
+        }
+    }
+    float v;
+    {
+        const bool hi = lane & 4;
+        const float send = hi ? acc[0] : acc[1];
+        const float keep = hi ? acc[1] : acc[0];
+        v = keep + __shfl_xor(send, 4, 64);
+    }
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    // lane L now holds column ((L>>5)&1)*8 + ((L>>4)&1)*4 + ((L>>3)&1)*2 + ((L>>2)&1); fetch column `lane`
+    const int src = (((lane >> 3) & 1) << 5) | (((lane >> 2) & 1) << 4) | (((lane >> 1) & 1) << 3) | ((lane & 1) << 2);
+    return __shfl(v, src, 64);
+}
+
+// ND / NF: compile-time n_dyn / n_fix (ND == 0: generic runtime sizes); TB: 1 = bf16 arithmetic type, 0 = fp32
+template <int ND, int NF, int TB>
+__device__ __forceinline__ int route_from_logits(const umoe_router_args& a, const int s, const int lane, float full);
+
+template <int ND, int NF, int TB>
+__device__ __forceinline__ int route_token(const umoe_router_args& a, const int s, const int lane) {
+    const int n_dyn = ND > 0 ? ND : a.n_dyn;
+    const int E = ND > 0 ? ND + NF : a.n_dyn + a.n_fix;
+    constexpr int T = TB;
+    constexpr int NE = ND > 0 ? ND + NF : 0;  // compile-time E (0 = runtime)
 
     // ---- logits: lane e <- column e ----------------------------------------------------------
     float full = -INFINITY;  // this lane's logit (valid for lane < E)
@@ -91,14 +157,19 @@ __global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
                     acc[e] += d;
                 }
         }
-        float mine = 0.f;
-#pragma unroll
-        for (int e = 0; e < UMOE_MAXE; ++e) {
-            const float t = wave_sum(acc[e]);
-            if (lane == e) mine = t;
-        }
+        const float mine = reduce16_to_lanes(acc, lane);
         if (lane < E) full = round_t(mine, T);
     }
+    return route_from_logits<ND, NF, TB>(a, s, lane, full);
+}
+
+
+template <int ND, int NF, int TB>
+__device__ __forceinline__ int route_from_logits(const umoe_router_args& a, const int s, const int lane, float full) {
+    const int n_dyn = ND > 0 ? ND : a.n_dyn;
+    const int E = ND > 0 ? ND + NF : a.n_dyn + a.n_fix;
+    constexpr int T = TB;
+    constexpr int NE = ND > 0 ? ND + NF : 0;  // compile-time E (0 = runtime)
     if (a.logits_out && lane < E) {
         if (T) reinterpret_cast<uint16_t*>(a.logits_out)[(size_t)s * E + lane] = f2bf(full);
         else reinterpret_cast<float*>(a.logits_out)[(size_t)s * E + lane] = full;
@@ -107,32 +178,39 @@ __global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
     // ---- Top-P count (core.py:157-167) -------------------------------------------------------
     int k = a.fixed_top_k;
     if (a.top_p != 0.0f) {
-        const float p = lane_softmax(full, n_dyn, lane, T);
-        // rank in descending order (ties: lower index first); values only matter
+        const float p = lane_softmax<ND, TB>(full, n_dyn, lane);
+        float ps[UMOE_MAXE];
+        gather16<ND>(p, n_dyn, -INFINITY, ps);
+        // rank in descending order (ties: lower index first); only the sorted VALUES matter
         int rank = 0;
-        for (int j = 0; j < n_dyn; ++j) {
-            const float pj = bcast(p, j);
-            rank += (pj > p) || (pj == p && j < lane);
-        }
-        // sorted[t] = p of the lane whose rank is t
-        int src = 0;
-        for (int j = 0; j < n_dyn; ++j)
-            if (__shfl(rank, j, 64) == lane) src = j;
-        const float sorted = __shfl(p, src, 64);
+#pragma unroll
+        for (int j = 0; j < UMOE_MAXE; ++j)
+            if (j < LIM(ND, n_dyn)) rank += (ps[j] > p) || (ps[j] == p && j < lane);
+        // value at sorted position t = p of the lane whose rank is t
+        float mineS = 0.f;
+#pragma unroll
+        for (int j = 0; j < UMOE_MAXE; ++j)
+            if (j < LIM(ND, n_dyn) && RLI(rank, j) == lane) mineS = ps[j];
+        float sorted[UMOE_MAXE];
+        gather16<ND>(mineS, n_dyn, 0.f, sorted);
         const float thr = round_t(a.top_p, T);
         int below = 0;
         if (T) {
             float acc = 0.f;
-            for (int t = 0; t < n_dyn; ++t) {
-                acc = acc + bcast(sorted, t);
-                below += !(rbf(acc) >= thr);
-            }
+#pragma unroll
+            for (int t = 0; t < UMOE_MAXE; ++t)
+                if (t < LIM(ND, n_dyn)) {
+                    acc = acc + sorted[t];
+                    below += !(rbf(acc) >= thr);
+                }
         } else {
             double acc = 0.0;
-            for (int t = 0; t < n_dyn; ++t) {
-                acc = acc + (double)bcast(sorted, t);
-                below += !((float)acc >= thr);
-            }
+#pragma unroll
+            for (int t = 0; t < UMOE_MAXE; ++t)
+                if (t < LIM(ND, n_dyn)) {
+                    acc = acc + (double)sorted[t];
+                    below += !((float)acc >= thr);
+                }
         }
         k = below + 1;
     }
@@ -144,26 +222,23 @@ __global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
     float w = 0.f;
     int m = 0;
     for (int j = 0; j < k; ++j) {
-        // max + lowest-index arg-max over lanes 0..15
-        float bv = masked;
-        int bi = lane;
+        // max + lowest-index arg-max over the n_dyn columns (uniform scan of the gathered values)
+        float ms[UMOE_MAXE];
+        gather16<ND>(masked, n_dyn, -INFINITY, ms);
+        float thr = ms[0];
+        int ind = 0;
 #pragma unroll
-        for (int o = 8; o >= 1; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
+        for (int e = 1; e < UMOE_MAXE; ++e)
+            if ((ND == 0 || e < ND) && ms[e] > thr) {
+                thr = ms[e];
+                ind = e;
             }
-        }
-        const float thr = __shfl(bv, 0, 64);
-        const int ind = __shfl(bi, 0, 64);
         const float af = fabsf(full), at = fabsf(thr);
         const float factor = af > at ? af : at;
         const float d = round_t(thr - full, T);
         const float q = round_t(d / factor, T);
         const float gate = (q > two_eps) ? -INFINITY : masked;
-        const float gsm = lane_softmax(gate, n_dyn, lane, T);
+        const float gsm = lane_softmax<ND, TB>(gate, n_dyn, lane);
         if (lane == ind) {
             w = gsm;
             m += 1;
@@ -174,8 +249,12 @@ __global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
     if (a.sel && lane >= k && lane < n_dyn) a.sel[(size_t)s * n_dyn + lane] = -1;
 
     // ---- renormalise / padding / shared always on (core.py:284-291) ---------------------------
-    float sum = bcast(w, 0);
-    for (int j = 1; j < n_dyn; ++j) sum = sum + bcast(w, j);
+    float ws[UMOE_MAXE];
+    gather16<ND>(w, n_dyn, 0.f, ws);
+    float sum = ws[0];
+#pragma unroll
+    for (int j = 1; j < UMOE_MAXE; ++j)
+        if (j < LIM(ND, n_dyn)) sum = sum + ws[j];
     sum = round_t(sum, T);
     const float den = round_t(sum + 1e-6f, T);
     w = (lane < n_dyn) ? round_t(w / den, T) : 0.f;
@@ -184,11 +263,15 @@ __global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
 
     // ---- global routing weight (core.py:178-193) ----------------------------------------------
     float gw = w;
-    if (a.n_fix > 0) {
+    if ((ND > 0 ? NF : a.n_fix) > 0) {
         const float gl = (lane < E && m) ? full : -INFINITY;
-        gw = lane_softmax(gl, E, lane, T);
-        float ds = bcast(gw, 0);
-        for (int j = 1; j < n_dyn; ++j) ds = ds + bcast(gw, j);
+        gw = lane_softmax<NE, TB>(gl, E, lane);
+        float gs[UMOE_MAXE];
+        gather16<ND>(gw, n_dyn, 0.f, gs);
+        float ds = gs[0];
+#pragma unroll
+        for (int j = 1; j < UMOE_MAXE; ++j)
+            if (j < LIM(ND, n_dyn)) ds = ds + gs[j];
         ds = round_t(ds, T);
         if (lane < n_dyn) gw = round_t(w * ds, T);
     }
@@ -199,9 +282,158 @@ __global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
     if (lane < n_dyn && a.routing_w) a.routing_w[(size_t)s * n_dyn + lane] = w;
     if (lane < a.n_real && a.moe_w) a.moe_w[(size_t)s * a.n_real + lane] = gw * (float)m;
     if (a.top_k && lane == 0) a.top_k[s] = k;
+    return m;  // this lane's mask entry (lane < E)
 }
 
-extern "C" int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream) {
+template <int ND, int NF, int TB>
+__global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
+    const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= a.S) return;
+    route_token<ND, NF, TB>(a, s, threadIdx.x & 63);
+}
+
+// decode-sized batches (S <= 16): one workgroup of 16 waves routes every token and then builds the ragged
+// dispatch tables from the masks it just produced -- router + dispatch in ONE launch.
+template <int ND, int NF, int TB>
+__global__ __launch_bounds__(1024) void router_dispatch_small_kernel(const umoe_router_args a, int32_t* counts,
+                                                                    int32_t* offsets, int32_t* slot_token, int32_t* slot_of) {
+    extern __shared__ __attribute__((aligned(16))) char gate_lds[];  // [E][D] bf16 when the fast path is taken
+    __shared__ int mask_s[16][UMOE_MAXE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int E = a.n_dyn + a.n_fix;
+    const bool fast = !a.logits_in && a.D <= 2048 && (a.D & 511) == 0;  // <= 4 sixteen-byte chunks per lane
+    if (fast) {
+        // ALL loads are issued before anything waits: the gate weights (cold in HBM; staged once for the 16 waves)
+        // and token w's row + norm weights (kept in registers: one pass for the sum of squares and the scaling)
+        const int gchunks = E * (a.D >> 3);
+        uint4 gt[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = threadIdx.x + 1024 * i;
+            if (c < gchunks) gt[i] = ld16(a.gate_w + (size_t)c * 8);
+        }
+        const int nch = a.D >> 9;  // chunks per lane (D/8/64)
+        uint4 xr[4], nw[4];
+        float logit = -INFINITY;
+        if (wave < a.S) {
+            const uint16_t* xrow = a.x + (size_t)wave * a.D;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < nch) {
+                    xr[n] = ld16(xrow + (lane + 64 * n) * 8);
+                    if (a.norm_w) nw[n] = ld16(a.norm_w + (lane + 64 * n) * 8);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = threadIdx.x + 1024 * i;
+            if (c < gchunks) st16(gate_lds + (size_t)c * 16, gt[i]);
+        }
+        if (wave < a.S) {
+            float rs = 1.f;
+            if (a.norm_w) {
+                float ss = 0.f;
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (n < nch) {
+                        float f[8];
+                        unpack8(xr[n], f);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+                    }
+                ss = wave_sum(ss);
+                rs = rsqrtf(ss / (float)a.D + a.rms_eps);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (n < nch) {
+                        float f[8], w[8];
+                        unpack8(xr[n], f);
+                        unpack8(nw[n], w);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
+                        xr[n] = pack8(f);
+                    }
+            }
+            if (a.h_out)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    if (n < nch) st16(a.h_out + (size_t)wave * a.D + (lane + 64 * n) * 8, xr[n]);
+        }
+        __syncthreads();
+        if (wave < a.S) {
+            float acc[UMOE_MAXE];
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < nch) {
+                    float f[8];
+                    unpack8(xr[n], f);
+#pragma unroll
+                    for (int e = 0; e < UMOE_MAXE; ++e)
+                        if (e < E) {
+                            float w[8];
+                            unpack8(*reinterpret_cast<const uint4*>(gate_lds + ((size_t)e * (a.D >> 3) + lane + 64 * n) * 16), w);
+                            float d = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) d += f[j] * w[j];
+                            acc[e] += d;
+                        }
+                }
+            const float mine = reduce16_to_lanes(acc, lane);
+            if (lane < E) logit = TB ? rbf(mine) : mine;
+            const int m = route_from_logits<ND, NF, TB>(a, wave, lane, logit);
+            if (lane < E) mask_s[wave][lane] = m;
+        }
+    } else if (wave < a.S) {
+        const int m = route_token<ND, NF, TB>(a, wave, lane);
+        if (lane < E) mask_s[wave][lane] = m;
+    }
+    __syncthreads();
+    // ragged dispatch tables by ballot + popcount: 16 lanes (tokens) per routed expert, token order preserved
+    __shared__ int cnt_s[UMOE_MAXE];
+    const int e = threadIdx.x >> 4, t = threadIdx.x & 15;
+    const bool mine = e < a.n_real;
+    const bool on = mine && t < a.S && mask_s[t][e] != 0;
+    const unsigned long long bal = __ballot(on);
+    const unsigned bits = (unsigned)((bal >> (16 * (e & 3))) & 0xffffull);
+    const int cnt = __popc(bits), pos = __popc(bits & ((1u << t) - 1u));
+    if (mine && t == 0) cnt_s[e] = cnt;
+    __syncthreads();
+    if (mine) {
+        int off = 0;
+        for (int ee = 0; ee < e; ++ee) off += cnt_s[ee];
+        if (t < a.S) slot_of[(size_t)t * a.n_real + e] = on ? off + pos : -1;
+        if (on) slot_token[off + pos] = t;
+        if (t == 0) {
+            counts[e] = cnt;
+            offsets[e] = off;
+            if (e == a.n_real - 1) offsets[a.n_real] = off + cnt;
+        }
+    }
+}
+
+extern "C" int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
+extern "C" int umoe_dispatch_build(const int32_t*, int, int, int, int32_t*, int32_t*, int32_t*, int32_t*, umoe_stream_t);
+
+template <int ND, int NF>
+static void launch_router(const umoe_router_args* a, dim3 grid, hipStream_t st) {
+    (void)grid;
+    // few tokens (decode): one wave per workgroup so every token's serial routing chain owns a SIMD on its own CU
+    const unsigned threads = a->S <= 256 ? 64u : 256u;
+    grid = dim3((unsigned)ceil_div(a->S, (int)(threads / 64)));
+    if (a->logits_bf16) router_kernel<ND, NF, 1><<<grid, threads, 0, st>>>(*a);
+    else router_kernel<ND, NF, 0><<<grid, threads, 0, st>>>(*a);
+}
+template <int ND, int NF>
+static void launch_router_small(const umoe_router_args* a, int32_t* c, int32_t* o, int32_t* st_, int32_t* so, hipStream_t st) {
+    const bool fast = !a->logits_in && a->D <= 2048 && (a->D & 511) == 0;
+    const size_t lds = fast ? (size_t)(a->n_dyn + a->n_fix) * a->D * 2 : 0;  // <= 64 KiB (16 x 2048 x 2)
+    if (a->logits_bf16) router_dispatch_small_kernel<ND, NF, 1><<<1, 1024, lds, st>>>(*a, c, o, st_, so);
+    else router_dispatch_small_kernel<ND, NF, 0><<<1, 1024, lds, st>>>(*a, c, o, st_, so);
+}
+
+static int router_check(const umoe_router_args* a) {
     UMOE_REQUIRE(a && a->expert_mask, "umoe_router_fwd: null argument");
     const int E = a->n_dyn + a->n_fix;
     UMOE_REQUIRE(a->S >= 0 && a->n_dyn >= 1 && E <= UMOE_MAXE && a->n_real <= a->n_dyn,
@@ -209,8 +441,59 @@ extern "C" int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream) 
                  a->n_fix, UMOE_MAXE);
     UMOE_REQUIRE(a->logits_in || (a->x && a->gate_w && a->D > 0 && a->D % 8 == 0),
                  "umoe_router_fwd: need logits_in or (x, gate_w, D %% 8 == 0)");
+    return 0;
+}
+
+// S <= 16: ragged dispatch tables by ballot + popcount, 16 lanes (tokens) per routed expert, token order preserved
+__global__ __launch_bounds__(256) void dispatch_small_kernel(const int32_t* __restrict__ mask, int S, int ld, int n_real,
+                                                             int32_t* counts, int32_t* offsets, int32_t* slot_token,
+                                                             int32_t* slot_of) {
+    __shared__ int cnt_s[UMOE_MAXE];
+    const int e = threadIdx.x >> 4, t = threadIdx.x & 15;
+    const bool mine = e < n_real;
+    const bool on = mine && t < S && mask[(size_t)t * ld + e] != 0;
+    const unsigned long long bal = __ballot(on);
+    const unsigned bits = (unsigned)((bal >> (16 * (e & 3))) & 0xffffull);
+    const int cnt = __popc(bits), pos = __popc(bits & ((1u << t) - 1u));
+    if (mine && t == 0) cnt_s[e] = cnt;
+    __syncthreads();
+    if (mine) {
+        int off = 0;
+        for (int ee = 0; ee < e; ++ee) off += cnt_s[ee];
+        if (t < S) slot_of[(size_t)t * n_real + e] = on ? off + pos : -1;
+        if (on) slot_token[off + pos] = t;
+        if (t == 0) {
+            counts[e] = cnt;
+            offsets[e] = off;
+            if (e == n_real - 1) offsets[n_real] = off + cnt;
+        }
+    }
+}
+
+// router + dispatch tables (decode, S <= 16: one-wave-per-token router + a 256-thread ballot dispatch)
+extern "C" int umoe_router_dispatch_fwd(const umoe_router_args* a, int32_t* counts, int32_t* offsets, int32_t* slot_token,
+                                        int32_t* slot_of, umoe_stream_t stream) {
+    if (int rc = router_check(a)) return rc;
+    UMOE_REQUIRE(counts && offsets && slot_token && slot_of, "umoe_router_dispatch_fwd: null table");
     if (a->S == 0) return 0;
-    router_kernel<<<dim3((unsigned)ceil_div(a->S, 4)), 256, 0, (hipStream_t)stream>>>(*a);
+    if (int rc = umoe_router_fwd(a, stream)) return rc;
+    if (a->S > 16)
+        return umoe_dispatch_build(a->expert_mask, a->S, a->n_dyn + a->n_fix, a->n_real, counts, offsets, slot_token, slot_of, stream);
+    dispatch_small_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a->expert_mask, a->S, a->n_dyn + a->n_fix, a->n_real, counts, offsets,
+                                                              slot_token, slot_of);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream) {
+    if (int rc = router_check(a)) return rc;
+    if (a->S == 0) return 0;
+    const dim3 grid((unsigned)ceil_div(a->S, 4));
+    hipStream_t st = (hipStream_t)stream;
+    // the shipped shapes (utils/config.json: 8 routed + 1 null + 2 shared) get fully unrolled, guard-free code
+    if (a->n_dyn == 9 && a->n_fix == 2) launch_router<9, 2>(a, grid, st);
+    else if (a->n_dyn == 8 && a->n_fix == 2) launch_router<8, 2>(a, grid, st);
+    else launch_router<0, 0>(a, grid, st);
     UMOE_LAUNCH_CHECK();
     return 0;
 }

@@ -94,6 +94,30 @@ def router_fwd(x: Optional[torch.Tensor], gate_w: Optional[torch.Tensor], *, n_d
     return o
 
 
+def router_dispatch_fwd(x, gate_w, *, n_dyn, n_real, n_fix, top_p, fixed_top_k=0, jitter_eps=0.01, norm_w=None,
+                        rms_eps=1e-6) -> dict:
+    """router + ragged dispatch tables; one fused launch when S <= 16 (the decode shape)."""
+    S, D = x.shape
+    E = n_dyn + n_fix
+    dev = x.device
+    o = dict(logits=torch.empty((S, E), dtype=torch.bfloat16, device=dev), top_k=torch.empty((S,), dtype=torch.int64, device=dev),
+             sel=torch.empty((S, n_dyn), dtype=torch.int32, device=dev), expert_mask=torch.empty((S, E), dtype=torch.int32, device=dev),
+             routing_weights=torch.empty((S, n_dyn), dtype=torch.float32, device=dev),
+             global_weight=torch.empty((S, E), dtype=torch.float32, device=dev),
+             moe_weight=torch.empty((S, n_real), dtype=torch.float32, device=dev),
+             counts=torch.zeros(16, dtype=torch.int32, device=dev), offsets=torch.zeros(17, dtype=torch.int32, device=dev),
+             slot_token=torch.zeros(max(1, S * n_real), dtype=torch.int32, device=dev),
+             slot_of=torch.empty((S, n_real), dtype=torch.int32, device=dev), h=torch.empty((S, D), dtype=torch.bfloat16, device=dev))
+    a = L.RouterArgs(x=_p(x), gate_w=_p(gate_w), norm_w=_p(norm_w), h_out=_p(o["h"]), logits_in=None, attn_mask=None, S=S, D=D,
+                     n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, logits_bf16=1, top_p=top_p, fixed_top_k=int(fixed_top_k),
+                     jitter_eps=jitter_eps, rms_eps=rms_eps, logits_out=_p(o["logits"]), top_k=_p(o["top_k"]), sel=_p(o["sel"]),
+                     expert_mask=_p(o["expert_mask"]), routing_w=_p(o["routing_weights"]), global_w=_p(o["global_weight"]),
+                     moe_w=_p(o["moe_weight"]))
+    L.check(L.lib().umoe_router_dispatch_fwd(C.byref(a), _p(o["counts"]), _p(o["offsets"]), _p(o["slot_token"]), _p(o["slot_of"]),
+                                             _stream()), "umoe_router_dispatch_fwd")
+    return o
+
+
 def dispatch_build(expert_mask: torch.Tensor, n_real: int) -> dict:
     S, ld = expert_mask.shape
     dev = expert_mask.device
@@ -139,34 +163,36 @@ class GroupTable:
 
 
 def grouped_gemm(table: GroupTable, a: torch.Tensor, out: torch.Tensor, *, max_rows: int, prologue=PRO_PLAIN,
-                 epilogue=EPI_BF16, norm_w=None, rms_eps=1e-6, resid=None, n_valid=None):
+                 epilogue=EPI_BF16, norm_w=None, rms_eps=1e-6, resid=None, n_valid=None, nt=0):
     args = L.GemmArgs(groups=_p(table.dev), num_groups=table.n, max_rows=max_rows, max_n_blocks=table.max_n_blocks,
                       max_k=table.max_k, a=_p(a), lda=a.stride(0), norm_w=_p(norm_w), rms_eps=rms_eps, resid=_p(resid),
                       out=_p(out), ldo=out.stride(0), n_valid=out.shape[1] if n_valid is None else n_valid,
-                      prologue=prologue, epilogue=epilogue)
+                      prologue=prologue, epilogue=epilogue, nt=nt)
     L.check(L.lib().umoe_grouped_gemm(C.byref(args), _stream()), "umoe_grouped_gemm")
     return out
 
 
 def linear(x: torch.Tensor, w_packed: torch.Tensor, N: int, *, bias: Optional[torch.Tensor] = None, norm_w=None,
-           rms_eps=1e-6, resid=None, out_f32=False) -> torch.Tensor:
+           rms_eps=1e-6, resid=None, out_f32=False, nt=0) -> torch.Tensor:
     """y = [rmsnorm](x) @ W^T (+bias) (+resid): one dense group."""
     S, K = x.shape
     tab = GroupTable([dict(w=w_packed, bias=bias, static_count=S, n_blocks=(N + 15) // 16, k=K)], x.device)
     out = torch.empty((S, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     epi = EPI_F32 if out_f32 else (EPI_BF16_RESID if resid is not None else EPI_BF16)
     return grouped_gemm(tab, x, out, max_rows=S, prologue=PRO_RMSNORM if norm_w is not None else PRO_PLAIN, epilogue=epi,
-                        norm_w=norm_w, rms_eps=rms_eps, resid=resid, n_valid=N)
+                        norm_w=norm_w, rms_eps=rms_eps, resid=resid, n_valid=N, nt=nt)
 
 
-def combine(y_slots, slot_of, moe_w, y_shared, global_w, resid, n_dyn: int, n_fix: int) -> torch.Tensor:
+def combine(y_slots, slot_of, moe_w, y_shared, global_w, resid, n_dyn: int, n_fix: int, norm_w=None, rms_eps=1e-6):
     S, n_real = slot_of.shape
     D = y_slots.shape[1]
     out = torch.empty((S, D), dtype=torch.bfloat16, device=y_slots.device)
+    hn = torch.empty_like(out) if norm_w is not None else None
     a = L.CombineArgs(y_slots=_p(y_slots), slot_of=_p(slot_of), moe_w=_p(moe_w), y_shared=_p(y_shared), global_w=_p(global_w),
-                      resid=_p(resid), out=_p(out), S=S, D=D, n_real=n_real, n_dyn=n_dyn, n_fix=n_fix)
+                      resid=_p(resid), out=_p(out), S=S, D=D, n_real=n_real, n_dyn=n_dyn, n_fix=n_fix, norm_w=_p(norm_w),
+                      norm_out=_p(hn), rms_eps=rms_eps)
     L.check(L.lib().umoe_unpermute_combine_fwd(C.byref(a), _stream()), "umoe_unpermute_combine_fwd")
-    return out
+    return (out, hn) if norm_w is not None else out
 
 
 # ----------------------------------------------------------------------------- norm / rope / attention
