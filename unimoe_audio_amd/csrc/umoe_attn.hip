@@ -69,7 +69,8 @@ extern "C" int umoe_qkv_mrope_kvappend(const umoe_rope_args* a, umoe_stream_t st
 }
 
 // ------------------------------------------------------------------------------------ attention
-// hd == 128 only (4 MFMA k-steps; lane owns 2 value columns).
+// hd == 128 only (4 MFMA k-steps; lane owns 2 value columns).  GP = GQA group size padded to a power of two.
+template <int GP>
 __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
     constexpr int HD = 128;
     __shared__ float p_lds[4][16][16];       // per wave: [key in tile][head]
@@ -106,21 +107,29 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
     }
     // running state: this lane's head is c (for m, l); O for ALL heads of the group on 2 columns
     float m_run = -INFINITY, l_run = 0.f;
-    float o[16][2];
+    float o[GP][2];
 #pragma unroll
-    for (int g = 0; g < 16; ++g) o[g][0] = o[g][1] = 0.f;
+    for (int g = 0; g < GP; ++g) o[g][0] = o[g][1] = 0.f;
 
     for (int k0 = kbeg + wave * 16; k0 < kend; k0 += 64) {
-        // S tile: D[key = 4*h4 + r][head = c]
-        f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+        // issue EVERY load of this tile up front: the 4 K fragments and the 16 V rows (2 columns per lane), so the
+        // tile pays one memory latency instead of one per key
+        uint4 kfr[4];
         {
             const int key = min(k0 + c, kend - 1);  // A operand row = lane&15 -> key index
             const uint16_t* kp = Kc + (size_t)key * HD + h4 * 32;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-                sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, ld16(kp + kb * 8)), qf[kb],
-                                                              sacc, 0, 0, 0);
+            for (int kb = 0; kb < 4; ++kb) kfr[kb] = ld16(kp + kb * 8);
         }
+        uint32_t vraw[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            vraw[kk] = *reinterpret_cast<const uint32_t*>(Vc + (size_t)min(k0 + kk, kend - 1) * HD + 2 * lane);
+        // S tile: D[key = 4*h4 + r][head = c]
+        f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kfr[kb]), qf[kb], sacc, 0, 0, 0);
         float sv[4];
         float tmax = -INFINITY;
 #pragma unroll
@@ -148,23 +157,34 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
         __builtin_amdgcn_wave_barrier();
         // P.V: lane owns value columns 2*lane, 2*lane+1
 #pragma unroll
-        for (int g = 0; g < 16; ++g)
-            if (g < G) {
-                const float al = al_lds[wave][g];
-                o[g][0] *= al;
-                o[g][1] *= al;
-            }
-        const int nk = min(16, kend - k0);
-        for (int kk = 0; kk < nk; ++kk) {
-            const uint32_t vv = *reinterpret_cast<const uint32_t*>(Vc + (size_t)(k0 + kk) * HD + 2 * lane);
-            const float v0 = __uint_as_float(vv << 16), v1 = __uint_as_float(vv & 0xffff0000u);
+        for (int g = 0; g < GP; ++g) {
+            const float al = al_lds[wave][g];
+            o[g][0] *= al;
+            o[g][1] *= al;
+        }
+        // keys beyond the slice carry p = 0 (masked above), so all 16 rows can be accumulated unconditionally;
+        // P comes back from LDS as 4 x 16-byte broadcasts per key (all lanes read the same address)
 #pragma unroll
-            for (int g = 0; g < 16; ++g)
-                if (g < G) {
-                    const float pv = p_lds[wave][kk][g];
-                    o[g][0] += pv * v0;
-                    o[g][1] += pv * v1;
+        for (int kk = 0; kk < 16; ++kk) {
+            const float v0 = __uint_as_float(vraw[kk] << 16), v1 = __uint_as_float(vraw[kk] & 0xffff0000u);
+            float pv[GP];
+            if (GP >= 4) {
+                const float4* pr4 = reinterpret_cast<const float4*>(&p_lds[wave][kk][0]);
+#pragma unroll
+                for (int q4 = 0; q4 < GP / 4; ++q4) {
+                    const float4 t4 = pr4[q4];
+                    pv[4 * q4] = t4.x; pv[4 * q4 + 1] = t4.y; pv[4 * q4 + 2] = t4.z; pv[4 * q4 + 3] = t4.w;
                 }
+            } else {
+#pragma unroll
+                for (int g = 0; g < GP; ++g) pv[g] = p_lds[wave][kk][g];
+            }
+#pragma unroll
+            for (int g = 0; g < GP; ++g) {   // heads >= G carry zero queries -> p is finite garbage-free, o unused
+                o[g][0] += pv[g] * v0;
+                o[g][1] += pv[g] * v1;
+            }
+            if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the unrolled body from hoisting all LDS reads
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -175,11 +195,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
         red_ml[wave][c][1] = l_run;
     }
 #pragma unroll
-    for (int g = 0; g < 16; ++g)
-        if (g < G) {
-            red_o[wave][g][2 * lane] = o[g][0];
-            red_o[wave][g][2 * lane + 1] = o[g][1];
-        }
+    for (int g = 0; g < GP; ++g) {
+        red_o[wave][g][2 * lane] = o[g][0];
+        red_o[wave][g][2 * lane + 1] = o[g][1];
+    }
     __syncthreads();
     // thread -> (head g, 8 columns): 16 heads x 16 column-groups
     const int g = tid >> 4, cg = tid & 15;
@@ -227,6 +246,15 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const umoe_attn_args 
     a.out[((size_t)qi * a.H + head) * HD + d] = f2bf(L > 0.f ? acc / L : 0.f);
 }
 
+static void launch_attn(const umoe_attn_args* a, dim3 grid, hipStream_t s) {
+    const int G = a->H / a->KVH;
+    if (G <= 1) attn_kernel<1><<<grid, 256, 0, s>>>(*a);
+    else if (G <= 2) attn_kernel<2><<<grid, 256, 0, s>>>(*a);
+    else if (G <= 4) attn_kernel<4><<<grid, 256, 0, s>>>(*a);
+    else if (G <= 8) attn_kernel<8><<<grid, 256, 0, s>>>(*a);
+    else attn_kernel<16><<<grid, 256, 0, s>>>(*a);
+}
+
 extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     UMOE_REQUIRE(a && a->q && a->k_cache && a->v_cache && a->kv_start && a->q_pos0 && a->part_o && a->part_ml && a->out,
                  "umoe_attn_decode: null argument");
@@ -240,7 +268,7 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     // grid.z <= 65535: fold large query counts
     UMOE_REQUIRE(nqi <= 65535u * 32u, "umoe_attn_decode: too many query tokens (%u)", nqi);
     if (nqi <= 65535u) {
-        attn_kernel<<<dim3((unsigned)a->splits, (unsigned)a->KVH, nqi), 256, 0, s>>>(*a);
+        launch_attn(a, dim3((unsigned)a->splits, (unsigned)a->KVH, nqi), s);
         UMOE_LAUNCH_CHECK();
         attn_combine_kernel<<<dim3((unsigned)a->H, nqi), 128, 0, s>>>(*a);
         UMOE_LAUNCH_CHECK();
@@ -258,7 +286,7 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
             b.part_o = a->part_o;
             b.part_ml = a->part_ml;
             UMOE_REQUIRE(a->nq <= 65535, "umoe_attn_decode: nq too large");
-            attn_kernel<<<dim3((unsigned)a->splits, (unsigned)a->KVH, (unsigned)a->nq), 256, 0, s>>>(b);
+            launch_attn(&b, dim3((unsigned)a->splits, (unsigned)a->KVH, (unsigned)a->nq), s);
             UMOE_LAUNCH_CHECK();
             attn_combine_kernel<<<dim3((unsigned)a->H, (unsigned)a->nq), 128, 0, s>>>(b);
             UMOE_LAUNCH_CHECK();
