@@ -107,6 +107,8 @@ typedef struct {
     int out_row_base;         /* output row = out_row_base + (row_off ? *row_off : 0) + r */
     int n_blocks;             /* N/16 (2*I/16 for gate/up pairs) */
     int k;                    /* K */
+    int a_col_off;            /* element offset added to every A row of this group (EP receive buffers) */
+    int reserved;
 } umoe_group_t;
 
 enum { UMOE_PRO_PLAIN = 0, UMOE_PRO_RMSNORM = 1 };

@@ -1,0 +1,124 @@
+"""CPU suite: the expert-parallel exchange (unimoe_audio_amd/ep.py) with world_size 2 over gloo.  The expert function
+is the CPU oracle's SwiGLU; the result on every rank must equal the single-process oracle DCMoE on that rank's tokens.
+Also covers bench.py's multi-rank aggregation (max over ranks)."""
+import os
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _cfg():
+    return types.SimpleNamespace(hidden_size=64, mlp_dynamic_expert_num=8, mlp_dynamic_null_expert_num=1, mlp_dynamic_top_p=0.7,
+                                 mlp_dynamic_top_k=2, mlp_fixed_expert_num=2, router_jitter_noise=0.01, token_drop=False,
+                                 fp32_gate=True, capacity_factor=6.0, min_capacity=8, drop_policy="probs",
+                                 dynamic_intermediate_size=96, shared_intermediate_size=64)
+
+
+def _weights(cfg, seed):
+    from oracle.dcmoe import EXPERT_FMT, SHARED_FMT
+    g = torch.Generator().manual_seed(seed)
+    w = {"gate.weight": (torch.randn(11, 64, generator=g) * 0.3).to(torch.bfloat16)}
+    for e in range(8):
+        for p, shp in (("gate", (96, 64)), ("up", (96, 64)), ("down", (64, 96))):
+            w[EXPERT_FMT.format(e=e, p=p)] = (torch.randn(*shp, generator=g) * 0.08).to(torch.bfloat16)
+    for i in range(2):
+        for p, shp in (("gate", (64, 64)), ("up", (64, 64)), ("down", (64, 64))):
+            w[SHARED_FMT.format(i=i, p=p)] = (torch.randn(*shp, generator=g) * 0.08).to(torch.bfloat16)
+    return w
+
+
+def _worker(rank, world, port, S, out_q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import router as OR
+        from oracle.dcmoe import DCMoEOracle, EXPERT_FMT, swiglu_mlp
+        from unimoe_audio_amd import ep as EP
+        cfg, w = _cfg(), _weights(_cfg(), 5)
+        n_real, n_dyn, n_fix = 8, 9, 2
+        E_loc = n_real // world
+        torch.manual_seed(100 + rank)
+        x = torch.randn(1, S, 64).to(torch.bfloat16)
+        ref = DCMoEOracle(cfg, w)(x, None, None)
+        h = x[0]
+        logits = torch.nn.functional.linear(h, w["gate.weight"])
+        r = OR.route(logits, n_dyn, n_real, n_fix, 0.7, 0, 0.01, None)
+        d = OR.dispatch(r["expert_mask"], n_real)
+        disp = dict(counts=d["counts"], offsets=d["offsets"], slot_token=torch.cat([d["slot_token"], torch.zeros(1, dtype=torch.int32)]),
+                    slot_of=d["slot_of"])
+
+        def expert_fn(recv, cnt):            # recv [ep, S, E_loc, D]: my local experts on the rows of every source rank
+            y = torch.zeros_like(recv)
+            for e_loc in range(E_loc):
+                e = rank * E_loc + e_loc
+                for src in range(world):
+                    n = int(cnt[src, e_loc])
+                    if n:
+                        y[src, :n, e_loc] = swiglu_mlp(recv[src, :n, e_loc], w[EXPERT_FMT.format(e=e, p="gate")],
+                                                       w[EXPERT_FMT.format(e=e, p="up")], w[EXPERT_FMT.format(e=e, p="down")])
+            return y
+        y_back, slot_of_ep = EP.ep_moe(h, disp, n_real, world, dist.group.WORLD, expert_fn)
+        # combine exactly as the single-GPU path does (ascending expert order, fp32 accumulate, one rounding)
+        moe_w = r["moe_weight"].float()
+        acc = torch.zeros(S, 64)
+        for e in range(n_real):
+            so = slot_of_ep[:, e].long()
+            sel = so >= 0
+            acc[sel] += moe_w[sel, e:e + 1] * y_back[so[sel]].float()
+        moe_out = acc.to(torch.bfloat16)
+        # reference MoE-only output = block output minus shared experts: recompute the same way on one process
+        one = DCMoEOracle(cfg, w)
+        ref_moe = one.moe_layer(h, r["expert_mask"][:, :n_real], r["global_weight"][:, :n_real])
+        ok = torch.allclose(moe_out.float(), ref_moe.float(), rtol=2 ** -6, atol=2 ** -9)
+        out_q.put((rank, bool(ok), float((moe_out.float() - ref_moe.float()).abs().max())))
+        # bench.py aggregation: MAX over ranks of the timed region
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out_q.put(("max", float(t)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("S", [5, 16])
+def test_ep_exchange_world2_gloo(S):
+    import random
+    port = random.randint(20000, 40000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, S, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(4)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    oks = [r for r in res if r[0] in (0, 1)]
+    assert len(oks) == 2 and all(r[1] for r in oks), oks
+    assert all(r[1] == 2.0 for r in res if r[0] == "max")
+
+
+def test_ep_index_math_single_process():
+    """ep_size 1 must be the identity exchange (the reference's single-process patch, utils.py:332-335)."""
+    from oracle import router as OR
+    from unimoe_audio_amd import ep as EP
+    torch.manual_seed(3)
+    S, D, n_real = 7, 16, 8
+    mask = (torch.rand(S, 11) < 0.5).to(torch.int32)
+    d = OR.dispatch(mask, n_real)
+    h = torch.randn(S, D)
+    disp = dict(counts=d["counts"], offsets=d["offsets"], slot_token=torch.cat([d["slot_token"], torch.zeros(1, dtype=torch.int32)]),
+                slot_of=d["slot_of"])
+    y_back, so = EP.ep_moe(h, disp, n_real, 1, None, lambda recv, cnt: recv * 2.0)
+    for s in range(S):
+        for e in range(n_real):
+            if mask[s, e]:
+                assert torch.equal(y_back[int(so[s, e])], h[s] * 2.0)
+            else:
+                assert int(so[s, e]) == -1

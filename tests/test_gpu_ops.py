@@ -404,3 +404,73 @@ def test_rvq_roundtrip_code_ids_exact(dev):
     e0 = (in_w[0] @ z).t()
     sim = torch.nn.functional.normalize(e0, dim=-1) @ torch.nn.functional.normalize(cb[0], dim=-1).t()
     assert torch.equal(q0[0].long(), sim.argmax(-1))
+
+
+# ----------------------------------------------------------------------------- expert parallel (HIP path, 2 virtual ranks)
+def test_dcmoe_expert_parallel_two_virtual_ranks(dev):
+    """ep_size = 2 on ONE GPU: two module instances (4 local experts each) exchange rows through a thread-rendezvous
+    all-to-all; every rank's output must be bit-identical to the ep_size = 1 block on the same tokens."""
+    import threading
+    from unimoe_audio_amd import ep as EP
+    from unimoe_audio_amd.config import UniMoEAudioConfig
+    from unimoe_audio_amd.dcmoe import UniMoEAudioSparseMoeBlock
+    cfg1 = UniMoEAudioConfig(hidden_size=256, dynamic_intermediate_size=128, shared_intermediate_size=64)
+    torch.manual_seed(77)
+    full = UniMoEAudioSparseMoeBlock(cfg1)
+    with torch.no_grad():
+        for n, p in full.named_parameters():
+            p.normal_(0, 0.3 if n == "gate.weight" else 0.06)
+    full = full.to(torch.bfloat16).eval().to(dev)
+    world, S = 2, 11
+    cfg2 = UniMoEAudioConfig(hidden_size=256, dynamic_intermediate_size=128, shared_intermediate_size=64, ep_size=world)
+    ranks = []
+    fsd = full.state_dict()
+    for r in range(world):
+        blk = UniMoEAudioSparseMoeBlock(cfg2).to(torch.bfloat16).eval()
+        sd = {}
+        for k, v in blk.state_dict().items():
+            if "deepspeed_experts." in k:
+                e_loc = int(k.split("deepspeed_experts.")[1].split(".")[0])
+                sd[k] = fsd[k.replace(f"deepspeed_experts.{e_loc}.", f"deepspeed_experts.{r * 4 + e_loc}.")]
+            else:
+                sd[k] = fsd[k]
+        blk.load_state_dict(sd)
+        blk = blk.to(dev)
+        blk.dynamic_real_moe.set_deepspeed_parallelism(ep_group=("virtual", r))
+        ranks.append(blk)
+    xs = [torch.randn(1, S, 256).to(torch.bfloat16).to(dev) for _ in range(world)]
+    bar = threading.Barrier(world)
+    box = {}
+
+    def fake_a2a(out, inp, group):
+        r = group[1]
+        box[r] = inp
+        bar.wait()
+        for src in range(world):
+            out[src].copy_(box[src][r])
+        torch.cuda.synchronize()
+        bar.wait()
+        return out
+    orig = EP._a2a
+    EP._a2a = fake_a2a
+    outs, errs = [None] * world, []
+
+    def run(r):
+        try:
+            with torch.no_grad():
+                outs[r] = ranks[r](xs[r], None, None)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            bar.abort()
+    try:
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    finally:
+        EP._a2a = orig
+    assert not errs, errs
+    for r in range(world):
+        with torch.no_grad():
+            ref = full(xs[r], None, None)
+        assert torch.equal(outs[r][3], ref[3]) and torch.equal(outs[r][2], ref[2])
+        assert torch.equal(outs[r][0], ref[0]), float((outs[r][0].float() - ref[0].float()).abs().max())

@@ -41,7 +41,7 @@ class RouterArgs(C.Structure):
 
 class Group(C.Structure):
     _fields_ = [("w", vp), ("bias", vp), ("rows", vp), ("row_off", vp), ("count", vp), ("static_count", i32),
-                ("a_row_base", i32), ("out_row_base", i32), ("n_blocks", i32), ("k", i32)]
+                ("a_row_base", i32), ("out_row_base", i32), ("n_blocks", i32), ("k", i32), ("a_col_off", i32), ("reserved", i32)]
 
 
 class GemmArgs(C.Structure):

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
         const bool valid = r < count;
         long arow = 0;
         if (valid) arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
-        const uint16_t* src = p.a + arow * (long)p.lda;
+        const uint16_t* src = p.a + arow * (long)p.lda + g.a_col_off;
         char* dst = smem + m * RS;
         const int Q8 = KB;  // 16-byte chunks per quarter
         if (PRO == UMOE_PRO_RMSNORM && 4 * Q8 <= 256) {

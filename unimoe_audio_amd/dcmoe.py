@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import ep as EP
 from . import ops
 
 
@@ -175,23 +176,30 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
             expert_mask, global_w, moe_w = self._token_drop(logits, expert_mask, r["routing_weights"], S)
         disp = ops.dispatch_build(expert_mask, n_real)
         I_d, I_s = self.dynamic_intermediate_size, self.shared_intermediate_size
-        Imax = max(I_d, I_s if n_fix else 0)
-        slots = S * n_real
-        groups_gu, groups_dn = [], []
-        for e in range(n_real):
-            off, cnt = disp["offsets"][e:e + 1], disp["counts"][e:e + 1]
-            groups_gu.append(dict(w=pk["exp_gu"][e], rows=disp["slot_token"], row_off=off, count=cnt,
-                                  n_blocks=2 * I_d // 16, k=D))
-            groups_dn.append(dict(w=pk["exp_dn"][e], row_off=off, count=cnt, n_blocks=D // 16, k=I_d))
-        for i in range(n_fix):
-            groups_gu.append(dict(w=pk["sh_gu"][i], static_count=S, out_row_base=slots + i * S, n_blocks=2 * I_s // 16, k=D))
-            groups_dn.append(dict(w=pk["sh_dn"][i], static_count=S, a_row_base=slots + i * S, out_row_base=slots + i * S,
-                                  n_blocks=D // 16, k=I_s))
-        hbuf = torch.empty((slots + n_fix * S, Imax), dtype=torch.bfloat16, device=x.device)
-        ybuf = torch.empty((slots + n_fix * S, D), dtype=torch.bfloat16, device=x.device)
-        ops.grouped_gemm(ops.GroupTable(groups_gu, x.device), x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Imax)
-        ops.grouped_gemm(ops.GroupTable(groups_dn, x.device), hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D)
-        out = ops.combine(ybuf, disp["slot_of"], moe_w, ybuf[slots:] if n_fix else None, global_w, None, n_dyn, n_fix)
+        ep = int(self.dynamic_real_moe.ep_size)
+        if ep > 1:
+            y_back, slot_of_ep = EP.ep_moe(x, disp, n_real, ep, self.dynamic_real_moe.deepspeed_moe.ep_group,
+                                           lambda recv, cnt: self._local_experts(recv, cnt, pk))
+            y_sh = self._shared_experts(x, pk) if n_fix else None
+            out = ops.combine(y_back, slot_of_ep, moe_w, y_sh, global_w, None, n_dyn, n_fix)
+        else:
+            Imax = max(I_d, I_s if n_fix else 0)
+            slots = S * n_real
+            groups_gu, groups_dn = [], []
+            for e in range(n_real):
+                off, cnt = disp["offsets"][e:e + 1], disp["counts"][e:e + 1]
+                groups_gu.append(dict(w=pk["exp_gu"][e], rows=disp["slot_token"], row_off=off, count=cnt,
+                                      n_blocks=2 * I_d // 16, k=D))
+                groups_dn.append(dict(w=pk["exp_dn"][e], row_off=off, count=cnt, n_blocks=D // 16, k=I_d))
+            for i in range(n_fix):
+                groups_gu.append(dict(w=pk["sh_gu"][i], static_count=S, out_row_base=slots + i * S, n_blocks=2 * I_s // 16, k=D))
+                groups_dn.append(dict(w=pk["sh_dn"][i], static_count=S, a_row_base=slots + i * S, out_row_base=slots + i * S,
+                                      n_blocks=D // 16, k=I_s))
+            hbuf = torch.empty((slots + n_fix * S, Imax), dtype=torch.bfloat16, device=x.device)
+            ybuf = torch.empty((slots + n_fix * S, D), dtype=torch.bfloat16, device=x.device)
+            ops.grouped_gemm(ops.GroupTable(groups_gu, x.device), x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Imax)
+            ops.grouped_gemm(ops.GroupTable(groups_dn, x.device), hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D)
+            out = ops.combine(ybuf, disp["slot_of"], moe_w, ybuf[slots:] if n_fix else None, global_w, None, n_dyn, n_fix)
         out = out.reshape(B, T, D)
         if (not self.training) and self.avg_hidden_states_last:               # core.py:355-356
             import torch.distributed as dist
@@ -199,6 +207,42 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
             if dist.is_initialized():
                 dist.all_reduce(out, op=dist.ReduceOp.AVG, group=grp)
         return out, logits, top_k, expert_mask, global_w.to(hidden_states.dtype), aux
+
+    # ---- expert-parallel pieces -----------------------------------------------------------------------------------
+    def _local_experts(self, recv: torch.Tensor, recv_cnt: torch.Tensor, pk) -> torch.Tensor:
+        """recv [ep, S, E_loc, D] rows routed to this rank's experts -> y of the same shape (grouped SwiGLU on the
+        compacted rows of all source ranks; one group per local expert)."""
+        ep, S, E_loc, D = recv.shape
+        I_d = self.dynamic_intermediate_size
+        mask2 = EP.ep_recv_mask(recv_cnt, S)
+        d2 = ops.dispatch_build(mask2, E_loc)
+        T2 = ep * S
+        gu, dn = [], []
+        for e in range(E_loc):
+            off, cnt = d2["offsets"][e:e + 1], d2["counts"][e:e + 1]
+            gu.append(dict(w=pk["exp_gu"][e], rows=d2["slot_token"], row_off=off, count=cnt, n_blocks=2 * I_d // 16, k=D,
+                           a_col_off=e * D))
+            dn.append(dict(w=pk["exp_dn"][e], row_off=off, count=cnt, n_blocks=D // 16, k=I_d))
+        a2 = recv.reshape(T2, E_loc * D)
+        hbuf = torch.empty((T2 * E_loc, I_d), dtype=torch.bfloat16, device=recv.device)
+        ybuf = torch.zeros((T2 * E_loc + 1, D), dtype=torch.bfloat16, device=recv.device)    # last row = zeros for -1
+        ops.grouped_gemm(ops.GroupTable(gu, recv.device), a2, hbuf, max_rows=T2, epilogue=ops.EPI_SWIGLU, n_valid=I_d)
+        ops.grouped_gemm(ops.GroupTable(dn, recv.device), hbuf, ybuf, max_rows=T2, epilogue=ops.EPI_BF16, n_valid=D)
+        so = d2["slot_of"].long()                                             # [T2, E_loc], -1 = no row
+        idx = torch.where(so >= 0, so, torch.full_like(so, T2 * E_loc))
+        return ybuf[idx.reshape(-1)].reshape(ep, S, E_loc, D)
+
+    def _shared_experts(self, x: torch.Tensor, pk) -> torch.Tensor:
+        S, D = x.shape
+        n_fix, I_s = self.mlp_fixed_expert_num, self.shared_intermediate_size
+        gu = [dict(w=pk["sh_gu"][i], static_count=S, out_row_base=i * S, n_blocks=2 * I_s // 16, k=D) for i in range(n_fix)]
+        dn = [dict(w=pk["sh_dn"][i], static_count=S, a_row_base=i * S, out_row_base=i * S, n_blocks=D // 16, k=I_s)
+              for i in range(n_fix)]
+        hbuf = torch.empty((n_fix * S, I_s), dtype=torch.bfloat16, device=x.device)
+        ybuf = torch.empty((n_fix * S, D), dtype=torch.bfloat16, device=x.device)
+        ops.grouped_gemm(ops.GroupTable(gu, x.device), x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=I_s)
+        ops.grouped_gemm(ops.GroupTable(dn, x.device), hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D)
+        return ybuf
 
     # ---- rarely used branch, device torch ops (shipped config: token_drop = false) ------------------------
     def _token_drop(self, logits, expert_mask, routing_w, num_tokens):

@@ -1,0 +1,94 @@
+"""Expert-parallel exchange for the DCMoE layer (one process per GPU, torch.distributed: "nccl" = RCCL over xGMI).
+
+Replaces the reference's AudioMOELayer exchange (reference utils/UniMoE_Audio_core.py:455-488): there, every rank pads
+each expert's rows to the GLOBAL maximum capacity (an extra scalar MAX all-reduce, core.py:455-457) and ships
+[E, C, D] through DeepSpeed's `_AllToAll` twice.  Here:
+  * rank r owns routed experts [r*E_loc, (r+1)*E_loc)  (core.py:505);
+  * the per-(destination expert) capacity is fixed at S_local rows -- every local row can pick an expert at most once --
+    so no collective is needed to agree on a capacity and the buffers are static (hipGraph friendly);
+  * counts travel in the same exchange pattern (one small all-to-all), rows in one all-to-all each way;
+  * the combine sums experts in ascending expert order on the token's owner, exactly like the single-GPU path.
+The index arithmetic below is backend-agnostic torch code (it runs under gloo on CPU in tests/test_ep_gloo.py with
+the oracle as the expert function); on a GPU the expert function is the HIP grouped GEMM.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def _a2a(out: torch.Tensor, inp: torch.Tensor, group):
+    if group is None or dist.get_world_size(group) == 1:
+        out.copy_(inp)          # the reference's single-process behaviour: identity (utils.py:332-335)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+    return out
+
+
+def ep_pack(h: torch.Tensor, counts: torch.Tensor, offsets: torch.Tensor, slot_token: torch.Tensor, n_real: int,
+            ep_size: int):
+    """Builds the send buffers: send [ep(dst), S(pos), E_loc, D] (rows of expert e compacted at positions < count[e]) and
+    send_cnt [ep(dst), E_loc]."""
+    S, D = h.shape
+    E_loc = n_real // ep_size
+    pos = torch.arange(S, device=h.device)
+    cnt = counts[:n_real].long()
+    valid = pos[None, :] < cnt[:, None]                                        # [n_real, S]
+    src_slot = (offsets[:n_real].long()[:, None] + pos[None, :]).clamp(max=max(slot_token.numel() - 1, 0))
+    rows = slot_token.long()[src_slot]                                          # token feeding (expert e, position pos)
+    send = h[rows.reshape(-1)].reshape(n_real, S, D) * valid[..., None].to(h.dtype)
+    send = send.reshape(ep_size, E_loc, S, D).permute(0, 2, 1, 3).contiguous()  # [ep(dst), S, E_loc, D]
+    send_cnt = counts[:n_real].reshape(ep_size, E_loc).contiguous()
+    return send, send_cnt
+
+
+def ep_dispatch(h: torch.Tensor, counts: torch.Tensor, offsets: torch.Tensor, slot_token: torch.Tensor, n_real: int,
+                ep_size: int, group=None):
+    """h [S, D]; counts/offsets/slot_token = local ragged dispatch tables (umoe_dispatch_build).
+    Returns recv [ep(src), S(pos), E_loc, D] and recv_cnt [ep(src), E_loc]: the rows rank `src` routed to MY experts,
+    compacted per expert (positions >= count are zero rows).  First all-to-all of the reference (core.py:467)."""
+    send, send_cnt = ep_pack(h, counts, offsets, slot_token, n_real, ep_size)
+    recv = torch.empty_like(send)
+    _a2a(recv, send, group)
+    recv_cnt = torch.empty_like(send_cnt)
+    _a2a(recv_cnt, send_cnt, group)
+    return recv, recv_cnt
+
+
+def ep_recv_mask(recv_cnt: torch.Tensor, S: int) -> torch.Tensor:
+    """[ep*S "tokens" (src, pos)][E_loc] 0/1 mask of the received rows (input of the ragged dispatch on the receiver)."""
+    ep, E_loc = recv_cnt.shape
+    pos = torch.arange(S, device=recv_cnt.device)
+    m = pos[None, :, None] < recv_cnt.long()[:, None, :]                        # [ep, S, E_loc]
+    return m.reshape(ep * S, E_loc).to(torch.int32).contiguous()
+
+
+def ep_return(y: torch.Tensor, group=None) -> torch.Tensor:
+    """y [ep(src), S, E_loc, D] expert outputs for the rows received -> [ep(owner), S, E_loc, D] on the token owner
+    (second all-to-all, core.py:480)."""
+    out = torch.empty_like(y)
+    return _a2a(out, y.contiguous(), group)
+
+
+def ep_slot_of(slot_of: torch.Tensor, offsets: torch.Tensor, S: int, ep_size: int) -> torch.Tensor:
+    """Local slot_of [S, n_real] (slot = offsets[e] + pos) -> row index into the returned [ep*S*E_loc, D] buffer
+    (row = (owner*S + pos)*E_loc + e_loc), -1 where the token is not routed to e."""
+    n_real = slot_of.shape[1]
+    E_loc = n_real // ep_size
+    e = torch.arange(n_real, device=slot_of.device)[None, :]
+    pos = slot_of.long() - offsets[:n_real].long()[None, :]
+    row = ((e // E_loc) * S + pos) * E_loc + (e % E_loc)
+    return torch.where(slot_of >= 0, row, torch.full_like(pos, -1)).to(torch.int32).contiguous()
+
+
+def ep_moe(h: torch.Tensor, disp: dict, n_real: int, ep_size: int, group,
+           expert_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor]):
+    """Full exchange around `expert_fn(recv [ep, S, E_loc, D], recv_cnt [ep, E_loc]) -> y [ep, S, E_loc, D]`.
+    Returns (y_back [ep*S*E_loc, D], slot_of_ep [S, n_real]) ready for the combine."""
+    S = h.shape[0]
+    recv, recv_cnt = ep_dispatch(h, disp["counts"], disp["offsets"], disp["slot_token"], n_real, ep_size, group)
+    y = expert_fn(recv, recv_cnt)
+    back = ep_return(y, group)
+    return back.reshape(-1, back.shape[-1]), ep_slot_of(disp["slot_of"], disp["offsets"], S, ep_size)

@@ -155,6 +155,7 @@ class GroupTable:
             arr[i].out_row_base = int(g.get("out_row_base", 0))
             arr[i].n_blocks = int(g["n_blocks"])
             arr[i].k = int(g["k"])
+            arr[i].a_col_off = int(g.get("a_col_off", 0))
         raw = bytes(arr)
         self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.n = len(groups)
