@@ -4,9 +4,10 @@
 // layer (utils/UniMoE_Audio_core.py:246-291, 94-167, 178-193; dispatch: utils/UniMoE_Audio_utils.py
 // :436-523) with two launches and no host sync.
 //
-// router_kernel: one 64-lane wave per token.  The gate GEMV (11 dot products of length D) is
-// spread over the wave and reduced with a fixed xor butterfly; afterwards lane e owns router
-// column e and the Top-P count / iterative arg-max mixer run lane-parallel with wave shuffles --
+// router_kernel: one 64-lane wave per token (decode: one wave per workgroup, so each token's serial
+// chain owns a SIMD).  The gate GEMV (11 dot products of length D) is spread over the wave and
+// reduced with a fixed reduce-scatter tree; afterwards lane e owns router column e and the Top-P
+// count / iterative arg-max mixer run on v_readlane gathers with compile-time sizes --
 // every fp32 operation happens in the order fixed by the arithmetic contract of
 // oracle/router_oracle.c (sequential softmax sum, reciprocal multiply, deterministic exp, cumsum
 // accumulator type, thresholds cast to T), so integer outputs are bit-exact given equal logits.
@@ -292,127 +293,6 @@ __global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
     route_token<ND, NF, TB>(a, s, threadIdx.x & 63);
 }
 
-// decode-sized batches (S <= 16): one workgroup of 16 waves routes every token and then builds the ragged
-// dispatch tables from the masks it just produced -- router + dispatch in ONE launch.
-template <int ND, int NF, int TB>
-__global__ __launch_bounds__(1024) void router_dispatch_small_kernel(const umoe_router_args a, int32_t* counts,
-                                                                    int32_t* offsets, int32_t* slot_token, int32_t* slot_of) {
-    extern __shared__ __attribute__((aligned(16))) char gate_lds[];  // [E][D] bf16 when the fast path is taken
-    __shared__ int mask_s[16][UMOE_MAXE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int E = a.n_dyn + a.n_fix;
-    const bool fast = !a.logits_in && a.D <= 2048 && (a.D & 511) == 0;  // <= 4 sixteen-byte chunks per lane
-    if (fast) {
-        // ALL loads are issued before anything waits: the gate weights (cold in HBM; staged once for the 16 waves)
-        // and token w's row + norm weights (kept in registers: one pass for the sum of squares and the scaling)
-        const int gchunks = E * (a.D >> 3);
-        uint4 gt[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = threadIdx.x + 1024 * i;
-            if (c < gchunks) gt[i] = ld16(a.gate_w + (size_t)c * 8);
-        }
-        const int nch = a.D >> 9;  // chunks per lane (D/8/64)
-        uint4 xr[4], nw[4];
-        float logit = -INFINITY;
-        if (wave < a.S) {
-            const uint16_t* xrow = a.x + (size_t)wave * a.D;
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                if (n < nch) {
-                    xr[n] = ld16(xrow + (lane + 64 * n) * 8);
-                    if (a.norm_w) nw[n] = ld16(a.norm_w + (lane + 64 * n) * 8);
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = threadIdx.x + 1024 * i;
-            if (c < gchunks) st16(gate_lds + (size_t)c * 16, gt[i]);
-        }
-        if (wave < a.S) {
-            float rs = 1.f;
-            if (a.norm_w) {
-                float ss = 0.f;
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    if (n < nch) {
-                        float f[8];
-                        unpack8(xr[n], f);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
-                    }
-                ss = wave_sum(ss);
-                rs = rsqrtf(ss / (float)a.D + a.rms_eps);
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    if (n < nch) {
-                        float f[8], w[8];
-                        unpack8(xr[n], f);
-                        unpack8(nw[n], w);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
-                        xr[n] = pack8(f);
-                    }
-            }
-            if (a.h_out)
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    if (n < nch) st16(a.h_out + (size_t)wave * a.D + (lane + 64 * n) * 8, xr[n]);
-        }
-        __syncthreads();
-        if (wave < a.S) {
-            float acc[UMOE_MAXE];
-#pragma unroll
-            for (int e = 0; e < UMOE_MAXE; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-                if (n < nch) {
-                    float f[8];
-                    unpack8(xr[n], f);
-#pragma unroll
-                    for (int e = 0; e < UMOE_MAXE; ++e)
-                        if (e < E) {
-                            float w[8];
-                            unpack8(*reinterpret_cast<const uint4*>(gate_lds + ((size_t)e * (a.D >> 3) + lane + 64 * n) * 16), w);
-                            float d = 0.f;
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) d += f[j] * w[j];
-                            acc[e] += d;
-                        }
-                }
-            const float mine = reduce16_to_lanes(acc, lane);
-            if (lane < E) logit = TB ? rbf(mine) : mine;
-            const int m = route_from_logits<ND, NF, TB>(a, wave, lane, logit);
-            if (lane < E) mask_s[wave][lane] = m;
-        }
-    } else if (wave < a.S) {
-        const int m = route_token<ND, NF, TB>(a, wave, lane);
-        if (lane < E) mask_s[wave][lane] = m;
-    }
-    __syncthreads();
-    // ragged dispatch tables by ballot + popcount: 16 lanes (tokens) per routed expert, token order preserved
-    __shared__ int cnt_s[UMOE_MAXE];
-    const int e = threadIdx.x >> 4, t = threadIdx.x & 15;
-    const bool mine = e < a.n_real;
-    const bool on = mine && t < a.S && mask_s[t][e] != 0;
-    const unsigned long long bal = __ballot(on);
-    const unsigned bits = (unsigned)((bal >> (16 * (e & 3))) & 0xffffull);
-    const int cnt = __popc(bits), pos = __popc(bits & ((1u << t) - 1u));
-    if (mine && t == 0) cnt_s[e] = cnt;
-    __syncthreads();
-    if (mine) {
-        int off = 0;
-        for (int ee = 0; ee < e; ++ee) off += cnt_s[ee];
-        if (t < a.S) slot_of[(size_t)t * a.n_real + e] = on ? off + pos : -1;
-        if (on) slot_token[off + pos] = t;
-        if (t == 0) {
-            counts[e] = cnt;
-            offsets[e] = off;
-            if (e == a.n_real - 1) offsets[a.n_real] = off + cnt;
-        }
-    }
-}
-
 extern "C" int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 extern "C" int umoe_dispatch_build(const int32_t*, int, int, int, int32_t*, int32_t*, int32_t*, int32_t*, umoe_stream_t);
 
@@ -425,14 +305,6 @@ static void launch_router(const umoe_router_args* a, dim3 grid, hipStream_t st) 
     if (a->logits_bf16) router_kernel<ND, NF, 1><<<grid, threads, 0, st>>>(*a);
     else router_kernel<ND, NF, 0><<<grid, threads, 0, st>>>(*a);
 }
-template <int ND, int NF>
-static void launch_router_small(const umoe_router_args* a, int32_t* c, int32_t* o, int32_t* st_, int32_t* so, hipStream_t st) {
-    const bool fast = !a->logits_in && a->D <= 2048 && (a->D & 511) == 0;
-    const size_t lds = fast ? (size_t)(a->n_dyn + a->n_fix) * a->D * 2 : 0;  // <= 64 KiB (16 x 2048 x 2)
-    if (a->logits_bf16) router_dispatch_small_kernel<ND, NF, 1><<<1, 1024, lds, st>>>(*a, c, o, st_, so);
-    else router_dispatch_small_kernel<ND, NF, 0><<<1, 1024, lds, st>>>(*a, c, o, st_, so);
-}
-
 static int router_check(const umoe_router_args* a) {
     UMOE_REQUIRE(a && a->expert_mask, "umoe_router_fwd: null argument");
     const int E = a->n_dyn + a->n_fix;
