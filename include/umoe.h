@@ -136,6 +136,9 @@ typedef struct {
     int n_valid;              /* columns >= n_valid are not stored (N not multiple of 16) */
     int prologue, epilogue;
     int nt;                   /* n-blocks per workgroup: 0 = auto, else 1/2/4/8 (tuning knob) */
+    int waves;                /* waves per workgroup: 0 = auto, 4, 8 (8 only with nt = 8; tuning knob) */
+    int ksplit;               /* >1: K split over workgroups; needs UMOE_EPI_F32_RAW: slab s at out + s*part_stride */
+    long part_stride;         /* elements between fp32 partial slabs */
 } umoe_gemm_args;
 int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream);
 
@@ -149,7 +152,7 @@ int umoe_grouped_swiglu_fwd(const umoe_group_t* gateup_groups, const umoe_group_
 /* combine: out[s] = resid[s] + ( sum_e moe_w[s][e] * y[slot_of[s][e]]  (+ shared_i[s] * global_w[s][n_dyn+i]) )
  * with the reference's rounding points (einsum core.py:488, adds :342,:351, residual model.py:242). */
 typedef struct {
-    const uint16_t* y_slots;  /* [slots][D] routed expert outputs */
+    const uint16_t* y_slots;  /* [slots][D] routed expert outputs (bf16), or NULL when y_parts is used */
     const int32_t* slot_of;   /* [S][n_real] */
     const float* moe_w;       /* [S][n_real] */
     const uint16_t* y_shared; /* [n_fix][S][D] or NULL */
@@ -157,6 +160,10 @@ typedef struct {
     const uint16_t* resid;    /* [S][D] or NULL */
     uint16_t* out;            /* [S][D] */
     int S, D, n_real, n_dyn, n_fix;
+    const float* y_parts;     /* optional fp32 partial slabs [n_parts][rows][D] of a K-split down GEMM: y = bf16(sum) */
+    int n_parts;
+    long part_stride;
+    int shared_row0;          /* >= 0: the shared experts' rows live in the slabs too, at shared_row0 + i*S + s */
     const uint16_t* norm_w;   /* optional [D]: also write norm_out = RMSNorm(out) * norm_w (next layer's input norm) */
     uint16_t* norm_out;       /* [S][D] */
     float rms_eps;

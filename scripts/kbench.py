@@ -79,6 +79,10 @@ if "experts" in which:
         t = timeit(lambda i: ops.grouped_gemm(sets[i % R][1], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=nt))
         res[f"down_nt{nt}"] = round(t, 2)
         print("down nt", nt, f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
+    t = timeit(lambda i: ops.grouped_gemm(sets[i % R][1], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=8, waves=8))
+    print("down nt 8 waves 8", f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
+    t = timeit(lambda i: ops.grouped_gemm(sets[i % R][0], x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=8, waves=8))
+    print("gateup nt 8 waves 8", f"{t:.2f} us  {gub/t/1e3:.0f} GB/s", flush=True)
 
 if "router" in which:
     gw = rnd(11, D)

@@ -474,3 +474,19 @@ def test_dcmoe_expert_parallel_two_virtual_ranks(dev):
             ref = full(xs[r], None, None)
         assert torch.equal(outs[r][3], ref[3]) and torch.equal(outs[r][2], ref[2])
         assert torch.equal(outs[r][0], ref[0]), float((outs[r][0].float() - ref[0].float()).abs().max())
+
+
+@pytest.mark.parametrize("S,K,N,ks", [(16, 2752, 2048, 2), (9, 1376, 2048, 2), (16, 2048, 512, 4), (5, 96, 64, 2)])
+def test_gemm_ksplit_partial_slabs(dev, S, K, N, ks):
+    """K split over workgroups: the fp32 partial slabs must add up to the unsplit product."""
+    from unimoe_audio_amd import ops
+    torch.manual_seed(K + N + ks)
+    x = (torch.randn(S, K) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K) * 0.05).to(torch.bfloat16)
+    tab = ops.GroupTable([dict(w=ops.pack_weight(w.to(dev)), static_count=S, n_blocks=(N + 15) // 16, k=K)], dev)
+    parts = torch.zeros(ks, S, N, dtype=torch.float32, device=dev)
+    ops.grouped_gemm(tab, x.to(dev), parts, max_rows=S, epilogue=ops.EPI_F32_RAW, n_valid=N, ksplit=ks, part_stride=parts.stride(0), nt=8 if N >= 512 else 1)
+    ref = x.float() @ w.float().t()
+    got = parts.sum(0).cpu()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4)
+    assert float(parts[0].abs().sum()) > 0 and float(parts[ks - 1].abs().sum()) > 0

@@ -47,12 +47,13 @@ class Group(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("groups", vp), ("num_groups", i32), ("max_rows", i32), ("max_n_blocks", i32), ("max_k", i32),
                 ("a", vp), ("lda", i32), ("norm_w", vp), ("rms_eps", f32), ("resid", vp), ("out", vp), ("ldo", i32),
-                ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32)]
+                ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32), ("waves", i32), ("ksplit", i32), ("part_stride", C.c_long)]
 
 
 class CombineArgs(C.Structure):
     _fields_ = [("y_slots", vp), ("slot_of", vp), ("moe_w", vp), ("y_shared", vp), ("global_w", vp), ("resid", vp),
-                ("out", vp), ("S", i32), ("D", i32), ("n_real", i32), ("n_dyn", i32), ("n_fix", i32), ("norm_w", vp),
+                ("out", vp), ("S", i32), ("D", i32), ("n_real", i32), ("n_dyn", i32), ("n_fix", i32), ("y_parts", vp), ("n_parts", i32), ("part_stride", C.c_long),
+                ("shared_row0", i32), ("norm_w", vp),
                 ("norm_out", vp), ("rms_eps", f32)]
 
 

@@ -53,7 +53,7 @@ struct umoe_engine {
     // carved buffers
     uint16_t *x = nullptr, *hin = nullptr, *x1 = nullptr, *h2 = nullptr, *qkv = nullptr, *q_r = nullptr, *attn_out = nullptr,
              *hbuf = nullptr, *ybuf = nullptr;
-    float *part_o = nullptr, *part_ml = nullptr, *logits = nullptr;
+    float *part_o = nullptr, *part_ml = nullptr, *logits = nullptr, *ypart = nullptr;
     int32_t *pos3 = nullptr, *kv_pos = nullptr, *q_pos0 = nullptr, *kv_start = nullptr, *tok_in = nullptr,
             *valid_count = nullptr, *eng_state = nullptr;
     void* r_logits = nullptr;
@@ -331,13 +331,14 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // 8. down projections
     umoe_gemm_args dn{};
     dn.groups = g + 2 + G; dn.num_groups = G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16; dn.max_k = Imax;
+    // (a 2-way K split over workgroups with fp32 partial slabs was measured: down 29 -> 28 us but combine +3 us; not used)
     dn.a = e->hbuf; dn.lda = Imax; dn.out = e->ybuf; dn.ldo = D; dn.n_valid = D;
     dn.prologue = UMOE_PRO_PLAIN; dn.epilogue = UMOE_EPI_BF16;
     if ((rc = umoe_grouped_gemm(&dn, s))) return rc;
     PROF(K_DOWN);
     // 9. combine + residual -> next layer input                   core.py:488,342-351; model.py:242
     umoe_combine_args cb{};
-    cb.y_slots = e->ybuf; cb.slot_of = e->slot_of; cb.moe_w = e->r_moe;
+    cb.y_slots = e->ybuf; cb.shared_row0 = -1; cb.slot_of = e->slot_of; cb.moe_w = e->r_moe;
     cb.y_shared = c.n_fix ? e->ybuf + (size_t)n_tok * c.n_real * D : nullptr; cb.global_w = e->r_global;
     cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
     // fused RMSNorm for the consumer of x: the next layer's input_layernorm, or the final norm in front of the head

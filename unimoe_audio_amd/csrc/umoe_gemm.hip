@@ -68,25 +68,29 @@ __device__ __forceinline__ int lds_chunk_off(int QS, int h, int i, int m) {
     return h * QS + (i >> 4) * 256 + (((i & 15) + m) & 15) * 16;
 }
 
-template <int NT, int U, int PRO, int EPI>
-__global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
+template <int NT, int U, int PRO, int EPI, int WV>
+__global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     const umoe_group_t g = p.groups[blockIdx.z];
     const int count = g.count ? *g.count : g.static_count;
     const int row0 = blockIdx.y * 16;
     if (row0 >= count) return;
-    const int nb0 = blockIdx.x * NT;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int ks = blockIdx.x % ksplit;      // K-slice of this workgroup (fp32 partial slab `ks`)
+    const int nb0 = (blockIdx.x / ksplit) * NT;
     if (nb0 >= g.n_blocks) return;
 
     const int K = g.k, KB = K >> 5;
-    const int QS = ((K >> 1) + 255) & ~255;  // bytes of one K-quarter of a row, padded to 256
+    // this workgroup covers MFMA k-steps [ia, ib) of every K-quarter; only those activation chunks are staged
+    const int ia = (KB * ks) / ksplit, ib = (KB * (ks + 1)) / ksplit;
+    const int QS = (((ib - ia) * 16) + 255) & ~255;  // bytes of one staged K-quarter slice of a row, padded to 256
     const int RS = QS * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int roff = g.row_off ? *g.row_off : 0;
 
     // ---- weight stream set-up; the first chunk is requested BEFORE the activation tile is staged -----------
-    const int i0 = (KB * wave) >> 2, i1 = (KB * (wave + 1)) >> 2;
+    const int i0 = ia + ((ib - ia) * wave) / WV, i1 = ia + ((ib - ia) * (wave + 1)) / WV;
     f32x4_t acc[NT];
     const u32x4_t* wp[NT];
 #pragma unroll
@@ -108,21 +112,23 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
 
     // ---- stage the 16-row activation tile ----------------------------------------------------------------
     {
-        const int m = tid >> 4, sub = tid & 15;
+        constexpr int TPR = WV * 4;  // threads per activation row
+        const int m = tid / TPR, sub = tid % TPR;
         const int r = row0 + m;
         const bool valid = r < count;
         long arow = 0;
         if (valid) arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
         const uint16_t* src = p.a + arow * (long)p.lda + g.a_col_off;
         char* dst = smem + m * RS;
-        const int Q8 = KB;  // 16-byte chunks per quarter
-        if (PRO == UMOE_PRO_RMSNORM && 4 * Q8 <= 256) {
+        const int Q8 = KB;       // 16-byte chunks per quarter of the full row
+        const int QW = ib - ia;  // chunks per quarter staged by this workgroup
+        if (PRO == UMOE_PRO_RMSNORM && 4 * Q8 <= 16 * TPR && QW == Q8) {
             // single pass: the row slice lives in registers between the sum of squares and the scaling
             uint4 buf[16];
             float ss = 0.f;
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
-                const int c = sub + 16 * n;
+                const int c = sub + TPR * n;
                 buf[n] = make_uint4(0, 0, 0, 0);
                 if (valid && c < 4 * Q8) {
                     buf[n] = ld16(src + c * 8);
@@ -133,11 +139,11 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
                 }
             }
 #pragma unroll
-            for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            for (int o = TPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
             const float rs = rsqrtf(ss / (float)K + p.rms_eps);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
-                const int c = sub + 16 * n;
+                const int c = sub + TPR * n;
                 if (c < 4 * Q8) {
                     uint4 u = buf[n];
                     if (valid) {
@@ -157,18 +163,18 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
             if (PRO == UMOE_PRO_RMSNORM) {
                 float ss = 0.f;
                 if (valid)
-                    for (int c = sub; c < 4 * Q8; c += 16) {
+                    for (int c = sub; c < 4 * Q8; c += TPR) {
                         float f[8];
                         unpack8(ld16(src + c * 8), f);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
                     }
 #pragma unroll
-                for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                for (int o = TPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
                 rs = rsqrtf(ss / (float)K + p.rms_eps);
             }
             for (int h = 0; h < 4; ++h)
-                for (int i = sub; i < Q8; i += 16) {
+                for (int i = ia + sub; i < ib; i += TPR) {
                     const int c = h * Q8 + i;
                     uint4 u = make_uint4(0, 0, 0, 0);
                     if (valid) {
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
                             u = pack8(f);
                         }
                     }
-                    st16(dst + lds_chunk_off(QS, h, i, m), u);
+                    st16(dst + lds_chunk_off(QS, h, i - ia, m), u);
                 }
         }
     }
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
         for (int u = 0; u < U; ++u) {
             const int ii = ibase + u;
             if (ii < i1) {
-                const uint4 bv = *reinterpret_cast<const uint4*>(bbase + lds_chunk_off(QS, h, ii, mm));
+                const uint4 bv = *reinterpret_cast<const uint4*>(bbase + lds_chunk_off(QS, h, ii - ia, mm));
                 const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, bv);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
     auto reduced = [&](int t) -> f32x4_t {
         f32x4_t s = red[t * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < WV; ++w) {
             const f32x4_t v = red[(w * NT + t) * 64 + lane];
             s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         }
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
     if (r >= count) return;
     const long orow = (long)g.out_row_base + roff + r;
     if (EPI == UMOE_EPI_SWIGLU) {
-        for (int q = wave; q < NT / 2; q += 4) {
+        for (int q = wave; q < NT / 2; q += WV) {
             if (nb0 + 2 * q >= g.n_blocks) break;
             const f32x4_t ga = reduced(2 * q), ua = reduced(2 * q + 1);
             const int col = (nb0 / 2 + q) * 16 + 4 * h;
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
         }
         return;
     }
-    for (int t = wave; t < NT; t += 4) {
+    for (int t = wave; t < NT; t += WV) {
         if (nb0 + t >= g.n_blocks) break;
         const f32x4_t a4 = reduced(t);
         const int n = (nb0 + t) * 16 + 4 * h;
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = a4[j] + ((g.bias && n + j < p.n_valid) ? g.bias[n + j] : 0.f);
         if (EPI == UMOE_EPI_F32 || EPI == UMOE_EPI_F32_RAW) {
-            float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + n;
+            float* o = reinterpret_cast<float*>(p.out) + (size_t)ks * p.part_stride + orow * p.ldo + n;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (n + j < p.n_valid) o[j] = (EPI == UMOE_EPI_F32) ? rbf(v[j]) : v[j];
@@ -283,26 +289,35 @@ __global__ __launch_bounds__(256) void wstream_gemm(const umoe_gemm_args p) {
 }
 
 // ------------------------------------------------------------------------------------ launcher
-static size_t gemm_lds_bytes(int max_k, int NT) {
-    const size_t QS = (size_t)(((max_k >> 1) + 255) & ~255);
-    const size_t a = 16 * 4 * QS, red = (size_t)4 * NT * 64 * 16;
+static size_t gemm_lds_bytes(int max_k, int NT, int WV, int ksplit) {
+    const int KB = max_k >> 5;
+    const int per = (KB + ksplit - 1) / ksplit;   // k-steps of the largest K-slice
+    const size_t QS = (size_t)((per * 16 + 255) & ~255);
+    const size_t a = 16 * 4 * QS, red = (size_t)WV * NT * 64 * 16;
     return a > red ? a : red;
 }
 
-template <int NT, int U, int PRO, int EPI>
+template <int NT, int U, int PRO, int EPI, int WV = 4>
 static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
-    const size_t lds = gemm_lds_bytes(a->max_k, NT);
+    const int ksplit = a->ksplit > 1 ? a->ksplit : 1;
+    const size_t lds = gemm_lds_bytes(a->max_k, NT, WV, ksplit);
     UMOE_REQUIRE(lds <= 160 * 1024, "umoe_grouped_gemm: K=%d needs %zu bytes of LDS (> 160 KiB)", a->max_k, lds);
     static size_t configured = 0;  // per instantiation
     if (lds > configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, U, PRO, EPI>),
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, U, PRO, EPI, WV>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
-    dim3 grid((unsigned)ceil_div(a->max_n_blocks, NT), (unsigned)ceil_div(a->max_rows, 16), (unsigned)a->num_groups);
-    wstream_gemm<NT, U, PRO, EPI><<<grid, 256, lds, s>>>(*a);
+    dim3 grid((unsigned)(ceil_div(a->max_n_blocks, NT) * ksplit), (unsigned)ceil_div(a->max_rows, 16), (unsigned)a->num_groups);
+    wstream_gemm<NT, U, PRO, EPI, WV><<<grid, WV * 64, lds, s>>>(*a);
     UMOE_LAUNCH_CHECK();
     return 0;
+}
+
+// 8 waves per workgroup when the staging tile leaves room for only one workgroup per CU (measured: +6 % on K=2752)
+static bool use8(const umoe_gemm_args* a, int nt) {
+    if (a->waves) return a->waves == 8;
+    return gemm_lds_bytes(a->max_k, nt, 4, a->ksplit > 1 ? a->ksplit : 1) > 80 * 1024;
 }
 
 // n-blocks per workgroup: more blocks amortise the activation staging, fewer blocks give more workgroups
@@ -312,7 +327,7 @@ static int launch_gemm_nt(const umoe_gemm_args* a, int nt, hipStream_t s) {
         case 1: return launch_gemm<1, 8, PRO, EPI>(a, s);
         case 2: return launch_gemm<2, 8, PRO, EPI>(a, s);
         case 4: return launch_gemm<4, 4, PRO, EPI>(a, s);
-        case 8: return launch_gemm<8, 2, PRO, EPI>(a, s);
+        case 8: return use8(a, 8) ? launch_gemm<8, 2, PRO, EPI, 8>(a, s) : launch_gemm<8, 2, PRO, EPI>(a, s);
     }
     UMOE_REQUIRE(false, "umoe_grouped_gemm: nt must be 1, 2, 4 or 8 (got %d)", nt);
 }
@@ -336,6 +351,8 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
     UMOE_REQUIRE(a->max_rows > 0 && a->max_n_blocks > 0, "umoe_grouped_gemm: empty problem");
     UMOE_REQUIRE(ceil_div(a->max_rows, 16) <= 65535, "umoe_grouped_gemm: too many rows (%d)", a->max_rows);
     UMOE_REQUIRE((a->lda & 7) == 0, "umoe_grouped_gemm: lda must be a multiple of 8 (16-byte rows)");
+    UMOE_REQUIRE(a->ksplit <= 1 || (a->epilogue == UMOE_EPI_F32_RAW && a->prologue == UMOE_PRO_PLAIN && a->ksplit <= 4),
+                 "umoe_grouped_gemm: ksplit > 1 needs the plain prologue and the raw fp32 partial-slab epilogue");
     hipStream_t s = (hipStream_t)stream;
     const int pro = a->prologue, epi = a->epilogue;
     if (pro == UMOE_PRO_RMSNORM) {
@@ -357,7 +374,8 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
             UMOE_REQUIRE(nt >= 2, "umoe_grouped_gemm: SwiGLU needs nt >= 2");
             if (nt == 2) return launch_gemm<2, 8, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
             if (nt == 4) return launch_gemm<4, 4, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
-            return launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
+            return use8(a, 8) ? launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s)
+                                 : launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
         }
         case UMOE_EPI_F32: return launch_gemm_nt<UMOE_PRO_PLAIN, UMOE_EPI_F32>(a, auto_nt(a, false), s);
         case UMOE_EPI_F32_RAW: return launch_gemm_nt<UMOE_PRO_PLAIN, UMOE_EPI_F32_RAW>(a, auto_nt(a, false), s);

@@ -80,6 +80,25 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a)
     const int s = blockIdx.x;
     const int E = a.n_dyn + a.n_fix;
     float ss = 0.f;
+    // one expert-output row chunk: bf16 slots, or the fixed-order sum of the K-split fp32 partial slabs rounded ONCE
+    // to bf16 (the rounding point of the reference's down_proj output)
+    auto load_y = [&](long row, int c, float* y) {
+        if (a.y_parts) {
+            float sacc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sacc[j] = 0.f;
+            for (int pz = 0; pz < a.n_parts; ++pz) {
+                const float4* q = reinterpret_cast<const float4*>(a.y_parts + (size_t)pz * a.part_stride + row * a.D + c * 8);
+                const float4 u0 = q[0], u1 = q[1];
+                sacc[0] += u0.x; sacc[1] += u0.y; sacc[2] += u0.z; sacc[3] += u0.w;
+                sacc[4] += u1.x; sacc[5] += u1.y; sacc[6] += u1.z; sacc[7] += u1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = rbf(sacc[j]);
+        } else {
+            unpack8(ld16(a.y_slots + (size_t)row * a.D + c * 8), y);
+        }
+    };
     for (int c = threadIdx.x; c < (a.D >> 3); c += 256) {
         float acc[8];
 #pragma unroll
@@ -89,18 +108,19 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a)
             if (slot >= 0) {
                 const float wgt = a.moe_w[(size_t)s * a.n_real + e];
                 float y[8];
-                unpack8(ld16(a.y_slots + (size_t)slot * a.D + c * 8), y);
+                load_y(slot, c, y);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += wgt * y[j];
             }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j]);
-        if (a.y_shared)
+        if (a.y_shared || (a.y_parts && a.shared_row0 >= 0))
             for (int i = 0; i < a.n_fix; ++i) {
                 const float wgt = a.global_w[(size_t)s * E + a.n_dyn + i];
                 float y[8];
-                unpack8(ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8), y);
+                if (a.y_shared) unpack8(ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8), y);
+                else load_y((long)a.shared_row0 + (long)i * a.S + s, c, y);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j] + rbf(y[j] * wgt));
             }
@@ -133,9 +153,10 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a)
 }
 
 extern "C" int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_stream_t stream) {
-    UMOE_REQUIRE(a && a->y_slots && a->slot_of && a->moe_w && a->out && a->D % 8 == 0,
+    UMOE_REQUIRE(a && (a->y_slots || (a->y_parts && a->n_parts > 0)) && a->slot_of && a->moe_w && a->out && a->D % 8 == 0,
                  "umoe_unpermute_combine_fwd: bad argument");
-    UMOE_REQUIRE(!a->y_shared || a->global_w, "umoe_unpermute_combine_fwd: shared experts need global_w");
+    UMOE_REQUIRE(!(a->y_shared || (a->y_parts && a->shared_row0 >= 0)) || a->global_w,
+                 "umoe_unpermute_combine_fwd: shared experts need global_w");
     if (a->S == 0) return 0;
     combine_kernel<<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(*a);
     UMOE_LAUNCH_CHECK();

@@ -164,11 +164,11 @@ class GroupTable:
 
 
 def grouped_gemm(table: GroupTable, a: torch.Tensor, out: torch.Tensor, *, max_rows: int, prologue=PRO_PLAIN,
-                 epilogue=EPI_BF16, norm_w=None, rms_eps=1e-6, resid=None, n_valid=None, nt=0):
+                 epilogue=EPI_BF16, norm_w=None, rms_eps=1e-6, resid=None, n_valid=None, nt=0, waves=0, ksplit=0, part_stride=0):
     args = L.GemmArgs(groups=_p(table.dev), num_groups=table.n, max_rows=max_rows, max_n_blocks=table.max_n_blocks,
                       max_k=table.max_k, a=_p(a), lda=a.stride(0), norm_w=_p(norm_w), rms_eps=rms_eps, resid=_p(resid),
-                      out=_p(out), ldo=out.stride(0), n_valid=out.shape[1] if n_valid is None else n_valid,
-                      prologue=prologue, epilogue=epilogue, nt=nt)
+                      out=_p(out), ldo=out.stride(-2), n_valid=out.shape[1] if n_valid is None else n_valid,
+                      prologue=prologue, epilogue=epilogue, nt=nt, waves=waves, ksplit=ksplit, part_stride=part_stride)
     L.check(L.lib().umoe_grouped_gemm(C.byref(args), _stream()), "umoe_grouped_gemm")
     return out
 
@@ -184,13 +184,19 @@ def linear(x: torch.Tensor, w_packed: torch.Tensor, N: int, *, bias: Optional[to
                         norm_w=norm_w, rms_eps=rms_eps, resid=resid, n_valid=N, nt=nt)
 
 
-def combine(y_slots, slot_of, moe_w, y_shared, global_w, resid, n_dyn: int, n_fix: int, norm_w=None, rms_eps=1e-6):
+def combine(y_slots, slot_of, moe_w, y_shared, global_w, resid, n_dyn: int, n_fix: int, norm_w=None, rms_eps=1e-6,
+            y_parts=None, shared_row0=-1):
+    """y_parts: optional fp32 [n_parts, rows, D] partial slabs of a K-split down GEMM (then y_slots may be None and the
+    shared experts' rows start at `shared_row0` of the same slabs)."""
     S, n_real = slot_of.shape
-    D = y_slots.shape[1]
-    out = torch.empty((S, D), dtype=torch.bfloat16, device=y_slots.device)
+    ref_t = y_slots if y_slots is not None else y_parts
+    D = ref_t.shape[-1]
+    out = torch.empty((S, D), dtype=torch.bfloat16, device=ref_t.device)
     hn = torch.empty_like(out) if norm_w is not None else None
     a = L.CombineArgs(y_slots=_p(y_slots), slot_of=_p(slot_of), moe_w=_p(moe_w), y_shared=_p(y_shared), global_w=_p(global_w),
-                      resid=_p(resid), out=_p(out), S=S, D=D, n_real=n_real, n_dyn=n_dyn, n_fix=n_fix, norm_w=_p(norm_w),
+                      resid=_p(resid), out=_p(out), S=S, D=D, n_real=n_real, n_dyn=n_dyn, n_fix=n_fix, y_parts=_p(y_parts),
+                      n_parts=0 if y_parts is None else y_parts.shape[0], part_stride=0 if y_parts is None else y_parts.stride(0),
+                      shared_row0=shared_row0, norm_w=_p(norm_w),
                       norm_out=_p(hn), rms_eps=rms_eps)
     L.check(L.lib().umoe_unpermute_combine_fwd(C.byref(a), _stream()), "umoe_unpermute_combine_fwd")
     return (out, hn) if norm_w is not None else out
