@@ -213,6 +213,13 @@ typedef struct {
     float* part_o;            /* [rows*nq][H][splits][hd] */
     float* part_ml;           /* [rows*nq][H][splits][2]  */
     uint16_t* out;
+    /* decode fusion (nq == 1): when qkv_raw is set the kernel applies mRoPE to q and to the new k itself, appends the
+     * new K/V to the cache slot q_pos0[row] (the caches are then written) and `q` is ignored */
+    const uint16_t* qkv_raw;  /* [rows][(H+2*KVH)*hd] bias-added QKV of the new token */
+    const uint16_t* cos_tab;
+    const uint16_t* sin_tab;
+    const int32_t* pos3;      /* [3][rows] */
+    int sec0, sec1, sec2;
 } umoe_attn_args;
 int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream);
 

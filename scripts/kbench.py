@@ -79,8 +79,9 @@ if "experts" in which:
         t = timeit(lambda i: ops.grouped_gemm(sets[i % R][1], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=nt))
         res[f"down_nt{nt}"] = round(t, 2)
         print("down nt", nt, f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
-    t = timeit(lambda i: ops.grouped_gemm(sets[i % R][1], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=8, waves=8))
-    print("down nt 8 waves 8", f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
+    for nt, wv in ((8, 8), (5, 4), (5, 8), (6, 4), (6, 8), (4, 8)):
+        t = timeit(lambda i: ops.grouped_gemm(sets[i % R][1], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=nt, waves=wv))
+        print("down nt", nt, "waves", wv, f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
     t = timeit(lambda i: ops.grouped_gemm(sets[i % R][0], x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=8, waves=8))
     print("gateup nt 8 waves 8", f"{t:.2f} us  {gub/t/1e3:.0f} GB/s", flush=True)
 

@@ -308,9 +308,16 @@ def test_rope_attention_prefill_and_decode(dev):
         qkv = ops.linear(xd, wqkv_p, wqkv.shape[0], bias=bqkv.to(dev))
         p3 = pos3[:, :, a:b].reshape(3, rows * nq).to(torch.int32).contiguous().to(dev)
         kvp = torch.arange(a, b, dtype=torch.int32).repeat(rows).to(dev)
-        q = ops.qkv_mrope_kvappend(qkv, cos_tab, sin_tab, p3, kvp, nq, H, KVH, hd, cfg.mrope_section, kc, vc)
         q0 = torch.full((rows,), a, dtype=torch.int32, device=dev)
+        if nq == 1:   # decode: the fused kernel (mRoPE + KV append inside attention) on copies of the caches
+            kc2, vc2 = kc.clone(), vc.clone()
+            ao_f = ops.attention(None, kc2, vc2, kv_start, q0, 1, H, splits=splits, qkv_raw=qkv, cos_tab=cos_tab, sin_tab=sin_tab,
+                                 pos3=p3, sections=cfg.mrope_section)
+        q = ops.qkv_mrope_kvappend(qkv, cos_tab, sin_tab, p3, kvp, nq, H, KVH, hd, cfg.mrope_section, kc, vc)
         ao = ops.attention(q, kc, vc, kv_start, q0, nq, H, splits=splits)
+        if nq == 1:
+            assert torch.equal(kc2, kc) and torch.equal(vc2, vc)          # same rotated K / V landed in the cache
+            assert torch.allclose(ao_f.float(), ao.float(), rtol=2 ** -7, atol=2 ** -9)
         out = ops.linear(ao, wo_p, H * hd).reshape(rows, nq, -1).cpu()
         qv = valid[:, a:b]
         # q/k/v proj -> rope -> attention -> o_proj chains ~4 bf16 roundings through a 2048-term sum.  The torch-CPU

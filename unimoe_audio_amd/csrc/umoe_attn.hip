@@ -69,7 +69,32 @@ extern "C" int umoe_qkv_mrope_kvappend(const umoe_rope_args* a, umoe_stream_t st
 }
 
 // ------------------------------------------------------------------------------------ attention
+// mRoPE of 32 consecutive dims [32*h4, 32*h4+32) of one head, straight from the raw (bias-added) QKV row:
+// out = x*cos + rotate_half(x)*sin with every product and the sum rounded to bf16 (as torch does on bf16 tensors).
+// `own` = the 32 dims, `par` = their rotate_half partners (dims +-64); chunks of 8 dims never straddle an mRoPE section
+// (host checks sec0 % 8 == 0 and (sec0+sec1) % 8 == 0).
+__device__ __forceinline__ void rope32(const uint16_t* head_raw, int h4, const umoe_attn_args& a, int p0, int p1, int p2,
+                                       uint4 (&out)[4]) {
+    const bool first = h4 < 2;
+    const uint16_t* own = head_raw + h4 * 32;
+    const uint16_t* par = head_raw + (first ? h4 * 32 + 64 : h4 * 32 - 64);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int i0 = (h4 & 1) * 32 + kb * 8;  // index into the half-dim cos/sin row
+        const int pos = (i0 < a.sec0) ? p0 : (i0 < a.sec0 + a.sec1 ? p1 : p2);
+        float x[8], y[8], c[8], sn[8], o[8];
+        unpack8(ld16(own + kb * 8), x);
+        unpack8(ld16(par + kb * 8), y);
+        unpack8(ld16(a.cos_tab + (size_t)pos * 64 + i0), c);
+        unpack8(ld16(a.sin_tab + (size_t)pos * 64 + i0), sn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rbf(x[j] * c[j]) + rbf((first ? -y[j] : y[j]) * sn[j]);
+        out[kb] = pack8(o);
+    }
+}
+
 // hd == 128 only (4 MFMA k-steps; lane owns 2 value columns).  GP = GQA group size padded to a power of two.
+// With a.qkv_raw set (decode, nq == 1) the kernel also applies mRoPE and appends the new K/V to the cache.
 template <int GP>
 __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
     constexpr int HD = 128;
@@ -83,8 +108,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h4 = lane >> 4, c = lane & 15;
 
+    const bool fuse = a.qkv_raw != nullptr;      // decode: rope + append fused, the new key is NOT read from the cache
     const int kbeg_all = a.kv_start[row];
-    const int kend_all = a.q_pos0[row] + t + 1;  // exclusive
+    const int kend_all = a.q_pos0[row] + t + (fuse ? 0 : 1);  // exclusive
     const int nkeys = max(kend_all - kbeg_all, 0);
     int chunk = (nkeys + a.splits - 1) / a.splits;
     chunk = (chunk + 15) & ~15;
@@ -96,7 +122,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
 
     // Q fragments (B operand): lane (h4, c = head in group) holds q[c][h4*32 + kb*8 .. +8]
     bf16x8_t qf[4];
-    {
+    const int QKV_LD = (a.H + 2 * a.KVH) * HD;
+    int p0 = 0, p1 = 0, p2 = 0;
+    if (fuse) {
+        const int ntok = a.rows * a.nq;
+        p0 = a.pos3[qi]; p1 = a.pos3[ntok + qi]; p2 = a.pos3[2 * ntok + qi];
+        uint4 u[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) u[kb] = make_uint4(0, 0, 0, 0);
+        if (c < G) rope32(a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(kvh * G + c) * HD, h4, a, p0, p1, p2, u);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) qf[kb] = __builtin_bit_cast(bf16x8_t, u[kb]);
+    } else {
         const uint16_t* qp = a.q + ((size_t)qi * a.H + kvh * G + c) * HD + h4 * 32;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -111,20 +148,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
 #pragma unroll
     for (int g = 0; g < GP; ++g) o[g][0] = o[g][1] = 0.f;
 
-    for (int k0 = kbeg + wave * 16; k0 < kend; k0 += 64) {
-        // issue EVERY load of this tile up front: the 4 K fragments and the 16 V rows (2 columns per lane), so the
-        // tile pays one memory latency instead of one per key
-        uint4 kfr[4];
-        {
-            const int key = min(k0 + c, kend - 1);  // A operand row = lane&15 -> key index
-            const uint16_t* kp = Kc + (size_t)key * HD + h4 * 32;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) kfr[kb] = ld16(kp + kb * 8);
-        }
-        uint32_t vraw[16];
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
-            vraw[kk] = *reinterpret_cast<const uint32_t*>(Vc + (size_t)min(k0 + kk, kend - 1) * HD + 2 * lane);
+    auto process_tile = [&](const uint4 (&kfr)[4], const uint32_t (&vraw)[16], const int k0, const int kend) {
         // S tile: D[key = 4*h4 + r][head = c]
         f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -187,6 +211,44 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
             if ((kk & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the unrolled body from hoisting all LDS reads
         }
         __builtin_amdgcn_wave_barrier();
+    };
+    for (int k0 = kbeg + wave * 16; k0 < kend; k0 += 64) {
+        // issue EVERY load of this tile up front: the 4 K fragments and the 16 V rows (2 columns per lane), so the
+        // tile pays one memory latency instead of one per key
+        uint4 kfr[4];
+        {
+            const int key = min(k0 + c, kend - 1);  // A operand row = lane&15 -> key index
+            const uint16_t* kp = Kc + (size_t)key * HD + h4 * 32;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) kfr[kb] = ld16(kp + kb * 8);
+        }
+        uint32_t vraw[16];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            vraw[kk] = *reinterpret_cast<const uint32_t*>(Vc + (size_t)min(k0 + kk, kend - 1) * HD + 2 * lane);
+        process_tile(kfr, vraw, k0, kend);
+    }
+    if (fuse && split == a.splits - 1 && wave == 0) {
+        // the new token: K roped from the raw QKV row (lanes c == 0 hold its 4 x 32 dims), V raw; one extra 1-key tile,
+        // and this wave is the single writer of cache slot q_pos0 for (row, kvh)
+        const int slot = a.q_pos0[row];
+        const uint16_t* kraw = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + kvh) * HD;
+        const uint16_t* vrow = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + a.KVH + kvh) * HD;
+        uint4 kfr[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) kfr[kb] = make_uint4(0, 0, 0, 0);
+        if (c == 0) {
+            rope32(kraw, h4, a, p0, p1, p2, kfr);
+            uint16_t* kd = const_cast<uint16_t*>(a.k_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + h4 * 32;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) st16(kd + kb * 8, kfr[kb]);
+        }
+        uint32_t vraw[16];
+        const uint32_t vnew = *reinterpret_cast<const uint32_t*>(vrow + 2 * lane);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) vraw[kk] = vnew;
+        *reinterpret_cast<uint32_t*>(const_cast<uint16_t*>(a.v_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + 2 * lane) = vnew;
+        process_tile(kfr, vraw, slot, slot + 1);   // keys slot+1.. are masked (p = 0)
     }
 
     // ---- merge the 4 waves --------------------------------------------------------------------
@@ -256,8 +318,13 @@ static void launch_attn(const umoe_attn_args* a, dim3 grid, hipStream_t s) {
 }
 
 extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
-    UMOE_REQUIRE(a && a->q && a->k_cache && a->v_cache && a->kv_start && a->q_pos0 && a->part_o && a->part_ml && a->out,
+    UMOE_REQUIRE(a && (a->q || a->qkv_raw) && a->k_cache && a->v_cache && a->kv_start && a->q_pos0 && a->part_o && a->part_ml && a->out,
                  "umoe_attn_decode: null argument");
+    if (a->qkv_raw) {
+        UMOE_REQUIRE(a->nq == 1 && a->cos_tab && a->sin_tab && a->pos3, "umoe_attn_decode: fused rope needs nq == 1 and rope tables");
+        UMOE_REQUIRE(a->sec0 % 8 == 0 && (a->sec0 + a->sec1) % 8 == 0 && a->sec0 + a->sec1 + a->sec2 == 64,
+                     "umoe_attn_decode: fused rope needs mRoPE sections on multiples of 8 (got %d,%d,%d)", a->sec0, a->sec1, a->sec2);
+    }
     UMOE_REQUIRE(a->hd == 128, "umoe_attn_decode: head_dim must be 128 (got %d)", a->hd);
     UMOE_REQUIRE(a->KVH > 0 && a->H % a->KVH == 0 && a->H / a->KVH <= 16,
                  "umoe_attn_decode: GQA group must be <= 16 (H=%d KVH=%d)", a->H, a->KVH);

@@ -292,13 +292,20 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     r.n_tok = n_tok; r.T = T; r.H = c.heads; r.KVH = c.kv_heads; r.hd = c.head_dim;
     r.sec0 = c.mrope0; r.sec1 = c.mrope1; r.sec2 = c.mrope2; r.Lmax = c.Lmax;
     r.q_out = e->q_r; r.k_cache = e->k_cache + kv_l; r.v_cache = e->v_cache + kv_l;
-    if ((rc = umoe_qkv_mrope_kvappend(&r, s))) return rc;
-    PROF(K_ROPE);
-    // 3. attention
+    const bool fuse_rope = (T == 1) && (c.mrope0 % 8 == 0) && ((c.mrope0 + c.mrope1) % 8 == 0);
+    if (!fuse_rope) {   // prefill: rope + append for all T positions first
+        if ((rc = umoe_qkv_mrope_kvappend(&r, s))) return rc;
+        PROF(K_ROPE);
+    }
+    // 3. attention (decode: mRoPE of q / new k and the KV append are fused into the kernel)
     umoe_attn_args t{};
     t.q = e->q_r; t.k_cache = r.k_cache; t.v_cache = r.v_cache; t.kv_start = e->kv_start; t.q_pos0 = e->q_pos0;
     t.rows = c.rows; t.nq = T; t.H = c.heads; t.KVH = c.kv_heads; t.hd = c.head_dim; t.Lmax = c.Lmax; t.splits = splits;
     t.scale = 1.0f / sqrtf((float)c.head_dim); t.part_o = e->part_o; t.part_ml = e->part_ml; t.out = e->attn_out;
+    if (fuse_rope) {
+        t.qkv_raw = e->qkv; t.cos_tab = e->cos_tab; t.sin_tab = e->sin_tab; t.pos3 = e->pos3;
+        t.sec0 = c.mrope0; t.sec1 = c.mrope1; t.sec2 = c.mrope2;
+    }
     if ((rc = umoe_attn_decode(&t, s))) return rc;
     PROF(K_ATTN);
     // 4. o_proj + residual                                        model.py:238

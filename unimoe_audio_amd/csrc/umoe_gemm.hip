@@ -327,9 +327,11 @@ static int launch_gemm_nt(const umoe_gemm_args* a, int nt, hipStream_t s) {
         case 1: return launch_gemm<1, 8, PRO, EPI>(a, s);
         case 2: return launch_gemm<2, 8, PRO, EPI>(a, s);
         case 4: return launch_gemm<4, 4, PRO, EPI>(a, s);
+        case 5: return use8(a, 5) ? launch_gemm<5, 3, PRO, EPI, 8>(a, s) : launch_gemm<5, 3, PRO, EPI>(a, s);
+        case 6: return use8(a, 6) ? launch_gemm<6, 2, PRO, EPI, 8>(a, s) : launch_gemm<6, 2, PRO, EPI>(a, s);
         case 8: return use8(a, 8) ? launch_gemm<8, 2, PRO, EPI, 8>(a, s) : launch_gemm<8, 2, PRO, EPI>(a, s);
     }
-    UMOE_REQUIRE(false, "umoe_grouped_gemm: nt must be 1, 2, 4 or 8 (got %d)", nt);
+    UMOE_REQUIRE(false, "umoe_grouped_gemm: nt must be 1, 2, 4, 5, 6 or 8 (got %d)", nt);
 }
 
 static int auto_nt(const umoe_gemm_args* a, bool swiglu) {

@@ -117,6 +117,66 @@ __device__ __forceinline__ int route_token(const umoe_router_args& a, const int 
         if (lane < E)
             full = T ? bf2f(reinterpret_cast<const uint16_t*>(a.logits_in)[(size_t)s * E + lane])
                      : reinterpret_cast<const float*>(a.logits_in)[(size_t)s * E + lane];
+    } else if (ND > 0 && a.D <= 2048 && (a.D & 511) == 0) {
+        // decode fast path: EVERY load of this token (row, norm weights, all E gate rows) is in flight before the
+        // first use -- one memory latency instead of one per chunk (the gate weights are cold in HBM every layer)
+        constexpr int NEc = ND > 0 ? ND + NF : 1;  // (the generic instantiation never takes this branch)
+        const uint16_t* xr = a.x + (size_t)s * a.D;
+        const int nch = a.D >> 9;  // 16-byte chunks per lane
+        uint4 xv[4], nw[4], gwv[NEc][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (n < nch) {
+                xv[n] = ld16(xr + (lane + 64 * n) * 8);
+                if (a.norm_w) nw[n] = ld16(a.norm_w + (lane + 64 * n) * 8);
+            }
+#pragma unroll
+        for (int e = 0; e < NEc; ++e)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < nch) gwv[e][n] = ld16(a.gate_w + (size_t)e * a.D + (lane + 64 * n) * 8);
+        float rs = 1.f;
+        if (a.norm_w) {
+            float ss = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                if (n < nch) {
+                    float f[8];
+                    unpack8(xv[n], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+                }
+            ss = wave_sum(ss);
+            rs = rsqrtf(ss / (float)a.D + a.rms_eps);
+        }
+        float acc[UMOE_MAXE];
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            if (n < nch) {
+                float f[8];
+                unpack8(xv[n], f);
+                if (a.norm_w) {
+                    float w[8];
+                    unpack8(nw[n], w);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = rbf(w[j] * rbf(f[j] * rs));
+                    xv[n] = pack8(f);
+                }
+                if (a.h_out) st16(a.h_out + (size_t)s * a.D + (lane + 64 * n) * 8, xv[n]);
+#pragma unroll
+                for (int e = 0; e < NEc; ++e) {
+                    float w[8];
+                    unpack8(gwv[e][n], w);
+                    float d = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d += f[j] * w[j];
+                    acc[e] += d;
+                }
+            }
+        const float mine = reduce16_to_lanes(acc, lane);
+        if (lane < E) full = round_t(mine, T);
     } else {
         const uint16_t* xr = a.x + (size_t)s * a.D;
         const int nchunk = a.D >> 3;
