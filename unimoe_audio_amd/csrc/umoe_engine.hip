@@ -67,6 +67,10 @@ struct umoe_engine {
     int T_prompt = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // second stream: the shared experts run beside the (latency-bound) router; fork/join by events, graph-capturable
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap_shared = false;  // measured on MI355X: 1429 vs 1825 tok/s -- cross-stream graph edges cost more than they hide
     // optional per-kernel-class timing of one eager step (hipEvents on the launch stream)
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -205,6 +209,14 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
         umoe_engine_destroy(e);
         return -2;
     }
+    if (hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
+        umoe_set_error("umoe_engine_create: stream/event creation failed");
+        umoe_engine_destroy(e);
+        return -2;
+    }
+    if (const char* v = getenv("UMOE_OVERLAP_SHARED")) e->overlap_shared = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -214,6 +226,9 @@ extern "C" void umoe_engine_destroy(umoe_engine* e) {
     if (e->exec) hipGraphExecDestroy(e->exec);
     if (e->graph) hipGraphDestroy(e->graph);
     for (hipEvent_t x : e->ev) hipEventDestroy(x);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
+    if (e->s2) hipStreamDestroy(e->s2);
     if (e->ws) hipFree(e->ws);
     if (e->k_cache) hipFree(e->k_cache);
     if (e->v_cache) hipFree(e->v_cache);
@@ -315,6 +330,21 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     o.prologue = UMOE_PRO_PLAIN; o.epilogue = UMOE_EPI_BF16_RESID;
     if ((rc = umoe_grouped_gemm(&o, s))) return rc;
     PROF(K_OPROJ);
+    if (e->overlap_shared && c.n_fix > 0) {   // fork: shared experts on s2 (x1 -> RMSNorm -> SwiGLU -> down)
+        UMOE_HIP(hipEventRecord(e->ev_fork, s));
+        UMOE_HIP(hipStreamWaitEvent(e->s2, e->ev_fork, 0));
+        umoe_gemm_args sg{};
+        sg.groups = g + 2 + c.n_real; sg.num_groups = c.n_fix; sg.max_rows = n_tok; sg.max_n_blocks = 2 * c.inter_shared / 16;
+        sg.max_k = D; sg.a = e->x1; sg.lda = D; sg.norm_w = L.w.post_norm; sg.rms_eps = c.rms_eps;
+        sg.out = e->hbuf; sg.ldo = Imax; sg.n_valid = Imax; sg.prologue = UMOE_PRO_RMSNORM; sg.epilogue = UMOE_EPI_SWIGLU;
+        if ((rc = umoe_grouped_gemm(&sg, e->s2))) return rc;
+        umoe_gemm_args sd{};
+        sd.groups = g + 2 + G + c.n_real; sd.num_groups = c.n_fix; sd.max_rows = n_tok; sd.max_n_blocks = D / 16;
+        sd.max_k = c.inter_shared; sd.a = e->hbuf; sd.lda = Imax; sd.out = e->ybuf; sd.ldo = D; sd.n_valid = D;
+        sd.prologue = UMOE_PRO_PLAIN; sd.epilogue = UMOE_EPI_BF16;
+        if ((rc = umoe_grouped_gemm(&sd, e->s2))) return rc;
+        UMOE_HIP(hipEventRecord(e->ev_join, e->s2));
+    }
     // 5. RMSNorm + router                                         model.py:240, core.py:246-291
     umoe_router_args ra{};
     ra.x = e->x1; ra.gate_w = L.w.gate_w; ra.norm_w = L.w.post_norm; ra.h_out = e->h2; ra.S = n_tok; ra.D = D;
@@ -328,21 +358,25 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     }
     if ((rc = umoe_router_dispatch_fwd(&ra, e->counts, e->offsets, e->slot_token, e->slot_of, s))) return rc;
     PROF(K_ROUTER);
-    // 7. gate/up SwiGLU: routed (gathered rows) + shared (all rows) in one launch
+    // 7./8. experts.  The shared experts need no routing: with `overlap_shared` they run on a second stream from the
+    // residual stream x1 (their own RMSNorm prologue) BESIDE the latency-bound router + dispatch (forked after o_proj,
+    // see below) and are joined before the combine; otherwise routed + shared share one launch each.
+    const bool ov = e->overlap_shared && c.n_fix > 0;
     umoe_gemm_args gu{};
-    gu.groups = g + 2; gu.num_groups = G; gu.max_rows = n_tok; gu.max_n_blocks = 2 * Imax / 16; gu.max_k = D;
+    gu.groups = g + 2; gu.num_groups = ov ? c.n_real : G; gu.max_rows = n_tok;
+    gu.max_n_blocks = 2 * (ov ? c.inter_dyn : Imax) / 16; gu.max_k = D;
     gu.a = e->h2; gu.lda = D; gu.out = e->hbuf; gu.ldo = Imax; gu.n_valid = Imax;
     gu.prologue = UMOE_PRO_PLAIN; gu.epilogue = UMOE_EPI_SWIGLU;
     if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
     PROF(K_GATEUP);
-    // 8. down projections
     umoe_gemm_args dn{};
-    dn.groups = g + 2 + G; dn.num_groups = G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16; dn.max_k = Imax;
-    // (a 2-way K split over workgroups with fp32 partial slabs was measured: down 29 -> 28 us but combine +3 us; not used)
+    dn.groups = g + 2 + G; dn.num_groups = ov ? c.n_real : G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16;
+    dn.max_k = ov ? c.inter_dyn : Imax;
     dn.a = e->hbuf; dn.lda = Imax; dn.out = e->ybuf; dn.ldo = D; dn.n_valid = D;
     dn.prologue = UMOE_PRO_PLAIN; dn.epilogue = UMOE_EPI_BF16;
     if ((rc = umoe_grouped_gemm(&dn, s))) return rc;
     PROF(K_DOWN);
+    if (ov) UMOE_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
     // 9. combine + residual -> next layer input                   core.py:488,342-351; model.py:242
     umoe_combine_args cb{};
     cb.y_slots = e->ybuf; cb.shared_row0 = -1; cb.slot_of = e->slot_of; cb.moe_w = e->r_moe;

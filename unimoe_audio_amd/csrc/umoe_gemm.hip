@@ -362,6 +362,13 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
         const int nt = auto_nt(a, false);
         if (epi == UMOE_EPI_BF16) return launch_gemm_nt<UMOE_PRO_RMSNORM, UMOE_EPI_BF16>(a, nt, s);
         if (epi == UMOE_EPI_F32) return launch_gemm_nt<UMOE_PRO_RMSNORM, UMOE_EPI_F32>(a, nt, s);
+        if (epi == UMOE_EPI_SWIGLU) {  // shared experts straight from the residual stream (norm fused in the staging)
+            UMOE_REQUIRE(a->max_n_blocks % 2 == 0, "umoe_grouped_gemm: SwiGLU needs gate/up block pairs");
+            const int ns = auto_nt(a, true);
+            if (ns <= 2) return launch_gemm<2, 8, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU>(a, s);
+            if (ns == 4) return launch_gemm<4, 4, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU>(a, s);
+            return launch_gemm<8, 2, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU>(a, s);
+        }
         UMOE_REQUIRE(false, "umoe_grouped_gemm: unsupported prologue/epilogue %d/%d", pro, epi);
     }
     UMOE_REQUIRE(pro == UMOE_PRO_PLAIN, "umoe_grouped_gemm: bad prologue %d", pro);
