@@ -149,6 +149,9 @@ int umoe_grouped_swiglu_fwd(const umoe_group_t* gateup_groups, const umoe_group_
                             int max_rows, const uint16_t* x, int D, int I, uint16_t* h_ws, uint16_t* y_slots,
                             umoe_stream_t stream);
 
+int umoe_shared_swiglu_fwd(const umoe_group_t* gateup_groups, const umoe_group_t* down_groups, int n_fix, int S,
+                           const uint16_t* x, int D, int I, uint16_t* h_ws, uint16_t* y_shared, umoe_stream_t stream);
+
 /* combine: out[s] = resid[s] + ( sum_e moe_w[s][e] * y[slot_of[s][e]]  (+ shared_i[s] * global_w[s][n_dyn+i]) )
  * with the reference's rounding points (einsum core.py:488, adds :342,:351, residual model.py:242). */
 typedef struct {
@@ -222,6 +225,8 @@ typedef struct {
     int sec0, sec1, sec2;
 } umoe_attn_args;
 int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream);
+/* causal prefill (nq = T queries per row) over keys already appended by umoe_qkv_mrope_kvappend */
+int umoe_attn_prefill_fwd(const umoe_attn_args* a, umoe_stream_t stream);
 
 /* ------------------------------------------------------------------ codec side
  * codec_embedding (model.py:655-661): out[r] = sum_c Emb_c[tok[r][c]], bf16 adds in channel order.

@@ -97,7 +97,7 @@ class DecodeIO(C.Structure):
 
 EXPORTS = [
     "umoe_last_error", "umoe_abi_version", "umoe_packed_elems", "umoe_pack_weight", "umoe_pack_gate_up",
-    "umoe_router_fwd", "umoe_router_dispatch_fwd", "umoe_dispatch_build", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd",
+    "umoe_router_fwd", "umoe_router_dispatch_fwd", "umoe_dispatch_build", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd", "umoe_shared_swiglu_fwd", "umoe_attn_prefill_fwd",
     "umoe_unpermute_combine_fwd", "umoe_rmsnorm_residual_fwd", "umoe_qkv_mrope_kvappend", "umoe_attn_decode",
     "umoe_codec_embed_sum", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",

@@ -1,0 +1,174 @@
+"""High-level API surface of the reference, on the HIP engine.
+
+Keeps both spellings the reference ships: the HF-directory flavour (`UniMoE_Audio.py:39-261`:
+`text_to_speech(transcription, prompt_transcription, prompt_wav, output_dir, max_audio_seconds, ...)`) and the in-repo twin
+(`utils/UniMoE_Audio_mod.py:294-619`: `caption`, `prompt_text`, `save_name`, `cfg_scale`, ...).  Prompt templates, negative /
+positive prompt pairing and `max_tokens = 50 * seconds` follow the reference (mod.py:56-59,343-348,449-466;
+UniMoE_Audio.py:137-138).
+
+Tokenizer (HF files under `model_path`) and the DAC codec (`descript-audio-codec`, weights_16khz.pth) are third-party
+assets that are not available offline; they are loaded lazily and a clear error is raised when they are missing.  The
+token-generation path itself (`generate_codes`) needs neither and is what tests/bench exercise.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Union
+
+import torch
+
+from .codec_utils import DecoderOutput, generate_output, prepare_audio_prompt, preprocess_codec
+from .config import UniMoEAudioConfig
+from .model import UniAudioRVQQwen2_5VLMoEForConditionalGeneration
+
+SYSTEM_MESSAGE = "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n"
+INPUT_FORMAT = "<|im_start|>user\n{}<|im_end|>\n<|im_start|>assistant\n"
+AUDIO_START = "<|AUDIO_START|>"
+
+
+class UniMoEAudio:
+    def __init__(self, model_path: Optional[str], device_id: int = 0, config: Optional[UniMoEAudioConfig] = None,
+                 model: Optional[UniAudioRVQQwen2_5VLMoEForConditionalGeneration] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("UniMoEAudio needs a ROCm device: the accelerated path has no CPU fallback")
+        torch.cuda.set_device(device_id)
+        self.device = torch.device(f"cuda:{device_id}")
+        self.TORCH_DTYPE = torch.bfloat16
+        self.model_path = model_path
+        if model is not None:
+            self.model = model
+        else:
+            cfg = config
+            if cfg is None:
+                if not model_path or not os.path.exists(os.path.join(model_path, "config.json")):
+                    raise FileNotFoundError("model_path must contain the reference config.json (and the safetensors shards)")
+                cfg = UniMoEAudioConfig.from_json(os.path.join(model_path, "config.json"))
+            self.model = UniAudioRVQQwen2_5VLMoEForConditionalGeneration(cfg)
+            self._load_weights(model_path)
+            self.model = self.model.to(self.device, torch.bfloat16).eval()
+        self._tokenizer = None
+        self._dac = None
+
+    # ---- third-party assets ---------------------------------------------------------------------------------------
+    def _load_weights(self, model_path):
+        import glob
+        from safetensors import safe_open
+        shards = sorted(glob.glob(os.path.join(model_path or "", "*.safetensors")))
+        if not shards:
+            raise FileNotFoundError(f"no *.safetensors under {model_path!r} (the reference downloads them from the HF hub)")
+        sd = {}
+        for sh in shards:
+            with safe_open(sh, framework="pt") as f:
+                for k in f.keys():
+                    kk = k
+                    if kk.startswith("model.") and not kk.startswith("model.language_model"):   # model.py:464-467
+                        kk = "language_model." + kk[len("model."):]
+                    sd[kk] = f.get_tensor(k)
+        missing, unexpected = self.model.load_state_dict(sd, strict=False)
+        hot = [m for m in missing if "visual" not in m and "lm_head" not in m]
+        if hot:
+            raise KeyError(f"checkpoint lacks hot-path tensors, e.g. {hot[:4]}")
+
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            from transformers import AutoTokenizer
+            self._tokenizer = AutoTokenizer.from_pretrained(self.model_path, padding_side="left", use_fast=False)
+        return self._tokenizer
+
+    @property
+    def dac(self):
+        if self._dac is None:
+            try:
+                import dac  # noqa: F401  (descript-audio-codec==1.0.0, reference configs/enviroment.yml:56)
+            except Exception as e:
+                raise ImportError("descript-audio-codec is not installed: waveform <-> code conversion (Dac.encode/decode, "
+                                  "reference utils/UniMoE_Audio_utils.py:56-134) is unavailable; generate_codes() still works") from e
+            raise NotImplementedError("DAC conv encoder/decoder are outside the accelerated path this round (SURVEY.md 8f-2)")
+        return self._dac
+
+    # ---- the accelerated part: tokens in, codes out -----------------------------------------------------------------
+    @torch.no_grad()
+    def generate_codes(self, input_ids: torch.Tensor, attention_mask: torch.Tensor, codec_input_ids: Optional[torch.Tensor] = None,
+                       max_audio_seconds: int = 10, min_audio_seconds: int = 2, cfg_scale: float = 3.0, temperature: float = 1.2,
+                       top_p: float = 0.95, cfg_filter_top_k: int = 45, eos_prob_mul_factor: float = 0.8, do_sample: bool = True,
+                       seed: int = 0):
+        """input_ids [2B, T] (negative prompt, positive prompt per sample), returns the list of [len_i, 12] code tensors
+        exactly as the reference's `generate_output` does (delay pattern reverted)."""
+        cfg = self.model.config
+        B = input_ids.shape[0] // 2
+        prefill, steps = prepare_audio_prompt(cfg, [None] * B)
+        dec = DecoderOutput(prefill, steps, self.device)
+        codes, lengths = self.model.generate(input_ids, attention_mask, dec, max_tokens=max_audio_seconds * 50,
+                                             min_tokens=min_audio_seconds * 50, codec_input_ids=codec_input_ids,
+                                             cfg_scale=cfg_scale, temperature=temperature, top_p=top_p,
+                                             cfg_filter_top_k=cfg_filter_top_k, eos_prob_mul_factor=eos_prob_mul_factor,
+                                             do_sample=do_sample, seed=seed)
+        if codes is None:
+            return []
+        return generate_output(cfg, codes, lengths)
+
+    # ---- reference task methods (both spellings) -----------------------------------------------------------------------
+    def _texts(self, obj: Union[str, List[str]]) -> List[str]:
+        if isinstance(obj, str):
+            obj = [obj]
+        obj = [c for c in obj if c.strip()]
+        if not obj:
+            raise ValueError("Please enter valid target texts.")        # UniMoE_Audio.py:94-103
+        return obj
+
+    def _finish(self, audios, output_dir, stem):
+        os.makedirs(output_dir, exist_ok=True)
+        paths = []
+        for i, a in enumerate(audios):
+            path = os.path.join(output_dir, f"generated_{stem}_{i}.wav")
+            self.dac.decode(a.transpose(0, 1).unsqueeze(0), save_path=path, min_duration=1)
+            paths.append(path)
+        return paths
+
+    def text_to_music(self, caption: Union[str, List[str]], output_dir: str = "./", max_audio_seconds: int = 20,
+                      min_audio_seconds: int = 8, temperature: float = 1.0, top_p: float = 1.0, cfg_filter_top_k: int = 45,
+                      save_name: str = "music", cfg_scale: float = 10.0, eos_prob_mul_factor: float = 0.6, do_sample: bool = True,
+                      **_) -> List[str]:
+        caption = self._texts(caption)
+        neg = SYSTEM_MESSAGE + INPUT_FORMAT.format("<|MUSIC_START|>Low quality.<|MUSIC_END|>") + AUDIO_START
+        texts = []
+        for c in caption:
+            texts += [neg, SYSTEM_MESSAGE + INPUT_FORMAT.format("<|MUSIC_START|>" + c + "<|MUSIC_END|>") + AUDIO_START]
+        enc = self.tokenizer(texts, add_special_tokens=False, return_tensors="pt", padding=True)
+        audios = self.generate_codes(enc.input_ids, enc.attention_mask, None, max_audio_seconds, min_audio_seconds, cfg_scale,
+                                     temperature, top_p, cfg_filter_top_k, eos_prob_mul_factor, do_sample)
+        return self._finish(audios, output_dir, save_name)
+
+    def text_to_speech(self, transcription: Union[str, List[str], None] = None, prompt_transcription: Optional[str] = None,
+                       prompt_wav: Optional[str] = None, output_dir: str = "./", max_audio_seconds: int = 10,
+                       min_audio_seconds: int = 2, temperature: float = 1.0, top_p: float = 1.0, cfg_filter_top_k: int = 45,
+                       caption=None, prompt_text=None, prompt_codec=None, save_name: str = "speech", cfg_scale: float = 1.0,
+                       eos_prob_mul_factor: float = 1.0, do_sample: bool = True, **_) -> List[str]:
+        texts_in = self._texts(transcription if transcription is not None else caption)
+        ptxt = prompt_transcription if prompt_transcription is not None else prompt_text
+        if prompt_codec is None:
+            if prompt_wav is None:
+                raise ValueError("Please provide a reference audio file.")
+            prompt_codec = self.dac.encode(prompt_wav)
+        cfg = self.model.config
+        pc = preprocess_codec(cfg, prompt_codec)
+        prompt_caption = ("<|SPEECH_PROMPT_START|>" + ptxt + "<|SPEECH_PROMPT_END|>" + "<|VOICE_PROMPT_START|>" +
+                          "<|AUDIO_PLACEHOLDER|>" * pc.shape[0] + "<|VOICE_PROMPT_END|>")
+        wrap = lambda x: prompt_caption + "<|SPEECH_START|>" + x + "<|SPEECH_END|>"   # noqa: E731
+        texts = []
+        for t in texts_in:
+            texts += [SYSTEM_MESSAGE + INPUT_FORMAT.format(wrap("")) + AUDIO_START,
+                      SYSTEM_MESSAGE + INPUT_FORMAT.format(wrap(t)) + AUDIO_START]
+        enc = self.tokenizer(texts, add_special_tokens=False, return_tensors="pt", padding=True)
+        codec = pc.unsqueeze(0).expand(len(texts), -1, -1).reshape(-1, pc.shape[1])
+        audios = self.generate_codes(enc.input_ids, enc.attention_mask, codec, max_audio_seconds, min_audio_seconds, cfg_scale,
+                                     temperature, top_p, cfg_filter_top_k, eos_prob_mul_factor, do_sample)
+        return self._finish(audios, output_dir, save_name)
+
+    def video_text_to_music(self, video, caption, output_dir: str = "./", **kw) -> List[str]:
+        raise NotImplementedError("video inputs need the vision tower, which is outside the accelerated path (SURVEY.md 8f-1)")
+
+
+def create_unimoe_audio(model_path: str, device_id: int = 0) -> UniMoEAudio:
+    return UniMoEAudio(model_path, device_id)

@@ -361,3 +361,9 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     }
     return 0;
 }
+
+// causal prefill over the cache (nq = T query tokens per row): same kernel family, key slices of one split by default
+extern "C" int umoe_attn_prefill_fwd(const umoe_attn_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && !a->qkv_raw, "umoe_attn_prefill_fwd: rope fusion is decode-only; run umoe_qkv_mrope_kvappend first");
+    return umoe_attn_decode(a, stream);
+}

@@ -407,3 +407,11 @@ extern "C" int umoe_grouped_swiglu_fwd(const umoe_group_t* gateup_groups, const 
     b.prologue = UMOE_PRO_PLAIN; b.epilogue = UMOE_EPI_BF16;
     return umoe_grouped_gemm(&b, stream);
 }
+
+// shared experts (reference core.py:344-351 + :16-31): dense SwiGLU over all S rows for n_fix experts; the scaling by
+// global_weight[:, n_dyn + i] and the accumulation happen in umoe_unpermute_combine_fwd with the reference's roundings.
+extern "C" int umoe_shared_swiglu_fwd(const umoe_group_t* gateup_groups, const umoe_group_t* down_groups, int n_fix, int S,
+                                      const uint16_t* x, int D, int I, uint16_t* h_ws, uint16_t* y_shared,
+                                      umoe_stream_t stream) {
+    return umoe_grouped_swiglu_fwd(gateup_groups, down_groups, n_fix, S, x, D, I, h_ws, y_shared, stream);
+}
