@@ -262,6 +262,15 @@ int umoe_codec_head_cfg_sample(const umoe_sample_args* a, umoe_stream_t stream);
 int umoe_delay_step(int64_t* pred, int32_t* tokens, int32_t* state, const int32_t* delay, int B, int C, int Tmax,
                     int eos, int pad, int max_delay, umoe_stream_t stream);
 
+/* Per-channel codec cross-entropy of the training loss (model.py:830-847) on already shifted logits [N][C][V] fp32 and
+ * labels [N][C] int64 (-100 = ignore): ch_loss[c] = mean nll over valid labels, total = ch_loss[0] + sum of channels with
+ * at least one valid label.  probs (optional [N][C][V]) keeps the softmax rows for umoe_codec_ce_bwd:
+ * dlogits = grad * (softmax - onehot) / count_c.  Fixed-order reductions, no atomics. */
+int umoe_codec_ce_fwd(const float* logits, const int64_t* labels, int N, int C, int V, float* nll_ws, float* probs,
+                      float* ch_loss, int32_t* ch_count, float* total, umoe_stream_t stream);
+int umoe_codec_ce_bwd(const float* probs, const int64_t* labels, const int32_t* ch_count, int N, int C, int V, float grad,
+                      float* dlogits, umoe_stream_t stream);
+
 /* RVQ (third-party descript-audio-codec 1.0.0 ResidualVectorQuantize, call sites
  * utils/UniMoE_Audio_utils.py:113,123): from_codes = sum_q out_proj_q(codebook_q[code]); nearest = per level
  * in_proj, L2-normalised nearest neighbour, subtract.  All DAC dims are load-time parameters. */

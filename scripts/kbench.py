@@ -71,7 +71,7 @@ if "experts" in which:
     ybuf = torch.zeros(slots + 2 * S, D, device=dev, dtype=torch.bfloat16)
     gub = (8 * 2 * Id * D + 2 * 2 * Is * D) * 2
     dnb = (8 * Id * D + 2 * Is * D) * 2
-    for nt in (2, 4, 8):
+    for nt in (2, 4, 6, 8):
         t = timeit(lambda i: ops.grouped_gemm(sets[i % R][0], x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=nt))
         res[f"gateup_nt{nt}"] = round(t, 2)
         print("gateup nt", nt, f"{t:.2f} us  {gub/t/1e3:.0f} GB/s", flush=True)

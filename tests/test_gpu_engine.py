@@ -187,3 +187,51 @@ def test_delay_step_kernel_vs_reference_trace(dev, case):
     finished[finished == -1] = final_step - md
     lengths = torch.clamp(finished - torch.tensor(psteps), min=0)
     assert torch.equal(lengths, g["out_lengths"])
+
+
+def test_model_forward_hidden_router_stats_and_loss(dev):
+    """Full-sequence forward() (reference model.py:672-871, forward only): last hidden state vs the oracle text model,
+    router statistics returned per layer, codec CE + decayed aux weight * mean aux vs torch on the oracle's logits."""
+    from oracle import decode as OD
+    cfg = small_cfg()
+    m, w = build(cfg, 21, 0.06)
+    B, T = 3, 14
+    torch.manual_seed(22)
+    ids = torch.randint(0, 290, (B, T))
+    am = torch.ones(B, T, dtype=torch.long)
+    am[0, :3] = 0                                        # left padding
+    ids[:, 4:7] = cfg.codec_placeholder_value
+    codec = torch.randint(0, 1024, (B * 3, cfg.codec_channels))
+    codec_labels = torch.randint(0, 1024, (B, T, cfg.codec_channels))
+    codec_labels[:, :6] = -100
+    codec_labels[:, :, 5] = -100
+    x = OD.input_embedding(cfg, w, ids, codec)
+    pos = (am.cumsum(-1) - 1).masked_fill(am == 0, 1)
+    tm = OD.TextModelOracle(cfg, w)
+    h_ref, _, router = tm.forward(x, am.bool(), pos, None, padding_token_mask=am.bool(), collect_router=True)
+    ref_logits = torch.nn.functional.linear(h_ref, w["codec_head.weight"]).float().view(B, T, cfg.codec_channels, -1)
+    gm = m.to(dev)
+    out = gm(input_ids=ids, codec_input_ids=codec, attention_mask=am, labels=ids, codec_labels=codec_labels,
+             output_router_logits_and_topk=True)
+    valid = am.bool()
+    hd = out.hidden_states.cpu().float()[valid] - h_ref.float()[valid]
+    rel = hd.norm(dim=-1) / h_ref.float()[valid].norm(dim=-1)
+    assert float(rel.median()) < 0.02 and float(rel.max()) < 0.3, (float(rel.median()), float(rel.max()))
+    assert len(out.all_router_expert_mask) == cfg.num_hidden_layers and len(out.all_router_top_k) == cfg.num_hidden_layers
+    m0 = out.all_router_expert_mask[0].cpu()
+    assert m0.shape == (B * T, cfg.num_experts)
+    agree = (m0 == router[0]["expert_mask"]).all(-1)[valid.reshape(-1)].float().mean()
+    assert agree > 0.8, float(agree)
+    assert bool((m0[~valid.reshape(-1)][:, : cfg.num_dyn] == 0).all())           # padded tokens route nowhere (core.py:286-288)
+    # loss on the oracle's logits with torch
+    ce = None
+    for c in range(cfg.codec_channels):
+        lab = codec_labels[:, 1:, c].reshape(-1)
+        if c != 0 and int((lab != -100).sum()) == 0:
+            continue
+        l = torch.nn.functional.cross_entropy(ref_logits[:, :-1, c].reshape(-1, ref_logits.shape[-1]), lab, ignore_index=-100)
+        ce = l if ce is None else ce + l
+    aux = torch.stack([r["aux"].float() for r in router]).mean()
+    ref_loss = ce + cfg.l_aux_weight * aux
+    assert abs(float(out.loss) - float(ref_loss)) < 0.03 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
+    assert gm.training_steps == 1 and gm.cur_aux_weight < cfg.l_aux_weight

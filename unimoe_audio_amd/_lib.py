@@ -100,7 +100,7 @@ EXPORTS = [
     "umoe_router_fwd", "umoe_router_dispatch_fwd", "umoe_dispatch_build", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd", "umoe_shared_swiglu_fwd", "umoe_attn_prefill_fwd",
     "umoe_unpermute_combine_fwd", "umoe_rmsnorm_residual_fwd", "umoe_qkv_mrope_kvappend", "umoe_attn_decode",
     "umoe_codec_embed_sum", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
-    "umoe_rvq_nearest", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
+    "umoe_rvq_nearest", "umoe_codec_ce_fwd", "umoe_codec_ce_bwd", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
     "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
     "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step",
 ]
@@ -138,6 +138,8 @@ def lib():
         L.umoe_delay_step.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L.umoe_rvq_from_codes.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
         L.umoe_rvq_nearest.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]
+        L.umoe_codec_ce_fwd.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+        L.umoe_codec_ce_bwd.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp]
         L.umoe_engine_create.argtypes = [C.POINTER(EngineCfg), C.POINTER(vp)]
         L.umoe_engine_set_layer.argtypes = [vp, i32, C.POINTER(LayerWeights)]
         L.umoe_engine_set_globals.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]

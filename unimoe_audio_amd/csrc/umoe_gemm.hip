@@ -324,7 +324,7 @@ static bool use8(const umoe_gemm_args* a, int nt) {
 template <int PRO, int EPI>
 static int launch_gemm_nt(const umoe_gemm_args* a, int nt, hipStream_t s) {
     switch (nt) {
-        case 1: return launch_gemm<1, 8, PRO, EPI>(a, s);
+        case 1: return launch_gemm<1, 16, PRO, EPI>(a, s);   // 16 k-steps per wave at K=2048: the whole stream is requested up front
         case 2: return launch_gemm<2, 8, PRO, EPI>(a, s);
         case 4: return launch_gemm<4, 4, PRO, EPI>(a, s);
         case 5: return use8(a, 5) ? launch_gemm<5, 3, PRO, EPI, 8>(a, s) : launch_gemm<5, 3, PRO, EPI>(a, s);
@@ -383,6 +383,7 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
             UMOE_REQUIRE(nt >= 2, "umoe_grouped_gemm: SwiGLU needs nt >= 2");
             if (nt == 2) return launch_gemm<2, 8, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
             if (nt == 4) return launch_gemm<4, 4, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
+            if (nt == 6) return launch_gemm<6, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
             return use8(a, 8) ? launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s)
                                  : launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
         }

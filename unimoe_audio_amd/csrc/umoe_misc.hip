@@ -688,3 +688,98 @@ extern "C" int umoe_rvq_nearest(const float* z, const float* codebooks, const fl
     UMOE_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ codec cross-entropy
+// reference UniMoE_Audio_model.py:830-847: for every codec channel c an nn.CrossEntropyLoss (mean over labels != -100)
+// of the already shifted logits/labels; channels c != 0 without any valid label are skipped; the channel losses are
+// summed.  logits [N][C][V] fp32, labels [N][C] int64.
+// ce_row_kernel: one workgroup per (n, c) row -> nll[n][c] (0 where ignored); optionally the softmax row for backward.
+__global__ __launch_bounds__(256) void ce_row_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int C,
+                                                     int V, float* __restrict__ nll, float* __restrict__ probs) {
+    __shared__ float sh[4];
+    const size_t row = blockIdx.x;  // n * C + c
+    const float* x = logits + row * V;
+    const int64_t lab = labels[row];
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, x[v]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    float sm = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) sm += expf(x[v] - mx);
+    sm = block_sum_256(sm, sh);
+    const float lse = mx + logf(sm);
+    if (threadIdx.x == 0) nll[row] = (lab >= 0 && lab < V) ? lse - x[lab] : 0.f;
+    if (probs)
+        for (int v = threadIdx.x; v < V; v += 256) probs[row * V + v] = expf(x[v] - lse);
+}
+
+// ce_reduce_kernel: one workgroup per channel; fixed-order sum over n -> channel mean; thread 0 of channel 0 waits for
+// nobody: the total is assembled by a second tiny launch (ce_total_kernel) to stay deterministic without atomics.
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ nll, const int64_t* __restrict__ labels, int N,
+                                                        int C, int V, float* __restrict__ ch_loss, int32_t* __restrict__ ch_count) {
+    __shared__ float sh[4];
+    const int c = blockIdx.x;
+    float s = 0.f, cnt = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const int64_t lab = labels[(size_t)n * C + c];
+        if (lab >= 0 && lab < V) {
+            s += nll[(size_t)n * C + c];
+            cnt += 1.f;
+        }
+    }
+    s = block_sum_256(s, sh);
+    cnt = block_sum_256(cnt, sh);
+    if (threadIdx.x == 0) {
+        ch_count[c] = (int)cnt;
+        ch_loss[c] = cnt > 0.f ? s / cnt : (c == 0 ? NAN : 0.f);  // torch: mean over zero elements is NaN (channel 0 is never skipped)
+    }
+}
+
+__global__ void ce_total_kernel(const float* __restrict__ ch_loss, const int32_t* __restrict__ ch_count, int C, float* total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float t = ch_loss[0];
+        for (int c = 1; c < C; ++c)
+            if (ch_count[c] > 0) t += ch_loss[c];
+        *total = t;
+    }
+}
+
+// dlogits = grad * (softmax - onehot) / count_c for valid rows, 0 elsewhere (probs from ce_row_kernel)
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ probs, const int64_t* __restrict__ labels,
+                                                     const int32_t* __restrict__ ch_count, int C, int V, float grad,
+                                                     float* __restrict__ dlogits) {
+    const size_t row = blockIdx.x;
+    const int c = (int)(row % C);
+    const int64_t lab = labels[row];
+    const bool valid = lab >= 0 && lab < V;
+    const float sc = valid ? grad / (float)ch_count[c] : 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) {
+        float p = probs[row * V + v];
+        if (v == lab) p -= 1.f;
+        dlogits[row * V + v] = sc * p;
+    }
+}
+
+extern "C" int umoe_codec_ce_fwd(const float* logits, const int64_t* labels, int N, int C, int V, float* nll_ws, float* probs,
+                                 float* ch_loss, int32_t* ch_count, float* total, umoe_stream_t stream) {
+    UMOE_REQUIRE(logits && labels && nll_ws && ch_loss && ch_count && total && N > 0 && C > 0 && V > 1, "umoe_codec_ce_fwd: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    ce_row_kernel<<<dim3((unsigned)((size_t)N * C)), 256, 0, s>>>(logits, labels, C, V, nll_ws, probs);
+    UMOE_LAUNCH_CHECK();
+    ce_reduce_kernel<<<dim3((unsigned)C), 256, 0, s>>>(nll_ws, labels, N, C, V, ch_loss, ch_count);
+    UMOE_LAUNCH_CHECK();
+    ce_total_kernel<<<1, 64, 0, s>>>(ch_loss, ch_count, C, total);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int umoe_codec_ce_bwd(const float* probs, const int64_t* labels, const int32_t* ch_count, int N, int C, int V, float grad,
+                                 float* dlogits, umoe_stream_t stream) {
+    UMOE_REQUIRE(probs && labels && ch_count && dlogits && N > 0, "umoe_codec_ce_bwd: bad argument");
+    ce_bwd_kernel<<<dim3((unsigned)((size_t)N * C)), 256, 0, (hipStream_t)stream>>>(probs, labels, ch_count, C, V, grad, dlogits);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}

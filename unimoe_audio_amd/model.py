@@ -9,6 +9,7 @@ replayed as a hipGraph, no per-step host synchronisation (the reference has > 50
 from __future__ import annotations
 
 import ctypes as C
+from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch
@@ -19,6 +20,37 @@ from . import ops
 from .codec_utils import DecoderOutput
 from .config import UniMoEAudioConfig
 from .dcmoe import UniMoEAudioSparseMoeBlock
+
+
+@dataclass
+class BaseModelOutputWithPast:
+    """reference model.py:180-190 (same field names)"""
+    last_hidden_state: torch.Tensor = None
+    past_key_values: Optional[tuple] = None
+    hidden_states: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+    all_router_logits: Optional[tuple] = None
+    all_router_top_k: Optional[tuple] = None
+    all_router_weight: Optional[tuple] = None
+    all_router_expert_mask: Optional[tuple] = None
+    all_aux_loss: Optional[tuple] = None
+
+
+@dataclass
+class MoEQwen2_5VLCausalLMOutputWithPast:
+    """reference model.py:165-177 (+ codec_logits, which the reference only uses internally for the loss)"""
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    codec_logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[tuple] = None
+    hidden_states: Optional[torch.Tensor] = None
+    attentions: Optional[tuple] = None
+    rope_deltas: Optional[torch.Tensor] = None
+    all_router_logits: Optional[tuple] = None
+    all_router_top_k: Optional[tuple] = None
+    all_router_expert_mask: Optional[tuple] = None
+    all_router_weight: Optional[tuple] = None
+    aux_balance_loss: Optional[torch.Tensor] = None
 
 
 class Qwen2RMSNorm(nn.Module):
@@ -121,6 +153,112 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
             x = x.masked_scatter(m, ce)
         return x
 
+    # ---- packed weights shared by forward() and the decode engine ------------------------------------------
+    def packed(self) -> dict:
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if getattr(self, "_pk", None) is not None and self._pk_key == key:
+            return self._pk
+        layers = []
+        for layer in self.language_model.layers:
+            a = layer.self_attn
+            layers.append(dict(
+                qkv_w=ops.pack_weight(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()),
+                qkv_b=torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).float().contiguous(),
+                o_w=ops.pack_weight(a.o_proj.weight.data.contiguous()), moe=layer.mlp.prepare()))
+        self._pk = dict(layers=layers, head=ops.pack_weight(self.codec_head.weight.data.contiguous()),
+                        emb=torch.stack([e.weight.data for e in self.codec_embed_tokens], 0).contiguous())
+        self._pk_key = key
+        return self._pk
+
+    # ---- full-sequence forward (no KV cache kept): reference Qwen2_5_VLMoETextModel.forward, model.py:319-457 ------
+    @torch.no_grad()
+    def text_forward(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                     position_ids: Optional[torch.Tensor] = None, padding_token_mask: Optional[torch.Tensor] = None,
+                     aux_balance_weight: Optional[torch.Tensor] = None, output_router_logits_and_topk: bool = False):
+        cfg, dev = self.config, inputs_embeds.device
+        B, T, D = inputs_embeds.shape
+        H, KVH, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        am = torch.ones(B, T, dtype=torch.long, device=dev) if attention_mask is None else attention_mask.to(dev).long()
+        if position_ids is None:                       # text-only mRoPE: three equal streams (model.py:365-368)
+            pos = (am.cumsum(-1) - 1).masked_fill(am == 0, 1)
+            position_ids = pos[None].expand(3, -1, -1)
+        elif position_ids.dim() == 2:
+            position_ids = position_ids[None].expand(3, -1, -1)
+        pos3 = position_ids.reshape(3, B * T).to(torch.int32).contiguous()
+        kv_pos = torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
+        first_valid = (am != 0).float().argmax(-1).to(torch.int32).contiguous()   # keys before it are left padding
+        q0 = torch.zeros(B, dtype=torch.int32, device=dev)
+        cos, sin = ops.rope_tables(int(position_ids.max()) + 2, hd, cfg.rope_theta, dev)
+        pk = self.packed()
+        x = inputs_embeds.reshape(B * T, D).contiguous()
+        layers = self.language_model.layers
+        h = ops.rmsnorm(x, layers[0].input_layernorm.weight.data, cfg.rms_norm_eps)
+        kc = torch.empty((B, KVH, T, hd), dtype=torch.bfloat16, device=dev)
+        vc = torch.empty_like(kc)
+        stats = dict(logits=[], top_k=[], expert_mask=[], weight=[], aux=[])
+        for li, layer in enumerate(layers):
+            lp = pk["layers"][li]
+            qkv = ops.linear(h, lp["qkv_w"], (H + 2 * KVH) * hd, bias=lp["qkv_b"])
+            q = ops.qkv_mrope_kvappend(qkv, cos, sin, pos3, kv_pos, T, H, KVH, hd, cfg.mrope_section, kc, vc)
+            ao = ops.attention(q, kc, vc, first_valid, q0, T, H, splits=1)
+            x1 = ops.linear(ao, lp["o_w"], D, resid=x)                                   # model.py:238
+            h2 = ops.rmsnorm(x1, layer.post_attention_layernorm.weight.data, cfg.rms_norm_eps)
+            out = layer.mlp(h2.view(B, T, D), padding_token_mask, aux_balance_weight)    # model.py:241
+            nxt = layers[li + 1].input_layernorm.weight.data if li + 1 < len(layers) else self.language_model.norm.weight.data
+            h, x = ops.rmsnorm(out[0].reshape(B * T, D), nxt, cfg.rms_norm_eps, resid=x1)  # x = x1 + moe (model.py:242)
+            if output_router_logits_and_topk:
+                stats["logits"].append(out[1]); stats["top_k"].append(out[2])
+            stats["expert_mask"].append(out[3]); stats["weight"].append(out[4]); stats["aux"].append(out[5])
+        return BaseModelOutputWithPast(last_hidden_state=h.view(B, T, D), all_router_logits=tuple(stats["logits"]) or None,
+                                       all_router_top_k=tuple(stats["top_k"]) or None,
+                                       all_router_expert_mask=tuple(stats["expert_mask"]), all_router_weight=tuple(stats["weight"]),
+                                       all_aux_loss=tuple(stats["aux"]))
+
+    @property
+    def cur_aux_weight(self):
+        """linear decay l_aux_weight -> min_l_aux_weight over l_aux_weight_decay_steps (model.py:489-493)"""
+        cfg = self.config
+        steps = max(1, cfg.l_aux_weight_decay_steps)
+        ts = getattr(self, "training_steps", 0)
+        if ts >= steps:
+            return cfg.min_l_aux_weight
+        return cfg.l_aux_weight - (cfg.l_aux_weight - cfg.min_l_aux_weight) / steps * ts
+
+    @torch.no_grad()
+    def forward(self, input_ids=None, codec_input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None,
+                labels=None, codec_labels=None, aux_balance_weight=None, padding_token_mask=None,
+                output_router_logits_and_topk=None, **unused):
+        """reference UniAudioRVQQwen2_5VLMoEForConditionalGeneration.forward (model.py:672-871), forward pass only:
+        embeddings -> text model -> codec head -> 12 shifted per-channel CE terms + decayed aux weight * mean layer aux."""
+        dev = self.device
+        if inputs_embeds is None:
+            inputs_embeds = self.calculate_input_embedding(input_ids.to(dev), None if codec_input_ids is None else codec_input_ids.to(dev))
+        if attention_mask is not None:
+            attention_mask = attention_mask.to(dev)
+            if aux_balance_weight is not None:
+                aux_balance_weight = attention_mask * aux_balance_weight.to(dev)          # model.py:793-794
+            if padding_token_mask is None:
+                padding_token_mask = attention_mask.bool()                                 # model.py:796-797
+        out = self.text_forward(inputs_embeds, attention_mask, position_ids, padding_token_mask, aux_balance_weight,
+                                bool(output_router_logits_and_topk))
+        B, T, D = out.last_hidden_state.shape
+        C, V = self.num_channels, self.codec_vocab_size
+        codec_logits = ops.linear(out.last_hidden_state.reshape(B * T, D).contiguous(), self.packed()["head"], C * V,
+                                  out_f32=True).view(B, T, C, V)                            # model.py:818-819
+        loss = aux_mean = None
+        if labels is not None and codec_labels is not None:
+            aux_mean = torch.stack([a.float() for a in out.all_aux_loss]).mean()            # model.py:824-826
+            sl = codec_logits[:, :-1].reshape(B * (T - 1), C, V).contiguous()
+            lab = codec_labels.to(dev)[:, 1:].reshape(B * (T - 1), C).contiguous()
+            codec_loss, _, _ = ops.codec_ce(sl, lab)
+            loss = codec_loss + self.cur_aux_weight * aux_mean
+            self.training_steps = getattr(self, "training_steps", 0) + 1                    # model.py:827
+        return MoEQwen2_5VLCausalLMOutputWithPast(loss=loss, logits=None, codec_logits=codec_logits,
+                                                  hidden_states=out.last_hidden_state, all_router_logits=out.all_router_logits,
+                                                  all_router_top_k=out.all_router_top_k,
+                                                  all_router_expert_mask=out.all_router_expert_mask,
+                                                  all_router_weight=out.all_router_weight, aux_balance_loss=aux_mean)
+
     # ---- engine -----------------------------------------------------------------------------------------
     def engine(self, batch: int, max_prompt: int, max_tokens: int, attn_splits: int = 8) -> "DecodeEngine":
         need_L = max_prompt + max_tokens + 8
@@ -201,22 +339,19 @@ class DecodeEngine:
         for p in m.parameters():
             if p.dtype != bf:
                 raise L.UmoeError("engine weights must be bfloat16")
+        mpk = m.packed()
+        self._k(mpk)
         for li, layer in enumerate(m.language_model.layers):
-            a = layer.self_attn
-            qkv_w = self._k(ops.pack_weight(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()))
-            qkv_b = self._k(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).float().contiguous())
-            o_w = self._k(ops.pack_weight(a.o_proj.weight.data.contiguous()))
-            pk = layer.mlp.prepare()
+            lp = mpk["layers"][li]
+            qkv_w, qkv_b, o_w, pk = lp["qkv_w"], lp["qkv_b"], lp["o_w"], lp["moe"]
             n_real, n_fix = cfg.mlp_dynamic_expert_num, cfg.mlp_fixed_expert_num
             arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
             eg, ed, sg, sd = arr(pk["exp_gu"]), arr(pk["exp_dn"]), arr(pk["sh_gu"]), arr(pk["sh_dn"])
-            self.keep += pk["exp_gu"] + pk["exp_dn"] + pk["sh_gu"] + pk["sh_dn"]
             w = L.LayerWeights(in_norm=layer.input_layernorm.weight.data_ptr(), qkv_w=qkv_w.data_ptr(), qkv_b=qkv_b.data_ptr(),
                                o_w=o_w.data_ptr(), post_norm=layer.post_attention_layernorm.weight.data_ptr(),
                                gate_w=layer.mlp.gate.weight.data_ptr(), exp_gu=eg, exp_dn=ed, sh_gu=sg, sh_dn=sd)
             L.check(lib.umoe_engine_set_layer(self.h, li, C.byref(w)), "umoe_engine_set_layer")
-        emb = self._k(torch.stack([e.weight.data for e in m.codec_embed_tokens], 0).contiguous())
-        head = self._k(ops.pack_weight(m.codec_head.weight.data.contiguous()))
+        emb, head = mpk["emb"], mpk["head"]
         max_pos = self.Lmax + 8
         cos, sin = ops.rope_tables(max_pos, cfg.head_dim, cfg.rope_theta, self.dev)
         self._k(cos), self._k(sin)

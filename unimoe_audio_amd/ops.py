@@ -290,3 +290,23 @@ def rvq_nearest(z, codebooks, in_w, in_b, out_w, out_b):
     L.check(L.lib().umoe_rvq_nearest(_p(z), _p(codebooks), _p(in_w), _p(in_b), _p(out_w), _p(out_b), NQ, CB, cd, Dl, T,
                                      _p(codes), _p(ws), _stream()), "umoe_rvq_nearest")
     return codes
+
+
+def codec_ce(logits: torch.Tensor, labels: torch.Tensor, want_grad: bool = False):
+    """logits [N, C, V] fp32 (already shifted), labels [N, C] int64 (-100 = ignore) -> (total, ch_loss [C], ch_count [C], dlogits?)
+    reference training loss, UniMoE_Audio_model.py:830-847."""
+    N, Cc, V = logits.shape
+    dev = logits.device
+    nll = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+    probs = torch.empty((N, Cc, V), dtype=torch.float32, device=dev) if want_grad else None
+    ch_loss = torch.empty(Cc, dtype=torch.float32, device=dev)
+    ch_cnt = torch.empty(Cc, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.float32, device=dev)
+    lab = labels.to(torch.int64).contiguous()
+    L.check(L.lib().umoe_codec_ce_fwd(_p(logits.contiguous()), _p(lab), N, Cc, V, _p(nll), _p(probs), _p(ch_loss), _p(ch_cnt),
+                                      _p(total), _stream()), "umoe_codec_ce_fwd")
+    if not want_grad:
+        return total[0], ch_loss, ch_cnt
+    dl = torch.empty_like(probs)
+    L.check(L.lib().umoe_codec_ce_bwd(_p(probs), _p(lab), _p(ch_cnt), N, Cc, V, 1.0, _p(dl), _stream()), "umoe_codec_ce_bwd")
+    return total[0], ch_loss, ch_cnt, dl
