@@ -109,8 +109,8 @@ def gpu_run(args, rank, world, device):
 
 
 def barrier(world):
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
 
 
@@ -218,19 +218,33 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     mode = args.parallel
-    if world > 1:
+    dist_on = world > 1 or "RANK" in os.environ
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
-        if mode == "auto":
+        os.environ.setdefault("MASTER_PORT", "29511")
+        try:
+            dist.init_process_group("nccl", device_id=device)          # "nccl" is RCCL on ROCm
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+        except Exception as e:  # keep the scaling run alive: the replica mode only needs a barrier and a MAX of one scalar
+            print(f"[bench] RCCL init failed ({e!r}); falling back to gloo for the barrier/reduce", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            dist.init_process_group("gloo")
+    if world > 1:
+        if mode in ("auto", "ep"):
+            # the in-engine RCCL exchange is the next step: this round every rank runs a full replica
             mode = "replica"
     else:
         mode = "single"
     dt, info = gpu_run(args, rank, world, device)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.tensor([dt], device=device if on_gpu else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                        # the slowest rank defines the step time
         dt = float(t.item())
     B, K, W = args.batch, args.steps, args.warmup
     if rank == 0:
@@ -257,7 +271,7 @@ def main():
             except Exception as e:  # the GPU number must not be lost to a host-side problem
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
