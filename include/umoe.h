@@ -76,6 +76,11 @@ typedef struct {
 } umoe_router_args;
 int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 
+/* aux load-balancing loss (core.py:361-389): n_dyn * sum_e mean_s(mask) * mean_s(softmax(masked logits)); token_weight
+ * (optional [S]) = aux_balance_weight expanded per token (core.py:380-385).  out = one fp32 scalar. */
+int umoe_aux_loss_fwd(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S, int E,
+                      int n_dyn, float* out, umoe_stream_t stream);
+
 /* Ragged dispatch tables from the 0/1 mask: the build's replacement for the dense
  * compress_matrix / decompress_matrix pair (utils/UniMoE_Audio_utils.py:436-523) and the
  * capacity MAX of core.py:455-457.  Wavefront ballot + prefix sums, token order preserved.

@@ -783,3 +783,63 @@ extern "C" int umoe_codec_ce_bwd(const float* probs, const int64_t* labels, cons
     UMOE_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ aux load-balancing loss
+// reference audio_load_balancing_loss_func, core.py:361-389: softmax over the n_dyn columns of the logits with
+// unselected experts filled with finfo.min, then n_dyn * sum_e mean_s(mask[s,e]) * mean_s(prob[s,e]) (optionally
+// token-weighted).  One workgroup; each thread owns tokens s = tid, tid+256, ...; fixed-order block reductions.
+// T-arithmetic follows the logits dtype (softmax in T as torch does); the means accumulate in fp32.
+__global__ __launch_bounds__(256) void aux_loss_kernel(const void* __restrict__ logits, int logits_bf16, const int32_t* __restrict__ mask,
+                                                       const float* __restrict__ tok_w, int S, int E, int n_dyn, float* out) {
+    __shared__ float sh[4];
+    float fm[UMOE_MAXE], fp[UMOE_MAXE];
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) fm[e] = fp[e] = 0.f;
+    float wsum = 0.f;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        float x[UMOE_MAXE];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < n_dyn) {
+                const float l = logits_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(logits)[(size_t)s * E + e])
+                                            : reinterpret_cast<const float*>(logits)[(size_t)s * E + e];
+                // masked_fill(mask == 0, finfo(dtype).min)
+                x[e] = mask[(size_t)s * E + e] ? l : (logits_bf16 ? -3.3895313892515355e38f : -3.4028234663852886e38f);
+                mx = fmaxf(mx, x[e]);
+            }
+        float sm = 0.f, ex[UMOE_MAXE];
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < n_dyn) {
+                ex[e] = expf(x[e] - mx);
+                sm += ex[e];
+            }
+        const float w = tok_w ? tok_w[s] : 1.f;
+        wsum += w;
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < n_dyn) {
+                const float p = round_t(ex[e] / sm, logits_bf16);
+                fm[e] += w * (float)mask[(size_t)s * E + e];
+                fp[e] += w * p;
+            }
+    }
+    wsum = block_sum_256(wsum, sh);
+    float total = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < n_dyn) {
+            const float a = block_sum_256(fm[e], sh), b = block_sum_256(fp[e], sh);
+            total += (a / wsum) * (b / wsum);
+        }
+    if (threadIdx.x == 0) *out = total * (float)n_dyn;
+}
+
+extern "C" int umoe_aux_loss_fwd(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S,
+                                 int E, int n_dyn, float* out, umoe_stream_t stream) {
+    UMOE_REQUIRE(logits && expert_mask && out && S > 0 && n_dyn >= 1 && n_dyn <= E && E <= UMOE_MAXE, "umoe_aux_loss_fwd: bad argument");
+    aux_loss_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, logits_bf16, expert_mask, token_weight, S, E, n_dyn, out);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}

@@ -273,16 +273,10 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
 
 
 def aux_loss(expert_mask, n_dyn, full_logits, aux_balance_weight=None):
-    """reference audio_load_balancing_loss_func, core.py:361-389 (small device reductions)."""
-    lowest = torch.finfo(full_logits.dtype).min
-    prob = torch.softmax(full_logits.masked_fill(expert_mask == 0, lowest)[:, :n_dyn], dim=-1)
-    m = expert_mask[:, :n_dyn]
-    if aux_balance_weight is None:
-        frac, mean_prob = m.float().mean(dim=0), prob.mean(dim=0)
-    else:
+    """reference audio_load_balancing_loss_func, core.py:361-389 (one HIP launch, fixed-order reductions)."""
+    tw = None
+    if aux_balance_weight is not None:
         b, t = aux_balance_weight.shape
-        layers = prob.shape[0] // (b * t)
-        w = aux_balance_weight[None, :, :, None].expand(layers, b, t, n_dyn).reshape(-1, n_dyn).to(prob.device)
-        frac = (m.float() * w).sum(0) / w.sum(0)
-        mean_prob = (prob * w).sum(0) / w.sum(0)
-    return (frac * mean_prob).sum() * n_dyn
+        layers = full_logits.shape[0] // (b * t)                     # core.py:381-383
+        tw = aux_balance_weight.reshape(1, b * t).expand(layers, -1).reshape(-1).to(full_logits.device)
+    return ops.aux_loss(full_logits, expert_mask, n_dyn, tw)

@@ -118,6 +118,16 @@ def router_dispatch_fwd(x, gate_w, *, n_dyn, n_real, n_fix, top_p, fixed_top_k=0
     return o
 
 
+def aux_loss(logits: torch.Tensor, expert_mask: torch.Tensor, n_dyn: int, token_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """reference audio_load_balancing_loss_func (core.py:361-389) as one HIP launch; returns a 0-dim fp32 tensor."""
+    S, E = logits.shape
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    tw = None if token_weight is None else token_weight.reshape(-1).float().contiguous()
+    L.check(L.lib().umoe_aux_loss_fwd(_p(logits.contiguous()), int(logits.dtype == torch.bfloat16), _p(expert_mask), _p(tw), S, E, n_dyn,
+                                      _p(out), _stream()), "umoe_aux_loss_fwd")
+    return out[0]
+
+
 def dispatch_build(expert_mask: torch.Tensor, n_real: int) -> dict:
     S, ld = expert_mask.shape
     dev = expert_mask.device
