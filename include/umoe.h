@@ -144,7 +144,10 @@ typedef struct {
     int waves;                /* waves per workgroup: 0 = auto, 4, 8 (8 only with nt = 8; tuning knob) */
     int ksplit;               /* >1: K split over workgroups; needs UMOE_EPI_F32_RAW: slab s at out + s*part_stride */
     long part_stride;         /* elements between fp32 partial slabs */
+    const umoe_group_t* groups_host; /* optional HOST copy of `groups`: with num_groups <= UMOE_GROUPS_INLINE the
+                               * descriptors travel in the kernel arguments (one dependent HBM round trip less per launch) */
 } umoe_gemm_args;
+#define UMOE_GROUPS_INLINE 12
 int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream);
 
 /* Named wrappers required by the scope table; thin calls of umoe_grouped_gemm.

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libumoe_hip.so")
+_SO = os.environ.get("UMOE_HIP_LIB") or os.path.join(_CSRC, "libumoe_hip.so")   # override: diagnostic builds only
 _lib = None
 
 
@@ -47,7 +47,7 @@ class Group(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("groups", vp), ("num_groups", i32), ("max_rows", i32), ("max_n_blocks", i32), ("max_k", i32),
                 ("a", vp), ("lda", i32), ("norm_w", vp), ("rms_eps", f32), ("resid", vp), ("out", vp), ("ldo", i32),
-                ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32), ("waves", i32), ("ksplit", i32), ("part_stride", C.c_long)]
+                ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32), ("waves", i32), ("ksplit", i32), ("part_stride", C.c_long), ("groups_host", vp)]
 
 
 class CombineArgs(C.Structure):

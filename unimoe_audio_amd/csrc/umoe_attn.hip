@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
     __shared__ float al_lds[4][16];          // per wave: rescale factor per head
     __shared__ float red_o[4][16][HD];       // cross-wave merge
     __shared__ float red_ml[4][16][2];
+    TL_ENTER(7);
     const int split = blockIdx.x, kvh = blockIdx.y, qi = blockIdx.z;
     const int row = qi / a.nq, t = qi - row * a.nq;
     const int G = a.H / a.KVH;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
             qf[kb] = __builtin_bit_cast(bf16x8_t, u);
         }
     }
+    TL_MARK(7, 4);
     // running state: this lane's head is c (for m, l); O for ALL heads of the group on 2 columns
     float m_run = -INFINITY, l_run = 0.f;
     float o[GP][2];
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
         process_tile(kfr, vraw, slot, slot + 1);   // keys slot+1.. are masked (p = 0)
     }
 
+    TL_MARK(7, 5);
     // ---- merge the 4 waves --------------------------------------------------------------------
     if (h4 == 0) {
         red_ml[wave][c][0] = m_run;
@@ -289,25 +292,60 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
             pm[1] = L;
         }
     }
+    TL_EXIT(7);
 }
 
+// SP > 0: the split count is a compile-time constant and EVERY partial is requested before the first use
+// (the partials were written by other XCDs: each dependent load is a trip to the Infinity Cache)
+template <int SP>
 __global__ __launch_bounds__(128) void attn_combine_kernel(const umoe_attn_args a) {
     constexpr int HD = 128;
+    TL_ENTER(8);
     const int head = blockIdx.x, qi = blockIdx.y, d = threadIdx.x;
-    const float* pm = a.part_ml + ((size_t)qi * a.H + head) * a.splits * 2;
-    const float* po = a.part_o + ((size_t)qi * a.H + head) * a.splits * HD;
-    float mm = -INFINITY;
-    for (int s = 0; s < a.splits; ++s) mm = fmaxf(mm, pm[2 * s]);
+    const int splits = SP > 0 ? SP : a.splits;
+    const float* pm = a.part_ml + ((size_t)qi * a.H + head) * splits * 2;
+    const float* po = a.part_o + ((size_t)qi * a.H + head) * splits * HD;
     float L = 0.f, acc = 0.f;
-    for (int s = 0; s < a.splits; ++s) {
-        const float ms = pm[2 * s];
-        const float sc = (ms == -INFINITY) ? 0.f : __expf(ms - mm);
-        L += sc * pm[2 * s + 1];
-        acc += sc * po[(size_t)s * HD + d];
+    if (SP > 0) {
+        float2 ml[SP > 0 ? SP : 1];
+        float ov[SP > 0 ? SP : 1];
+#pragma unroll
+        for (int s = 0; s < SP; ++s) {
+            ml[s] = *reinterpret_cast<const float2*>(pm + 2 * s);
+            ov[s] = po[(size_t)s * HD + d];
+        }
+        float mm = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < SP; ++s) mm = fmaxf(mm, ml[s].x);
+#pragma unroll
+        for (int s = 0; s < SP; ++s) {
+            const float sc = (ml[s].x == -INFINITY) ? 0.f : __expf(ml[s].x - mm);
+            L += sc * ml[s].y;
+            acc += sc * ov[s];
+        }
+    } else {
+        float mm = -INFINITY;
+        for (int s = 0; s < splits; ++s) mm = fmaxf(mm, pm[2 * s]);
+        for (int s = 0; s < splits; ++s) {
+            const float ms = pm[2 * s];
+            const float sc = (ms == -INFINITY) ? 0.f : __expf(ms - mm);
+            L += sc * pm[2 * s + 1];
+            acc += sc * po[(size_t)s * HD + d];
+        }
     }
     a.out[((size_t)qi * a.H + head) * HD + d] = f2bf(L > 0.f ? acc / L : 0.f);
+    TL_EXIT(8);
 }
-
+UMOE_TL_SETTER(attn)
+static void launch_attn_combine(const umoe_attn_args* a, dim3 grid, hipStream_t s) {
+    switch (a->splits) {
+        case 1: attn_combine_kernel<1><<<grid, 128, 0, s>>>(*a); break;
+        case 2: attn_combine_kernel<2><<<grid, 128, 0, s>>>(*a); break;
+        case 4: attn_combine_kernel<4><<<grid, 128, 0, s>>>(*a); break;
+        case 8: attn_combine_kernel<8><<<grid, 128, 0, s>>>(*a); break;
+        default: attn_combine_kernel<0><<<grid, 128, 0, s>>>(*a);
+    }
+}
 static void launch_attn(const umoe_attn_args* a, dim3 grid, hipStream_t s) {
     const int G = a->H / a->KVH;
     if (G <= 1) attn_kernel<1><<<grid, 256, 0, s>>>(*a);
@@ -337,7 +375,7 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     if (nqi <= 65535u) {
         launch_attn(a, dim3((unsigned)a->splits, (unsigned)a->KVH, nqi), s);
         UMOE_LAUNCH_CHECK();
-        attn_combine_kernel<<<dim3((unsigned)a->H, nqi), 128, 0, s>>>(*a);
+        launch_attn_combine(a, dim3((unsigned)a->H, nqi), s);
         UMOE_LAUNCH_CHECK();
     } else {
         // process row by row (prefill with very long prompts)
@@ -355,7 +393,7 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
             UMOE_REQUIRE(a->nq <= 65535, "umoe_attn_decode: nq too large");
             launch_attn(&b, dim3((unsigned)a->splits, (unsigned)a->KVH, (unsigned)a->nq), s);
             UMOE_LAUNCH_CHECK();
-            attn_combine_kernel<<<dim3((unsigned)a->H, (unsigned)a->nq), 128, 0, s>>>(b);
+            launch_attn_combine(&b, dim3((unsigned)a->H, (unsigned)a->nq), s);
             UMOE_LAUNCH_CHECK();
         }
     }

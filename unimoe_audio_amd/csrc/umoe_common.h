@@ -31,6 +31,47 @@ void umoe_set_error(const char* fmt, ...);
     } while (0)
 #define UMOE_LAUNCH_CHECK() UMOE_HIP(hipGetLastError())
 
+// ---- optional in-kernel timeline (diagnostic build only: make tl -> libumoe_hip_tl.so, scripts/timeline.py) -----------
+// slots per kernel id: 0 = min entry over workgroups, 1 = max entry, 2 = max exit, 3.. = marks of workgroup (0,0,0)
+#ifdef UMOE_TIMELINE
+// buffer: [layer][kernel id][16 slots] of u64, then one word counting finished dispatch kernels (= current layer for the
+// kernels before the dispatch, layer + 1 for the ones after it)
+#define UMOE_TL_CTR (64 * 256)
+static __device__ unsigned long long* g_tl;
+// time stamps stay in registers until the kernel's exit: nothing but s_memrealtime is added to the measured path
+struct tl_state { unsigned long long m[10]; };
+__device__ __forceinline__ void tl_exit(const tl_state& st, int kid) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t = wall_clock64();
+    int lay = (int)__atomic_load_n(&g_tl[UMOE_TL_CTR], __ATOMIC_RELAXED);
+    if (kid == 2 || kid == 3 || kid == 9) lay -= 1;
+    lay = lay < 0 ? 0 : (lay > 63 ? 63 : lay);
+    const int b = lay * 256 + kid * 16;
+    atomicMin(&g_tl[b + 0], st.m[3]);
+    atomicMax(&g_tl[b + 1], st.m[3]);
+    atomicMax(&g_tl[b + 2], t);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+#pragma unroll
+        for (int k = 3; k < 10; ++k) g_tl[b + k] = st.m[k];
+    }
+    if (kid == 6) atomicAdd(&g_tl[UMOE_TL_CTR], 1ull);
+}
+#define UMOE_TL_SETTER(name) \
+    extern "C" int umoe_tl_set_##name(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &p, sizeof(p)); }
+#define TL_ENTER(kid) tl_state tl_st; for (int tl_i = 0; tl_i < 10; ++tl_i) tl_st.m[tl_i] = 0; tl_st.m[3] = wall_clock64()
+#define TL_MARK(kid, k) tl_st.m[k] = wall_clock64()
+#define TL_EXIT(kid) tl_exit(tl_st, kid)
+#define TL_PARAM , tl_state& tl_st
+#define TL_PASS , tl_st
+#else
+#define UMOE_TL_SETTER(name)
+#define TL_PARAM
+#define TL_PASS
+#define TL_ENTER(kid)
+#define TL_MARK(kid, k)
+#define TL_EXIT(kid)
+#endif
+
 // ---- bf16 <-> f32 (round to nearest even; NaN stays NaN) -----------------------------------
 __host__ __device__ __forceinline__ float bf2f(uint16_t h) {
     union { uint32_t u; float f; } c;

@@ -49,6 +49,7 @@ struct umoe_engine {
     uint16_t *k_cache = nullptr, *v_cache = nullptr;
     int32_t* d_delay = nullptr;
     umoe_group_t* d_groups = nullptr;  // per layer: [qkv 1][o 1][gateup G][down G]; then [head 1]
+    std::vector<umoe_group_t> h_groups;  // host copy: descriptors travel by value in the GEMM kernel arguments
     int groups_for_tok = -1;
     // carved buffers
     uint16_t *x = nullptr, *hin = nullptr, *x1 = nullptr, *h2 = nullptr, *qkv = nullptr, *q_r = nullptr, *attn_out = nullptr,
@@ -145,7 +146,8 @@ static int build_groups(umoe_engine* e, int n_tok, hipStream_t s) {
     if (e->groups_for_tok == n_tok) return 0;
     const umoe_engine_cfg& c = e->c;
     const int G = c.n_real + c.n_fix, GPL = e->groups_per_layer();
-    std::vector<umoe_group_t> h((size_t)c.layers * GPL + 1);
+    std::vector<umoe_group_t>& h = e->h_groups;
+    h.assign((size_t)c.layers * GPL + 1, umoe_group_t{});
     const int slots_routed = n_tok * c.n_real;
     for (int l = 0; l < c.layers; ++l) {
         const LayerDev& L = e->layers[l];
@@ -291,11 +293,12 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     const int Imax = c.inter_dyn > c.inter_shared ? c.inter_dyn : c.inter_shared;
     const LayerDev& L = e->layers[l];
     const umoe_group_t* g = e->d_groups + (size_t)l * GPL;
+    const umoe_group_t* gh = e->h_groups.data() + (size_t)l * GPL;   // same table, host side
     const size_t kv_l = (size_t)l * c.rows * c.kv_heads * c.Lmax * c.head_dim;
     int rc;
     // 1. RMSNorm + QKV (+bias)                                   model.py:227, Qwen2_5_VLAttention q/k/v_proj
     umoe_gemm_args a{};
-    a.groups = g; a.num_groups = 1; a.max_rows = n_tok; a.max_n_blocks = QKV / 16; a.max_k = D;
+    a.groups = g; a.groups_host = gh; a.num_groups = 1; a.max_rows = n_tok; a.max_n_blocks = QKV / 16; a.max_k = D;
     a.a = e->hin; a.lda = D; a.out = e->qkv; a.ldo = QKV; a.n_valid = QKV;   // hin = RMSNorm(x) from the previous combine
     a.prologue = UMOE_PRO_PLAIN; a.epilogue = UMOE_EPI_BF16;
     PROF(-1);
@@ -325,7 +328,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     PROF(K_ATTN);
     // 4. o_proj + residual                                        model.py:238
     umoe_gemm_args o{};
-    o.groups = g + 1; o.num_groups = 1; o.max_rows = n_tok; o.max_n_blocks = D / 16; o.max_k = HD;
+    o.groups = g + 1; o.groups_host = gh + 1; o.num_groups = 1; o.max_rows = n_tok; o.max_n_blocks = D / 16; o.max_k = HD;
     o.a = e->attn_out; o.lda = HD; o.resid = e->x; o.out = e->x1; o.ldo = D; o.n_valid = D;
     o.prologue = UMOE_PRO_PLAIN; o.epilogue = UMOE_EPI_BF16_RESID;
     if ((rc = umoe_grouped_gemm(&o, s))) return rc;
@@ -334,12 +337,12 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         UMOE_HIP(hipEventRecord(e->ev_fork, s));
         UMOE_HIP(hipStreamWaitEvent(e->s2, e->ev_fork, 0));
         umoe_gemm_args sg{};
-        sg.groups = g + 2 + c.n_real; sg.num_groups = c.n_fix; sg.max_rows = n_tok; sg.max_n_blocks = 2 * c.inter_shared / 16;
+        sg.groups = g + 2 + c.n_real; sg.groups_host = gh + 2 + c.n_real; sg.num_groups = c.n_fix; sg.max_rows = n_tok; sg.max_n_blocks = 2 * c.inter_shared / 16;
         sg.max_k = D; sg.a = e->x1; sg.lda = D; sg.norm_w = L.w.post_norm; sg.rms_eps = c.rms_eps;
         sg.out = e->hbuf; sg.ldo = Imax; sg.n_valid = Imax; sg.prologue = UMOE_PRO_RMSNORM; sg.epilogue = UMOE_EPI_SWIGLU;
         if ((rc = umoe_grouped_gemm(&sg, e->s2))) return rc;
         umoe_gemm_args sd{};
-        sd.groups = g + 2 + G + c.n_real; sd.num_groups = c.n_fix; sd.max_rows = n_tok; sd.max_n_blocks = D / 16;
+        sd.groups = g + 2 + G + c.n_real; sd.groups_host = gh + 2 + G + c.n_real; sd.num_groups = c.n_fix; sd.max_rows = n_tok; sd.max_n_blocks = D / 16;
         sd.max_k = c.inter_shared; sd.a = e->hbuf; sd.lda = Imax; sd.out = e->ybuf; sd.ldo = D; sd.n_valid = D;
         sd.prologue = UMOE_PRO_PLAIN; sd.epilogue = UMOE_EPI_BF16;
         if ((rc = umoe_grouped_gemm(&sd, e->s2))) return rc;
@@ -363,14 +366,14 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // see below) and are joined before the combine; otherwise routed + shared share one launch each.
     const bool ov = e->overlap_shared && c.n_fix > 0;
     umoe_gemm_args gu{};
-    gu.groups = g + 2; gu.num_groups = ov ? c.n_real : G; gu.max_rows = n_tok;
+    gu.groups = g + 2; gu.groups_host = gh + 2; gu.num_groups = ov ? c.n_real : G; gu.max_rows = n_tok;
     gu.max_n_blocks = 2 * (ov ? c.inter_dyn : Imax) / 16; gu.max_k = D;
     gu.a = e->h2; gu.lda = D; gu.out = e->hbuf; gu.ldo = Imax; gu.n_valid = Imax;
     gu.prologue = UMOE_PRO_PLAIN; gu.epilogue = UMOE_EPI_SWIGLU;
     if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
     PROF(K_GATEUP);
     umoe_gemm_args dn{};
-    dn.groups = g + 2 + G; dn.num_groups = ov ? c.n_real : G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16;
+    dn.groups = g + 2 + G; dn.groups_host = gh + 2 + G; dn.num_groups = ov ? c.n_real : G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16;
     dn.max_k = ov ? c.inter_dyn : Imax;
     dn.a = e->hbuf; dn.lda = Imax; dn.out = e->ybuf; dn.ldo = D; dn.n_valid = D;
     dn.prologue = UMOE_PRO_PLAIN; dn.epilogue = UMOE_EPI_BF16;
@@ -475,7 +478,8 @@ static int enqueue_step(umoe_engine* e, const umoe_decode_io* io, hipStream_t s)
         if ((rc = run_layer(e, l, c.rows, 1, c.attn_splits, s))) return rc;
     // final norm + codec head -> fp32 logits                       model.py:428, 982-983
     umoe_gemm_args h{};
-    h.groups = e->d_groups + (size_t)c.layers * e->groups_per_layer(); h.num_groups = 1; h.max_rows = c.rows;
+    h.groups = e->d_groups + (size_t)c.layers * e->groups_per_layer();
+    h.groups_host = e->h_groups.data() + (size_t)c.layers * e->groups_per_layer(); h.num_groups = 1; h.max_rows = c.rows;
     h.max_n_blocks = ceil_div(C * V, 16); h.max_k = c.hidden; h.a = e->hin; h.lda = c.hidden;   // hin = final norm(x)
     h.out = e->logits; h.ldo = C * V; h.n_valid = C * V;
     h.prologue = UMOE_PRO_PLAIN; h.epilogue = UMOE_EPI_F32;

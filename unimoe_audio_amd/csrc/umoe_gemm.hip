@@ -18,6 +18,7 @@
 //    never synchronises on the router's result.
 // Roofline: HBM. Algorithmic bytes per launch = sum over groups hit of N*K*2 (+ activations).
 #include "umoe_common.h"
+#include <string.h>
 
 // ------------------------------------------------------------------------------------ packing
 __global__ void pack_kernel(const uint16_t* __restrict__ Wa, const uint16_t* __restrict__ Wb, int N, int K, int KB,
@@ -68,14 +69,17 @@ __device__ __forceinline__ int lds_chunk_off(int QS, int h, int i, int m) {
     return h * QS + (i >> 4) * 256 + (((i & 15) + m) & 15) * 16;
 }
 
+struct umoe_group_pack { umoe_group_t g[UMOE_GROUPS_INLINE]; };
+
 template <int NT, int U, int PRO, int EPI, int WV>
-__global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) {
+__global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    const umoe_group_t g = p.groups[blockIdx.z];
-    const int count = g.count ? *g.count : g.static_count;
-    const int row0 = blockIdx.y * 16;
-    if (row0 >= count) return;
+    constexpr int KID = EPI == UMOE_EPI_SWIGLU ? 2 : (EPI == UMOE_EPI_F32 ? 4 : (EPI == UMOE_EPI_BF16_RESID ? 1 : (NT == 1 ? 0 : 3)));
+    (void)KID;
+    TL_ENTER(KID);
+    // group descriptor: from the kernel arguments when the host passed them by value (scalar loads, no HBM round trip)
+    const umoe_group_t g = p.groups_host ? gp.g[blockIdx.z] : p.groups[blockIdx.z];
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int ks = blockIdx.x % ksplit;      // K-slice of this workgroup (fp32 partial slab `ks`)
     const int nb0 = (blockIdx.x / ksplit) * NT;
@@ -87,9 +91,9 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) 
     const int QS = (((ib - ia) * 16) + 255) & ~255;  // bytes of one staged K-quarter slice of a row, padded to 256
     const int RS = QS * 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int roff = g.row_off ? *g.row_off : 0;
 
-    // ---- weight stream set-up; the first chunk is requested BEFORE the activation tile is staged -----------
+    // ---- weight stream set-up: the first chunk is requested BEFORE anything that depends on device-produced data
+    //      (row counts, gather lists, activations), so the HBM latency of the stream overlaps the whole prologue ----
     const int i0 = ia + ((ib - ia) * wave) / WV, i1 = ia + ((ib - ia) * (wave + 1)) / WV;
     f32x4_t acc[NT];
     const u32x4_t* wp[NT];
@@ -109,13 +113,20 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) 
         }
     };
     if (i0 < i1) load_chunk(w0, i0);
+    TL_MARK(KID, 4);
 
-    // ---- stage the 16-row activation tile ----------------------------------------------------------------
+    const int count = g.count ? *g.count : g.static_count;
+    const int roff = g.row_off ? *g.row_off : 0;
+    const int row0 = blockIdx.y * 16;
+    if (row0 >= count) return;   // (an expert no row chose: its first chunk was requested for nothing -- rare at 16 rows)
+
+    // ---- stage the 16-row activation tile: every global load of a thread is in flight before the first LDS write ----
     {
         constexpr int TPR = WV * 4;  // threads per activation row
         const int m = tid / TPR, sub = tid % TPR;
         const int r = row0 + m;
-        const bool valid = r < count;
+        const bool valid = r < count;   // rows beyond the count stay unwritten: a token is one MFMA column, garbage
+                                        // there never reaches another token's outputs and is never stored
         long arow = 0;
         if (valid) arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
         const uint16_t* src = p.a + arow * (long)p.lda + g.a_col_off;
@@ -130,13 +141,14 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) 
             for (int n = 0; n < 16; ++n) {
                 const int c = sub + TPR * n;
                 buf[n] = make_uint4(0, 0, 0, 0);
-                if (valid && c < 4 * Q8) {
-                    buf[n] = ld16(src + c * 8);
-                    float f[8];
-                    unpack8(buf[n], f);
+                if (valid && c < 4 * Q8) buf[n] = ld16(src + c * 8);
+            }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
-                }
+            for (int n = 0; n < 16; ++n) {
+                float f[8];
+                unpack8(buf[n], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
             }
 #pragma unroll
             for (int o = TPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -173,26 +185,56 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) 
                 for (int o = TPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
                 rs = rsqrtf(ss / (float)K + p.rms_eps);
             }
-            for (int h = 0; h < 4; ++h)
-                for (int i = ia + sub; i < ib; i += TPR) {
-                    const int c = h * Q8 + i;
-                    uint4 u = make_uint4(0, 0, 0, 0);
-                    if (valid) {
-                        u = ld16(src + c * 8);
+            // rounds of 16 loads per thread (4 per K-quarter); one round covers K <= 128 * TPR
+            for (int ib0 = 0; ib0 < QW; ib0 += 4 * TPR) {
+                uint4 buf[16];
+#pragma unroll
+                for (int n = 0; n < 16; ++n) {
+                    const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
+                    if (valid && i < QW) buf[n] = ld16(src + (h * Q8 + ia + i) * 8);
+                }
+#pragma unroll
+                for (int n = 0; n < 16; ++n) {
+                    const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
+                    if (valid && i < QW) {
+                        uint4 u = buf[n];
                         if (PRO == UMOE_PRO_RMSNORM) {
                             float f[8], w[8];
                             unpack8(u, f);
-                            unpack8(ld16(p.norm_w + c * 8), w);
+                            unpack8(ld16(p.norm_w + (h * Q8 + ia + i) * 8), w);
 #pragma unroll
                             for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
                             u = pack8(f);
                         }
+                        st16(dst + lds_chunk_off(QS, h, i, m), u);
                     }
-                    st16(dst + lds_chunk_off(QS, h, i - ia, m), u);
                 }
+            }
         }
     }
+    // ---- epilogue operands (bias / residual) requested now, consumed after the reduction ---------------------------
+    constexpr int TPW = (NT + WV - 1) / WV;   // output tiles finished by one wave
+    const int hq = lane >> 4, mq = lane & 15;
+    float4 bias_r[TPW];
+    uint2 resid_r[TPW];
+    const bool bias_vec = g.bias && ((size_t)g.bias & 15) == 0;
+    if (EPI != UMOE_EPI_SWIGLU) {
+        const long orow_q = (long)g.out_row_base + roff + row0 + mq;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int t = wave + q * WV;
+            const int n = (nb0 + t) * 16 + 4 * hq;
+            bias_r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            resid_r[q] = make_uint2(0, 0);
+            const bool live = t < NT && nb0 + t < g.n_blocks && row0 + mq < count && n + 3 < p.n_valid;
+            if (live && bias_vec) bias_r[q] = *reinterpret_cast<const float4*>(g.bias + n);
+            if (EPI == UMOE_EPI_BF16_RESID && live && (p.ldo & 3) == 0)
+                resid_r[q] = *reinterpret_cast<const uint2*>(p.resid + orow_q * p.ldo + n);
+        }
+    }
+    TL_MARK(KID, 5);
     __syncthreads();
+    TL_MARK(KID, 6);
 
     // ---- stream weights (double-buffered in registers), 4 waves split K -------------------------------------
     const int h = lane >> 4, mm = lane & 15;
@@ -219,7 +261,9 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) 
     }
 
     // ---- fixed-order cross-wave reduction through the (now free) staging area -------------------------------
+    TL_MARK(KID, 7);
     __syncthreads();
+    TL_MARK(KID, 8);
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
 #pragma unroll
     for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[t];
@@ -254,15 +298,21 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) 
             uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + col;
             *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
         }
+        TL_EXIT(KID);
         return;
     }
-    for (int t = wave; t < NT; t += WV) {
-        if (nb0 + t >= g.n_blocks) break;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int t = wave + q * WV;
+        if (t >= NT || nb0 + t >= g.n_blocks) break;
         const f32x4_t a4 = reduced(t);
         const int n = (nb0 + t) * 16 + 4 * h;
+        const bool fast = n + 3 < p.n_valid;   // whole 4-feature group valid: operands were prefetched
         float v[4];
+        const float bq[4] = {bias_r[q].x, bias_r[q].y, bias_r[q].z, bias_r[q].w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = a4[j] + ((g.bias && n + j < p.n_valid) ? g.bias[n + j] : 0.f);
+        for (int j = 0; j < 4; ++j)
+            v[j] = a4[j] + ((fast && (bias_vec || !g.bias)) ? bq[j] : ((g.bias && n + j < p.n_valid) ? g.bias[n + j] : 0.f));
         if (EPI == UMOE_EPI_F32 || EPI == UMOE_EPI_F32_RAW) {
             float* o = reinterpret_cast<float*>(p.out) + (size_t)ks * p.part_stride + orow * p.ldo + n;
 #pragma unroll
@@ -274,7 +324,12 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float x = rbf(v[j]);
-                if (EPI == UMOE_EPI_BF16_RESID && n + j < p.n_valid) x = bf2f(p.resid[orow * p.ldo + n + j]) + x;
+                if (EPI == UMOE_EPI_BF16_RESID && n + j < p.n_valid) {
+                    const uint32_t rw = j < 2 ? resid_r[q].x : resid_r[q].y;
+                    const float rv = (fast && (p.ldo & 3) == 0) ? __uint_as_float((j & 1) ? (rw & 0xffff0000u) : (rw << 16))
+                                                                : bf2f(p.resid[orow * p.ldo + n + j]);
+                    x = rv + x;
+                }
                 y[j] = f2bf(x);
             }
             if (n + 3 < p.n_valid && (p.ldo & 3) == 0) {
@@ -286,8 +341,10 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p) 
             }
         }
     }
+    TL_EXIT(KID);
 }
 
+UMOE_TL_SETTER(gemm)
 // ------------------------------------------------------------------------------------ launcher
 static size_t gemm_lds_bytes(int max_k, int NT, int WV, int ksplit) {
     const int KB = max_k >> 5;
@@ -309,7 +366,15 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
         configured = lds;
     }
     dim3 grid((unsigned)(ceil_div(a->max_n_blocks, NT) * ksplit), (unsigned)ceil_div(a->max_rows, 16), (unsigned)a->num_groups);
-    wstream_gemm<NT, U, PRO, EPI, WV><<<grid, WV * 64, lds, s>>>(*a);
+    umoe_group_pack gp;
+    umoe_gemm_args b = *a;
+    if (a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE) {
+        memcpy(gp.g, a->groups_host, sizeof(umoe_group_t) * a->num_groups);
+    } else {
+        b.groups_host = nullptr;
+        memset(&gp, 0, sizeof(umoe_group_t));
+    }
+    wstream_gemm<NT, U, PRO, EPI, WV><<<grid, WV * 64, lds, s>>>(b, gp);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -347,7 +412,8 @@ static int auto_nt(const umoe_gemm_args* a, bool swiglu) {
 }
 
 extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) {
-    UMOE_REQUIRE(a && a->groups && a->a && a->out, "umoe_grouped_gemm: null argument");
+    UMOE_REQUIRE(a && (a->groups || (a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE)) && a->a && a->out,
+                 "umoe_grouped_gemm: null argument");
     UMOE_REQUIRE(a->num_groups > 0 && a->num_groups <= 65535, "umoe_grouped_gemm: bad num_groups %d", a->num_groups);
     UMOE_REQUIRE(a->max_k > 0 && a->max_k % 32 == 0, "umoe_grouped_gemm: K must be a multiple of 32 (got %d)", a->max_k);
     UMOE_REQUIRE(a->max_rows > 0 && a->max_n_blocks > 0, "umoe_grouped_gemm: empty problem");

@@ -77,6 +77,7 @@ extern "C" int umoe_rmsnorm_residual_fwd(const uint16_t* x, const uint16_t* r, c
 // core.py:342, shared experts `expert(x) * w` then add core.py:349-351, residual model.py:242.
 __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a) {
     __shared__ float sh[4];
+    TL_ENTER(9);
     const int s = blockIdx.x;
     const int E = a.n_dyn + a.n_fix;
     float ss = 0.f;
@@ -99,36 +100,89 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a)
             unpack8(ld16(a.y_slots + (size_t)row * a.D + c * 8), y);
         }
     };
+    // routing of this token: all table entries first (one round trip), then every selected expert row, the shared
+    // rows and the residual are requested together; the accumulation order below is the reference's
+    int slot[UMOE_MAXE];
+    float wgt[UMOE_MAXE], swgt[UMOE_MAXE];
+    const bool fastp = !a.y_parts && a.n_real <= UMOE_MAXE && a.n_fix <= 4;
+    if (fastp) {
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e) {
+            slot[e] = -1;
+            wgt[e] = 0.f;
+            if (e < a.n_real) {
+                slot[e] = a.slot_of[(size_t)s * a.n_real + e];
+                wgt[e] = a.moe_w[(size_t)s * a.n_real + e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) swgt[i] = (a.y_shared && i < a.n_fix) ? a.global_w[(size_t)s * E + a.n_dyn + i] : 0.f;
+    }
     for (int c = threadIdx.x; c < (a.D >> 3); c += 256) {
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        for (int e = 0; e < a.n_real; ++e) {
-            const int slot = a.slot_of[(size_t)s * a.n_real + e];
-            if (slot >= 0) {
-                const float wgt = a.moe_w[(size_t)s * a.n_real + e];
-                float y[8];
-                load_y(slot, c, y);
+        if (fastp) {
+            uint4 yv[UMOE_MAXE], sv[4], rv = make_uint4(0, 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += wgt * y[j];
+            for (int e = 0; e < UMOE_MAXE; ++e)
+                if (e < a.n_real && slot[e] >= 0) yv[e] = ld16(a.y_slots + (size_t)slot[e] * a.D + c * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (a.y_shared && i < a.n_fix) sv[i] = ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8);
+            if (a.resid) rv = ld16(a.resid + (size_t)s * a.D + c * 8);
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e)
+                if (e < a.n_real && slot[e] >= 0) {
+                    float y[8];
+                    unpack8(yv[e], y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += wgt[e] * y[j];
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (a.y_shared && i < a.n_fix) {
+                    float y[8];
+                    unpack8(sv[i], y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j] + rbf(y[j] * swgt[i]));
+                }
+            if (a.resid) {
+                float r[8];
+                unpack8(rv, r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = r[j] + acc[j];
             }
-        }
+        } else {
+            for (int e = 0; e < a.n_real; ++e) {
+                const int sl = a.slot_of[(size_t)s * a.n_real + e];
+                if (sl >= 0) {
+                    const float wg = a.moe_w[(size_t)s * a.n_real + e];
+                    float y[8];
+                    load_y(sl, c, y);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j]);
-        if (a.y_shared || (a.y_parts && a.shared_row0 >= 0))
-            for (int i = 0; i < a.n_fix; ++i) {
-                const float wgt = a.global_w[(size_t)s * E + a.n_dyn + i];
-                float y[8];
-                if (a.y_shared) unpack8(ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8), y);
-                else load_y((long)a.shared_row0 + (long)i * a.S + s, c, y);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j] + rbf(y[j] * wgt));
+                    for (int j = 0; j < 8; ++j) acc[j] += wg * y[j];
+                }
             }
-        if (a.resid) {
-            float r[8];
-            unpack8(ld16(a.resid + (size_t)s * a.D + c * 8), r);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = r[j] + acc[j];
+            for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j]);
+            if (a.y_shared || (a.y_parts && a.shared_row0 >= 0))
+                for (int i = 0; i < a.n_fix; ++i) {
+                    const float wg = a.global_w[(size_t)s * E + a.n_dyn + i];
+                    float y[8];
+                    if (a.y_shared) unpack8(ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8), y);
+                    else load_y((long)a.shared_row0 + (long)i * a.S + s, c, y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j] + rbf(y[j] * wg));
+                }
+            if (a.resid) {
+                float r[8];
+                unpack8(ld16(a.resid + (size_t)s * a.D + c * 8), r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = r[j] + acc[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -137,6 +191,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a)
         }
         st16(a.out + (size_t)s * a.D + c * 8, pack8(acc));
     }
+    TL_MARK(9, 4);
     if (!a.norm_w) return;
     // fused RMSNorm of the row just produced (input_layernorm of the NEXT layer / final norm): saves every QKV
     // workgroup from recomputing it (model.py:227,428)
@@ -150,7 +205,9 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a)
         for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
         st16(a.norm_out + (size_t)s * a.D + c * 8, pack8(f));
     }
+    TL_EXIT(9);
 }
+UMOE_TL_SETTER(misc)
 
 extern "C" int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_stream_t stream) {
     UMOE_REQUIRE(a && (a->y_slots || (a->y_parts && a->n_parts > 0)) && a->slot_of && a->moe_w && a->out && a->D % 8 == 0,

@@ -102,10 +102,10 @@ __device__ __forceinline__ float reduce16_to_lanes(float (&acc)[UMOE_MAXE], int 
 
 // ND / NF: compile-time n_dyn / n_fix (ND == 0: generic runtime sizes); TB: 1 = bf16 arithmetic type, 0 = fp32
 template <int ND, int NF, int TB>
-__device__ __forceinline__ int route_from_logits(const umoe_router_args& a, const int s, const int lane, float full);
+__device__ __forceinline__ int route_from_logits(const umoe_router_args& a, const int s, const int lane, float full TL_PARAM);
 
 template <int ND, int NF, int TB>
-__device__ __forceinline__ int route_token(const umoe_router_args& a, const int s, const int lane) {
+__device__ __forceinline__ int route_token(const umoe_router_args& a, const int s, const int lane TL_PARAM) {
     const int n_dyn = ND > 0 ? ND : a.n_dyn;
     const int E = ND > 0 ? ND + NF : a.n_dyn + a.n_fix;
     constexpr int T = TB;
@@ -135,6 +135,7 @@ __device__ __forceinline__ int route_token(const umoe_router_args& a, const int 
 #pragma unroll
             for (int n = 0; n < 4; ++n)
                 if (n < nch) gwv[e][n] = ld16(a.gate_w + (size_t)e * a.D + (lane + 64 * n) * 8);
+        TL_MARK(5, 4);
         float rs = 1.f;
         if (a.norm_w) {
             float ss = 0.f;
@@ -149,6 +150,7 @@ __device__ __forceinline__ int route_token(const umoe_router_args& a, const int 
             ss = wave_sum(ss);
             rs = rsqrtf(ss / (float)a.D + a.rms_eps);
         }
+        TL_MARK(5, 5);
         float acc[UMOE_MAXE];
 #pragma unroll
         for (int e = 0; e < UMOE_MAXE; ++e) acc[e] = 0.f;
@@ -221,12 +223,13 @@ __device__ __forceinline__ int route_token(const umoe_router_args& a, const int 
         const float mine = reduce16_to_lanes(acc, lane);
         if (lane < E) full = round_t(mine, T);
     }
-    return route_from_logits<ND, NF, TB>(a, s, lane, full);
+    TL_MARK(5, 6);
+    return route_from_logits<ND, NF, TB>(a, s, lane, full TL_PASS);
 }
 
 
 template <int ND, int NF, int TB>
-__device__ __forceinline__ int route_from_logits(const umoe_router_args& a, const int s, const int lane, float full) {
+__device__ __forceinline__ int route_from_logits(const umoe_router_args& a, const int s, const int lane, float full TL_PARAM) {
     const int n_dyn = ND > 0 ? ND : a.n_dyn;
     const int E = ND > 0 ? ND + NF : a.n_dyn + a.n_fix;
     constexpr int T = TB;
@@ -276,6 +279,7 @@ __device__ __forceinline__ int route_from_logits(const umoe_router_args& a, cons
         k = below + 1;
     }
     if (k > n_dyn) k = n_dyn;
+    TL_MARK(5, 7);
 
     // ---- iterative arg-max mixer, eval branch (core.py:94-154, 262-282) -----------------------
     const float two_eps = round_t((float)(2.0 * a.jitter_eps), T);
@@ -308,6 +312,7 @@ __device__ __forceinline__ int route_from_logits(const umoe_router_args& a, cons
         if (a.sel && lane == 0) a.sel[(size_t)s * n_dyn + j] = ind;
     }
     if (a.sel && lane >= k && lane < n_dyn) a.sel[(size_t)s * n_dyn + lane] = -1;
+    TL_MARK(5, 8);
 
     // ---- renormalise / padding / shared always on (core.py:284-291) ---------------------------
     float ws[UMOE_MAXE];
@@ -348,10 +353,13 @@ __device__ __forceinline__ int route_from_logits(const umoe_router_args& a, cons
 
 template <int ND, int NF, int TB>
 __global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
+    TL_ENTER(5);
     const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= a.S) return;
-    route_token<ND, NF, TB>(a, s, threadIdx.x & 63);
+    route_token<ND, NF, TB>(a, s, threadIdx.x & 63 TL_PASS);
+    TL_EXIT(5);
 }
+UMOE_TL_SETTER(router)
 
 extern "C" int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 extern "C" int umoe_dispatch_build(const int32_t*, int, int, int, int32_t*, int32_t*, int32_t*, int32_t*, umoe_stream_t);
@@ -381,6 +389,7 @@ __global__ __launch_bounds__(256) void dispatch_small_kernel(const int32_t* __re
                                                              int32_t* counts, int32_t* offsets, int32_t* slot_token,
                                                              int32_t* slot_of) {
     __shared__ int cnt_s[UMOE_MAXE];
+    TL_ENTER(6);
     const int e = threadIdx.x >> 4, t = threadIdx.x & 15;
     const bool mine = e < n_real;
     const bool on = mine && t < S && mask[(size_t)t * ld + e] != 0;
@@ -400,6 +409,7 @@ __global__ __launch_bounds__(256) void dispatch_small_kernel(const int32_t* __re
             if (e == n_real - 1) offsets[n_real] = off + cnt;
         }
     }
+    TL_EXIT(6);
 }
 
 // router + dispatch tables (decode, S <= 16: one-wave-per-token router + a 256-thread ballot dispatch)

@@ -166,6 +166,7 @@ class GroupTable:
             arr[i].n_blocks = int(g["n_blocks"])
             arr[i].k = int(g["k"])
             arr[i].a_col_off = int(g.get("a_col_off", 0))
+        self.host = arr          # host copy: the descriptors also travel by value in the kernel arguments
         raw = bytes(arr)
         self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
         self.n = len(groups)
@@ -178,7 +179,8 @@ def grouped_gemm(table: GroupTable, a: torch.Tensor, out: torch.Tensor, *, max_r
     args = L.GemmArgs(groups=_p(table.dev), num_groups=table.n, max_rows=max_rows, max_n_blocks=table.max_n_blocks,
                       max_k=table.max_k, a=_p(a), lda=a.stride(0), norm_w=_p(norm_w), rms_eps=rms_eps, resid=_p(resid),
                       out=_p(out), ldo=out.stride(-2), n_valid=out.shape[1] if n_valid is None else n_valid,
-                      prologue=prologue, epilogue=epilogue, nt=nt, waves=waves, ksplit=ksplit, part_stride=part_stride)
+                      prologue=prologue, epilogue=epilogue, nt=nt, waves=waves, ksplit=ksplit, part_stride=part_stride,
+                      groups_host=C.cast(table.host, C.c_void_p))
     L.check(L.lib().umoe_grouped_gemm(C.byref(args), _stream()), "umoe_grouped_gemm")
     return out
 
