@@ -146,8 +146,15 @@ typedef struct {
     long part_stride;         /* elements between fp32 partial slabs */
     const umoe_group_t* groups_host; /* optional HOST copy of `groups`: with num_groups <= UMOE_GROUPS_INLINE the
                                * descriptors travel in the kernel arguments (one dependent HBM round trip less per launch) */
+    int cache_policy;         /* reserved (0): the weight stream is always non-temporal -- a default-policy variant and an
+                               * Infinity Cache warm-up were measured and bought nothing */
 } umoe_gemm_args;
 #define UMOE_GROUPS_INLINE 12
+
+/* Warm the Infinity Cache (256 MiB, memory side) with `bytes` at `p`: plain loads, nothing stored.  `wgs` workgroups of 256
+ * threads, 8 x 16 B per thread in flight.  Used to pull the next weight-streaming kernel's first bytes out of HBM while
+ * a latency-bound kernel leaves the memory idle. */
+int umoe_prefetch(const void* p, size_t bytes, int wgs, umoe_stream_t stream);
 int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream);
 
 /* Named wrappers required by the scope table; thin calls of umoe_grouped_gemm.
@@ -178,6 +185,8 @@ typedef struct {
     const uint16_t* norm_w;   /* optional [D]: also write norm_out = RMSNorm(out) * norm_w (next layer's input norm) */
     uint16_t* norm_out;       /* [S][D] */
     float rms_eps;
+    const int32_t* expert_mask; /* dense-expert layout (slot_of == NULL): expert e's output row of token s is e*dense_rows + s, */
+    int mask_ld, dense_rows;    /* used iff expert_mask[s*mask_ld + e] != 0 (every expert computed all rows; decode, S <= 16) */
 } umoe_combine_args;
 int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_stream_t stream);
 

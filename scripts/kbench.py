@@ -85,6 +85,47 @@ if "experts" in which:
     t = timeit(lambda i: ops.grouped_gemm(sets[i % R][0], x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=8, waves=8))
     print("gateup nt 8 waves 8", f"{t:.2f} us  {gub/t/1e3:.0f} GB/s", flush=True)
 
+if "mall" in which:
+    # Does the Infinity Cache (256 MiB) feed a weight-streaming kernel faster than HBM?  One contiguous weight buffer per
+    # set so that a prefetch kernel can touch exactly the bytes the GEMM streams next.
+    R = 4
+    mask = torch.ones(S, 11, device=dev, dtype=torch.int32)
+    slots = S * 8
+    def make_set():
+        per_gu, per_sh = 2 * Id * D, 2 * Is * D
+        buf = torch.empty(8 * per_gu + 2 * per_sh, device=dev, dtype=torch.bfloat16)
+        g1 = []
+        for e in range(8):
+            w = buf[e * per_gu:(e + 1) * per_gu]
+            w.copy_(ops.pack_gate_up(rnd(Id, D), rnd(Id, D)).view(-1))
+            g1.append(dict(w=w, static_count=S, out_row_base=e * S, n_blocks=2 * Id // 16, k=D))
+        for i in range(2):
+            w = buf[8 * per_gu + i * per_sh: 8 * per_gu + (i + 1) * per_sh]
+            w.copy_(ops.pack_gate_up(rnd(Is, D), rnd(Is, D)).view(-1))
+            g1.append(dict(w=w, static_count=S, out_row_base=slots + i * S, n_blocks=2 * Is // 16, k=D))
+        return buf, ops.GroupTable(g1, dev)
+    sets = [make_set() for _ in range(R)]
+    hbuf = torch.zeros(slots + 2 * S, Id, device=dev, dtype=torch.bfloat16)
+    nbytes = sets[0][0].numel() * 2
+    def gemm(i, pol): ops.grouped_gemm(sets[i][1], x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=8, cache_policy=pol)
+    for pol in (0, 1):
+        t = timeit(lambda i: gemm(i % R, pol))
+        print(f"gate_up dense policy {pol} rotating {R} sets (cold): {t:.2f} us  {nbytes/t/1e3:.0f} GB/s", flush=True)
+        t = timeit(lambda i: gemm(0, pol))
+        print(f"gate_up dense policy {pol} same set (warm): {t:.2f} us  {nbytes/t/1e3:.0f} GB/s", flush=True)
+    for wgs in (256, 512, 1024, 2048):
+        t = timeit(lambda i: ops.prefetch(sets[i % R][0], wgs))
+        print(f"prefetch {nbytes/1e6:.0f} MB with {wgs} workgroups (cold): {t:.2f} us  {nbytes/t/1e3:.0f} GB/s", flush=True)
+    for frac in (0.25, 0.5, 1.0):
+        nb = int(nbytes * frac) // 4096 * 4096
+        for pol in (0, 1):
+            def both(i):
+                ops.prefetch(sets[i % R][0], 1024, nb)
+                gemm(i % R, pol)
+            tb = timeit(both)
+            tp = timeit(lambda i: ops.prefetch(sets[i % R][0], 1024, nb))
+            print(f"prefetch {frac:.2f} of the set then gate_up policy {pol}: pair {tb:.2f} us, prefetch alone {tp:.2f} us -> gate_up {tb - tp:.2f} us", flush=True)
+
 if "router" in which:
     gw = rnd(11, D)
     nw = torch.ones(D, device=dev, dtype=torch.bfloat16)

@@ -51,7 +51,9 @@ eng.start_decode(pre, psteps, 256, 256, cfg_scale=3.0, temperature=1.2, top_p=0.
 trash = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 init = torch.zeros(NL, NK, 16, dtype=torch.int64)
 init[:, :, 0] = (1 << 62)
-init = torch.cat([init.reshape(-1), torch.zeros(8, dtype=torch.int64)]).to(dev)
+tailw = torch.zeros(8, dtype=torch.int64)
+tailw[1] = 2 * B          # combine workgroups per launch (one per row)
+init = torch.cat([init.reshape(-1), tailw]).to(dev)
 for _ in range(4):
     eng.step(True)
 rows = []

@@ -73,6 +73,36 @@ extern "C" int umoe_qkv_mrope_kvappend(const umoe_rope_args* a, umoe_stream_t st
 // out = x*cos + rotate_half(x)*sin with every product and the sum rounded to bf16 (as torch does on bf16 tensors).
 // `own` = the 32 dims, `par` = their rotate_half partners (dims +-64); chunks of 8 dims never straddle an mRoPE section
 // (host checks sec0 % 8 == 0 and (sec0+sec1) % 8 == 0).
+struct rope_regs { uint4 x[4], y[4], c[4], s[4]; };
+__device__ __forceinline__ void rope32_load(const uint16_t* head_raw, int h4, const umoe_attn_args& a, int p0, int p1, int p2,
+                                            rope_regs& r) {
+    const bool first = h4 < 2;
+    const uint16_t* own = head_raw + h4 * 32;
+    const uint16_t* par = head_raw + (first ? h4 * 32 + 64 : h4 * 32 - 64);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int i0 = (h4 & 1) * 32 + kb * 8;  // index into the half-dim cos/sin row
+        const int pos = (i0 < a.sec0) ? p0 : (i0 < a.sec0 + a.sec1 ? p1 : p2);
+        r.x[kb] = ld16(own + kb * 8);
+        r.y[kb] = ld16(par + kb * 8);
+        r.c[kb] = ld16(a.cos_tab + (size_t)pos * 64 + i0);
+        r.s[kb] = ld16(a.sin_tab + (size_t)pos * 64 + i0);
+    }
+}
+__device__ __forceinline__ void rope32_math(const rope_regs& r, int h4, uint4 (&out)[4]) {
+    const bool first = h4 < 2;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        float x[8], y[8], c[8], sn[8], o[8];
+        unpack8(r.x[kb], x);
+        unpack8(r.y[kb], y);
+        unpack8(r.c[kb], c);
+        unpack8(r.s[kb], sn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rbf(x[j] * c[j]) + rbf((first ? -y[j] : y[j]) * sn[j]);
+        out[kb] = pack8(o);
+    }
+}
 __device__ __forceinline__ void rope32(const uint16_t* head_raw, int h4, const umoe_attn_args& a, int p0, int p1, int p2,
                                        uint4 (&out)[4]) {
     const bool first = h4 < 2;
@@ -125,16 +155,40 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
     bf16x8_t qf[4];
     const int QKV_LD = (a.H + 2 * a.KVH) * HD;
     int p0 = 0, p1 = 0, p2 = 0;
+    // first key tile of this wave: requested right behind the rope operands, so the (HBM-cold) K/V rows are in flight
+    // while the rope arithmetic runs (a wave's loads return in issue order: operands first, then the tile)
+    uint4 kfr_first[4];
+    uint32_t vraw_first[16];
+    const int k0_first = kbeg + wave * 16;
+    auto load_tile = [&](uint4 (&kfr)[4], uint32_t (&vraw)[16], const int k0) {
+        // unconditional, clamped into the cache row: a tile past the slice re-reads valid memory and is masked (or never
+        // consumed) -- no branch around the loads, so the compiler can count them and wait for exactly what it needs
+        const int key = max(min(k0 + c, kend - 1), 0);  // A operand row = lane&15 -> key index
+        const uint16_t* kp = Kc + (size_t)key * HD + h4 * 32;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) kfr[kb] = ld16(kp + kb * 8);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            vraw[kk] = *reinterpret_cast<const uint32_t*>(Vc + (size_t)max(min(k0 + kk, kend - 1), 0) * HD + 2 * lane);
+    };
     if (fuse) {
         const int ntok = a.rows * a.nq;
         p0 = a.pos3[qi]; p1 = a.pos3[ntok + qi]; p2 = a.pos3[2 * ntok + qi];
         uint4 u[4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) u[kb] = make_uint4(0, 0, 0, 0);
-        if (c < G) rope32(a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(kvh * G + c) * HD, h4, a, p0, p1, p2, u);
+        // straight-line code (no branch around any load: lanes beyond the group re-read head 0 and are zeroed below), so
+        // the compiler counts the loads and the rope arithmetic waits for its 16 operands only, not for the K/V tile
+        rope_regs rr;
+        rope32_load(a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(kvh * G + (c < G ? c : 0)) * HD, h4, a, p0, p1, p2, rr);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(kfr_first, vraw_first, k0_first);
+        __builtin_amdgcn_sched_barrier(0);
+        rope32_math(rr, h4, u);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) qf[kb] = __builtin_bit_cast(bf16x8_t, u[kb]);
+        for (int kb = 0; kb < 4; ++kb) qf[kb] = __builtin_bit_cast(bf16x8_t, c < G ? u[kb] : make_uint4(0, 0, 0, 0));
     } else {
+        load_tile(kfr_first, vraw_first, k0_first);
         const uint16_t* qp = a.q + ((size_t)qi * a.H + kvh * G + c) * HD + h4 * 32;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -214,21 +268,24 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
         }
         __builtin_amdgcn_wave_barrier();
     };
-    for (int k0 = kbeg + wave * 16; k0 < kend; k0 += 64) {
-        // issue EVERY load of this tile up front: the 4 K fragments and the 16 V rows (2 columns per lane), so the
-        // tile pays one memory latency instead of one per key
-        uint4 kfr[4];
-        {
-            const int key = min(k0 + c, kend - 1);  // A operand row = lane&15 -> key index
-            const uint16_t* kp = Kc + (size_t)key * HD + h4 * 32;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) kfr[kb] = ld16(kp + kb * 8);
+    // two tiles in flight: the next tile is requested before the current one is consumed
+    {
+        int k0 = k0_first;
+        bool have = k0 < kend;
+        while (have) {
+            const int k1 = k0 + 64;
+            const bool nb = k1 < kend;
+            uint4 kB[4];
+            uint32_t vB[16];
+            load_tile(kB, vB, k1);
+            process_tile(kfr_first, vraw_first, k0, kend);
+            if (!nb) break;
+            const int k2 = k1 + 64;
+            have = k2 < kend;
+            load_tile(kfr_first, vraw_first, k2);
+            process_tile(kB, vB, k1, kend);
+            k0 = k2;
         }
-        uint32_t vraw[16];
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
-            vraw[kk] = *reinterpret_cast<const uint32_t*>(Vc + (size_t)min(k0 + kk, kend - 1) * HD + 2 * lane);
-        process_tile(kfr, vraw, k0, kend);
     }
     if (fuse && split == a.splits - 1 && wave == 0) {
         // the new token: K roped from the raw QKV row (lanes c == 0 hold its 4 x 32 dims), V raw; one extra 1-key tile,

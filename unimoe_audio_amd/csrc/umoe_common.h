@@ -34,8 +34,8 @@ void umoe_set_error(const char* fmt, ...);
 // ---- optional in-kernel timeline (diagnostic build only: make tl -> libumoe_hip_tl.so, scripts/timeline.py) -----------
 // slots per kernel id: 0 = min entry over workgroups, 1 = max entry, 2 = max exit, 3.. = marks of workgroup (0,0,0)
 #ifdef UMOE_TIMELINE
-// buffer: [layer][kernel id][16 slots] of u64, then one word counting finished dispatch kernels (= current layer for the
-// kernels before the dispatch, layer + 1 for the ones after it)
+// buffer: [layer][kernel id][16 slots] of u64, then one word counting finished combine workgroups and one word holding
+// the number of workgroups per combine launch
 #define UMOE_TL_CTR (64 * 256)
 static __device__ unsigned long long* g_tl;
 // time stamps stay in registers until the kernel's exit: nothing but s_memrealtime is added to the measured path
@@ -43,8 +43,9 @@ struct tl_state { unsigned long long m[10]; };
 __device__ __forceinline__ void tl_exit(const tl_state& st, int kid) {
     if (threadIdx.x != 0) return;
     const unsigned long long t = wall_clock64();
-    int lay = (int)__atomic_load_n(&g_tl[UMOE_TL_CTR], __ATOMIC_RELAXED);
-    if (kid == 2 || kid == 3 || kid == 9) lay -= 1;
+    // layer = finished combine workgroups / workgroups per combine launch (second word, set by the harness)
+    const int div = (int)g_tl[UMOE_TL_CTR + 1];
+    int lay = (int)__atomic_load_n(&g_tl[UMOE_TL_CTR], __ATOMIC_RELAXED) / (div > 0 ? div : 1);
     lay = lay < 0 ? 0 : (lay > 63 ? 63 : lay);
     const int b = lay * 256 + kid * 16;
     atomicMin(&g_tl[b + 0], st.m[3]);
@@ -54,7 +55,7 @@ __device__ __forceinline__ void tl_exit(const tl_state& st, int kid) {
 #pragma unroll
         for (int k = 3; k < 10; ++k) g_tl[b + k] = st.m[k];
     }
-    if (kid == 6) atomicAdd(&g_tl[UMOE_TL_CTR], 1ull);
+    if (kid == 9) atomicAdd(&g_tl[UMOE_TL_CTR], 1ull);
 }
 #define UMOE_TL_SETTER(name) \
     extern "C" int umoe_tl_set_##name(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &p, sizeof(p)); }

@@ -72,7 +72,7 @@ __device__ __forceinline__ int lds_chunk_off(int QS, int h, int i, int m) {
 struct umoe_group_pack { umoe_group_t g[UMOE_GROUPS_INLINE]; };
 
 template <int NT, int U, int PRO, int EPI, int WV>
-__global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp) {
+__global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     constexpr int KID = EPI == UMOE_EPI_SWIGLU ? 2 : (EPI == UMOE_EPI_F32 ? 4 : (EPI == UMOE_EPI_BF16_RESID ? 1 : (NT == 1 ? 0 : 3)));
@@ -112,7 +112,13 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p, 
             for (int t = 0; t < NT; ++t) dst[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)ii * 64);
         }
     };
-    if (i0 < i1) load_chunk(w0, i0);
+    // Order of requests.  A wave's loads return in issue order, so whatever is requested first is usable first:
+    //  * static groups (dense layers, shared experts, dense-expert decode): the activation rows (and norm weights) are
+    //    requested FIRST, the weight stream right behind them -- the tile is staged while the first chunk is in flight;
+    //  * ragged groups: the activation addresses hang on device-produced tables (count -> offset -> gather list), so the
+    //    weight stream goes first and overlaps that chain.
+    const bool ragged = g.count || g.row_off || g.rows;
+    if (ragged && i0 < i1) load_chunk(w0, i0);
     TL_MARK(KID, 4);
 
     const int count = g.count ? *g.count : g.static_count;
@@ -133,81 +139,75 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p, 
         char* dst = smem + m * RS;
         const int Q8 = KB;       // 16-byte chunks per quarter of the full row
         const int QW = ib - ia;  // chunks per quarter staged by this workgroup
-        if (PRO == UMOE_PRO_RMSNORM && 4 * Q8 <= 16 * TPR && QW == Q8) {
-            // single pass: the row slice lives in registers between the sum of squares and the scaling
-            uint4 buf[16];
+        // thread (m, sub) owns chunks i = sub + TPR*j (j = 0..3) of each K-quarter h per round: 16 loads, no division
+        const bool single = PRO == UMOE_PRO_RMSNORM && QW == Q8 && Q8 <= 4 * TPR;   // whole row in one round
+        float rs = 0.f;
+        if (PRO == UMOE_PRO_RMSNORM && !single) {
             float ss = 0.f;
+            if (valid)
+                for (int c = sub; c < 4 * Q8; c += TPR) {
+                    float f[8];
+                    unpack8(ld16(src + c * 8), f);
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                const int c = sub + TPR * n;
-                buf[n] = make_uint4(0, 0, 0, 0);
-                if (valid && c < 4 * Q8) buf[n] = ld16(src + c * 8);
-            }
-#pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                float f[8];
-                unpack8(buf[n], f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
-            }
+                    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+                }
 #pragma unroll
             for (int o = TPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            const float rs = rsqrtf(ss / (float)K + p.rms_eps);
+            rs = rsqrtf(ss / (float)K + p.rms_eps);
+        }
+        for (int ib0 = 0; ib0 < QW; ib0 += 4 * TPR) {
+            uint4 buf[16];
+            // norm weights: one 16-byte chunk per thread into LDS (behind the tile), read back per chunk below --
+            // 4 registers instead of 64 (single-round RMSNorm only: 4*Q8 <= threads)
+            uint4 nw1 = make_uint4(0, 0, 0, 0);
+            char* nw_lds = smem + 16 * RS;
+            if (single && tid < 4 * Q8) nw1 = ld16(p.norm_w + tid * 8);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
-                const int c = sub + TPR * n;
-                if (c < 4 * Q8) {
+                const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
+                buf[n] = make_uint4(0, 0, 0, 0);
+                if (valid && i < QW) buf[n] = ld16(src + (h * Q8 + ia + i) * 8);
+            }
+            if (ib0 == 0 && !ragged) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (i0 < i1) load_chunk(w0, i0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (single) {
+                float ss = 0.f;
+#pragma unroll
+                for (int n = 0; n < 16; ++n) {
+                    float f[8];
+                    unpack8(buf[n], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+                }
+#pragma unroll
+                for (int o = TPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                rs = rsqrtf(ss / (float)K + p.rms_eps);
+                if (tid < 4 * Q8) st16(nw_lds + tid * 16, nw1);
+                __syncthreads();
+                // keep the row slice packed (64 registers): without this the compiler carries all 128 unpacked floats
+                // from the sum of squares to the scaling and spills beside the in-flight weight chunk
+#pragma unroll
+                for (int n = 0; n < 16; ++n)
+                    asm volatile("" : "+v"(buf[n].x), "+v"(buf[n].y), "+v"(buf[n].z), "+v"(buf[n].w));
+            }
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
+                if (valid && i < QW) {
                     uint4 u = buf[n];
-                    if (valid) {
+                    if (PRO == UMOE_PRO_RMSNORM) {
                         float f[8], w[8];
                         unpack8(u, f);
-                        unpack8(ld16(p.norm_w + c * 8), w);
+                        unpack8(single ? *reinterpret_cast<const uint4*>(nw_lds + (h * Q8 + i) * 16)
+                                       : ld16(p.norm_w + (h * Q8 + ia + i) * 8), w);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
                         u = pack8(f);
                     }
-                    const int h = c / Q8, i = c - h * Q8;
                     st16(dst + lds_chunk_off(QS, h, i, m), u);
-                }
-            }
-        } else {
-            float rs = 0.f;
-            if (PRO == UMOE_PRO_RMSNORM) {
-                float ss = 0.f;
-                if (valid)
-                    for (int c = sub; c < 4 * Q8; c += TPR) {
-                        float f[8];
-                        unpack8(ld16(src + c * 8), f);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
-                    }
-#pragma unroll
-                for (int o = TPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-                rs = rsqrtf(ss / (float)K + p.rms_eps);
-            }
-            // rounds of 16 loads per thread (4 per K-quarter); one round covers K <= 128 * TPR
-            for (int ib0 = 0; ib0 < QW; ib0 += 4 * TPR) {
-                uint4 buf[16];
-#pragma unroll
-                for (int n = 0; n < 16; ++n) {
-                    const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
-                    if (valid && i < QW) buf[n] = ld16(src + (h * Q8 + ia + i) * 8);
-                }
-#pragma unroll
-                for (int n = 0; n < 16; ++n) {
-                    const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
-                    if (valid && i < QW) {
-                        uint4 u = buf[n];
-                        if (PRO == UMOE_PRO_RMSNORM) {
-                            float f[8], w[8];
-                            unpack8(u, f);
-                            unpack8(ld16(p.norm_w + (h * Q8 + ia + i) * 8), w);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
-                            u = pack8(f);
-                        }
-                        st16(dst + lds_chunk_off(QS, h, i, m), u);
-                    }
                 }
             }
         }
@@ -346,18 +346,18 @@ __global__ __launch_bounds__(WV * 64) void wstream_gemm(const umoe_gemm_args p, 
 
 UMOE_TL_SETTER(gemm)
 // ------------------------------------------------------------------------------------ launcher
-static size_t gemm_lds_bytes(int max_k, int NT, int WV, int ksplit) {
+static size_t gemm_lds_bytes(int max_k, int NT, int WV, int ksplit, int pro = UMOE_PRO_PLAIN) {
     const int KB = max_k >> 5;
     const int per = (KB + ksplit - 1) / ksplit;   // k-steps of the largest K-slice
     const size_t QS = (size_t)((per * 16 + 255) & ~255);
-    const size_t a = 16 * 4 * QS, red = (size_t)WV * NT * 64 * 16;
+    const size_t a = 16 * 4 * QS + (pro == UMOE_PRO_RMSNORM ? (size_t)max_k * 2 : 0), red = (size_t)WV * NT * 64 * 16;
     return a > red ? a : red;
 }
 
 template <int NT, int U, int PRO, int EPI, int WV = 4>
 static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
     const int ksplit = a->ksplit > 1 ? a->ksplit : 1;
-    const size_t lds = gemm_lds_bytes(a->max_k, NT, WV, ksplit);
+    const size_t lds = gemm_lds_bytes(a->max_k, NT, WV, ksplit, PRO);
     UMOE_REQUIRE(lds <= 160 * 1024, "umoe_grouped_gemm: K=%d needs %zu bytes of LDS (> 160 KiB)", a->max_k, lds);
     static size_t configured = 0;  // per instantiation
     if (lds > configured) {

@@ -361,12 +361,99 @@ __global__ __launch_bounds__(256) void router_kernel(const umoe_router_args a) {
 }
 UMOE_TL_SETTER(router)
 
+// Decode shapes (S <= 256, D = 2048 or 4096): one 256-thread workgroup per token.  The four waves split the RMSNorm and
+// the gate GEMV over D (13 loads per lane instead of 52, a quarter of the VALU work each), partial sums meet in LDS in
+// fixed order, wave 0 then walks the serial routing chain.
+template <int ND, int NF, int TB>
+__global__ __launch_bounds__(256) void router_kernel4(const umoe_router_args a) {
+    constexpr int NEc = ND + NF;
+    constexpr int T = TB;
+    __shared__ float ss_part[4];
+    __shared__ float lg_part[4][UMOE_MAXE];
+    TL_ENTER(5);
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = a.D >> 11;  // 16-byte chunks per lane: 1 or 2
+    const uint16_t* xr = a.x + (size_t)s * a.D;
+    uint4 xv[2], nw[2], gwv[NEc][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+        if (n < nch) {
+            const int c = (n * 4 + wave) * 64 + lane;
+            xv[n] = ld16(xr + c * 8);
+            if (a.norm_w) nw[n] = ld16(a.norm_w + c * 8);
+#pragma unroll
+            for (int e = 0; e < NEc; ++e) gwv[e][n] = ld16(a.gate_w + (size_t)e * a.D + c * 8);
+        }
+    TL_MARK(5, 4);
+    float rs = 1.f;
+    if (a.norm_w) {
+        float ss = 0.f;
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            if (n < nch) {
+                float f[8];
+                unpack8(xv[n], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+            }
+        ss = wave_sum(ss);
+        if (lane == 0) ss_part[wave] = ss;
+        __syncthreads();
+        ss = ((ss_part[0] + ss_part[1]) + ss_part[2]) + ss_part[3];
+        rs = rsqrtf(ss / (float)a.D + a.rms_eps);
+    }
+    TL_MARK(5, 5);
+    float acc[UMOE_MAXE];
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+        if (n < nch) {
+            const int c = (n * 4 + wave) * 64 + lane;
+            float f[8];
+            unpack8(xv[n], f);
+            if (a.norm_w) {
+                float w[8];
+                unpack8(nw[n], w);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = rbf(w[j] * rbf(f[j] * rs));
+                xv[n] = pack8(f);
+            }
+            if (a.h_out) st16(a.h_out + (size_t)s * a.D + c * 8, xv[n]);
+#pragma unroll
+            for (int e = 0; e < NEc; ++e) {
+                float w[8];
+                unpack8(gwv[e][n], w);
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += f[j] * w[j];
+                acc[e] += d;
+            }
+        }
+    const float mine = reduce16_to_lanes(acc, lane);
+    if (lane < UMOE_MAXE) lg_part[wave][lane] = mine;
+    __syncthreads();
+    if (wave != 0) return;
+    float full = -INFINITY;
+    if (lane < NEc) full = round_t(((lg_part[0][lane] + lg_part[1][lane]) + lg_part[2][lane]) + lg_part[3][lane], T);
+    TL_MARK(5, 6);
+    route_from_logits<ND, NF, TB>(a, s, lane, full TL_PASS);
+    TL_EXIT(5);
+}
+
 extern "C" int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 extern "C" int umoe_dispatch_build(const int32_t*, int, int, int, int32_t*, int32_t*, int32_t*, int32_t*, umoe_stream_t);
 
 template <int ND, int NF>
 static void launch_router(const umoe_router_args* a, dim3 grid, hipStream_t st) {
     (void)grid;
+    if constexpr (ND > 0) {
+        if (a->S <= 256 && !a->logits_in && (a->D == 2048 || a->D == 4096)) {
+            if (a->logits_bf16) router_kernel4<ND, NF, 1><<<dim3((unsigned)a->S), 256, 0, st>>>(*a);
+            else router_kernel4<ND, NF, 0><<<dim3((unsigned)a->S), 256, 0, st>>>(*a);
+            return;
+        }
+    }
     // few tokens (decode): one wave per workgroup so every token's serial routing chain owns a SIMD on its own CU
     const unsigned threads = a->S <= 256 ? 64u : 256u;
     grid = dim3((unsigned)ceil_div(a->S, (int)(threads / 64)));

@@ -175,12 +175,13 @@ class GroupTable:
 
 
 def grouped_gemm(table: GroupTable, a: torch.Tensor, out: torch.Tensor, *, max_rows: int, prologue=PRO_PLAIN,
-                 epilogue=EPI_BF16, norm_w=None, rms_eps=1e-6, resid=None, n_valid=None, nt=0, waves=0, ksplit=0, part_stride=0):
+                 epilogue=EPI_BF16, norm_w=None, rms_eps=1e-6, resid=None, n_valid=None, nt=0, waves=0, ksplit=0, part_stride=0,
+                 cache_policy=0):
     args = L.GemmArgs(groups=_p(table.dev), num_groups=table.n, max_rows=max_rows, max_n_blocks=table.max_n_blocks,
                       max_k=table.max_k, a=_p(a), lda=a.stride(0), norm_w=_p(norm_w), rms_eps=rms_eps, resid=_p(resid),
                       out=_p(out), ldo=out.stride(-2), n_valid=out.shape[1] if n_valid is None else n_valid,
                       prologue=prologue, epilogue=epilogue, nt=nt, waves=waves, ksplit=ksplit, part_stride=part_stride,
-                      groups_host=C.cast(table.host, C.c_void_p))
+                      groups_host=C.cast(table.host, C.c_void_p), cache_policy=cache_policy)
     L.check(L.lib().umoe_grouped_gemm(C.byref(args), _stream()), "umoe_grouped_gemm")
     return out
 
@@ -322,3 +323,9 @@ def codec_ce(logits: torch.Tensor, labels: torch.Tensor, want_grad: bool = False
     dl = torch.empty_like(probs)
     L.check(L.lib().umoe_codec_ce_bwd(_p(probs), _p(lab), _p(ch_cnt), N, Cc, V, 1.0, _p(dl), _stream()), "umoe_codec_ce_bwd")
     return total[0], ch_loss, ch_cnt, dl
+
+
+def prefetch(t: torch.Tensor, wgs: int = 256, nbytes: Optional[int] = None):
+    """Warm the Infinity Cache with the bytes of `t` (plain loads, nothing stored)."""
+    n = t.numel() * t.element_size() if nbytes is None else nbytes
+    L.check(L.lib().umoe_prefetch(_p(t), n, wgs, _stream()), "umoe_prefetch")
