@@ -157,6 +157,38 @@ typedef struct {
 int umoe_prefetch(const void* p, size_t bytes, int wgs, umoe_stream_t stream);
 int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream);
 
+/* ------------------------------------------------------------------ tiled MFMA GEMM (prefill / training shapes)
+ * Y[rows(g), N(g)] = epilogue( A[rows(g), K] * W_g^T ) with W_g ROW-MAJOR [N][K] bf16 (the reference's nn.Linear layout,
+ * core.py:21-28,39-46; no packing: training updates these tensors every step).  Compute-bound counterpart of
+ * umoe_grouped_gemm: 128x128x64 tiles through LDS, v_mfma_f32_16x16x32_bf16, fp32 accumulation, the same ragged-group
+ * conventions (gather list / device-side count and offset) and the same rounding points in the epilogues.
+ * UMOE_EPI_SWIGLU takes gate rows from `w` and up rows from `w2` (N = intermediate size). */
+typedef struct {
+    const uint16_t* w;        /* [N][ldw] row-major */
+    const uint16_t* w2;       /* SwiGLU only: up_proj [N][ldw] */
+    const float* bias;        /* optional [N] fp32 */
+    const int32_t* rows;      /* optional gather list; NULL = identity */
+    const int32_t* row_off;   /* optional device scalar added to the row number */
+    const int32_t* count;     /* optional device scalar: rows of this group; NULL => static_count */
+    int static_count;
+    int a_row_base, out_row_base;
+    int n, k, ldw;            /* output features, contraction length (k % 8 == 0), elements between weight rows */
+    int a_col_off;
+} umoe_tgroup_t;
+
+typedef struct {
+    const umoe_tgroup_t* groups;  /* HOST array (descriptors travel in the kernel arguments), num_groups <= 12 */
+    int num_groups;
+    int max_rows;             /* upper bound of rows in any group (grid sizing) */
+    const uint16_t* a;        /* [*, lda] bf16 */
+    int lda;
+    const uint16_t* resid;    /* UMOE_EPI_BF16_RESID: [*, ldo] */
+    void* out;                /* bf16 (or fp32 for UMOE_EPI_F32 / _RAW) [*, ldo] */
+    int ldo;
+    int epilogue;             /* UMOE_EPI_* */
+} umoe_tgemm_args;
+int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream);
+
 /* Named wrappers required by the scope table; thin calls of umoe_grouped_gemm.
  * umoe_grouped_swiglu_fwd: routed experts, core.py:406-416 + :34-49 on ragged rows.
  * umoe_shared_swiglu_fwd : shared experts, core.py:344-351 + :16-31. */

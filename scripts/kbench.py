@@ -126,6 +126,30 @@ if "mall" in which:
             tp = timeit(lambda i: ops.prefetch(sets[i % R][0], 1024, nb))
             print(f"prefetch {frac:.2f} of the set then gate_up policy {pol}: pair {tb:.2f} us, prefetch alone {tp:.2f} us -> gate_up {tb - tp:.2f} us", flush=True)
 
+if "tiled" in which:
+    # compute-bound shapes: prefill (4800 tokens) and training (6240 tokens) through umoe_tiled_gemm
+    for M in (4800, 6240):
+        xa = rnd(M, D) * 50
+        for name, N, K in (("qkv", 2560, D), ("o_proj", D, D), ("head", 12324, D)):
+            w = rnd(N, K)
+            xin = rnd(M, K)
+            t = timeit(lambda i: ops.tlinear(xin, w), iters=20)
+            print(f"tiled {name} M={M} N={N} K={K}: {t:.1f} us  {2*M*N*K/t/1e6:.0f} TFLOP/s", flush=True)
+        wg, wu, wd = rnd(Id, D), rnd(Id, D), rnd(D, Id)
+        hb = torch.empty(M, Id, device=dev, dtype=torch.bfloat16)
+        yb = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda i: ops.tiled_gemm([dict(w=wg, w2=wu, static_count=M)], xa, hb, max_rows=M, epilogue=ops.EPI_SWIGLU), iters=20)
+        print(f"tiled gate/up SwiGLU M={M}: {t:.1f} us  {4*M*Id*D/t/1e6:.0f} TFLOP/s", flush=True)
+        t = timeit(lambda i: ops.tiled_gemm([dict(w=wd, static_count=M)], hb, yb, max_rows=M, epilogue=ops.EPI_BF16), iters=20)
+        print(f"tiled down M={M}: {t:.1f} us  {2*M*Id*D/t/1e6:.0f} TFLOP/s", flush=True)
+        xin = rnd(M, D)
+        w = rnd(2560, D)
+        t = timeit(lambda i: torch.nn.functional.linear(xin, w), iters=20)
+        print(f"torch (hipBLASLt) qkv M={M}: {t:.1f} us  {2*M*2560*D/t/1e6:.0f} TFLOP/s", flush=True)
+        wp = ops.pack_weight(w)
+        t = timeit(lambda i: ops.linear(xin, wp, 2560), iters=5)
+        print(f"weight-streaming qkv M={M}: {t:.1f} us  {2*M*2560*D/t/1e6:.0f} TFLOP/s", flush=True)
+
 if "router" in which:
     gw = rnd(11, D)
     nw = torch.ones(D, device=dev, dtype=torch.bfloat16)

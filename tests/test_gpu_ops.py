@@ -36,6 +36,71 @@ def _ref_linear(x, w, bias=None):
 
 
 # ----------------------------------------------------------------------------- GEMM family
+@pytest.mark.parametrize("S,K,N", [(300, 2048, 2560), (129, 2752, 2048), (128, 1376, 2048), (1, 64, 8), (257, 72, 130),
+                                   (640, 2048, 12324)])
+def test_tiled_gemm_plain_bias_resid_f32(dev, S, K, N):
+    """umoe_tiled_gemm (row-major weights, 128x128x64 MFMA tiles) against an fp32 torch reference with the reference's
+    rounding points: Linear output rounded to bf16, then bias-free residual add rounded again."""
+    from unimoe_audio_amd import ops
+    g = torch.Generator().manual_seed(S * 7 + K + N)
+    x = (torch.randn(S, K, generator=g) * 1.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16)
+    b = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(S, N, generator=g).to(torch.bfloat16)
+    xd, wd, bd, rd = x.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    ref = _ref_linear(x, w, b)
+    y = ops.tlinear(xd, wd, bias=bd).cpu()
+    torch.testing.assert_close(y.float(), ref.to(torch.bfloat16).float(), **BF16_TOL)
+    y2 = ops.tlinear(xd, wd, resid=rd).cpu()
+    ref2 = (r.float() + _ref_linear(x, w).to(torch.bfloat16).float()).to(torch.bfloat16)
+    # a 1-ulp flip of the rounded Linear output survives the residual add unscaled: bound it by the ulp of the addends
+    lin = _ref_linear(x, w)
+    assert (y2.float() - ref2.float()).abs().max() <= 2 ** -7 * max(float(lin.abs().max()), float(r.float().abs().max()))
+    assert ((y2.float() - ref2.float()).abs() > 2 ** -8 * (1 + ref2.float().abs())).float().mean() < 1e-3
+    y3 = ops.tlinear(xd, wd, out_f32=True).cpu()
+    torch.testing.assert_close(y3, _ref_linear(x, w).to(torch.bfloat16).float(), **BF16_TOL)
+    # same numbers as the weight-streaming kernel up to accumulation order (both round the fp32 sum once)
+    if K % 32 == 0 and S <= 300:
+        y4 = ops.linear(xd, ops.pack_weight(wd), N, bias=bd).cpu()
+        assert (y4.float() - y.float()).abs().max() <= 2 ** -6 * ref.abs().max()
+
+
+def test_tiled_gemm_ragged_swiglu_groups(dev):
+    """Routed experts at training-like sizes: ragged row lists (device-side counts / offsets / gather list), SwiGLU
+    epilogue from separate gate/up matrices, then the down projection over the slot rows; oracle = oracle.dcmoe.swiglu_mlp."""
+    from unimoe_audio_amd import ops
+    from oracle import dcmoe as OD
+    g = torch.Generator().manual_seed(5)
+    S, D, I, E = 700, 256, 352, 4
+    x = torch.randn(S, D, generator=g).to(torch.bfloat16)
+    mask = (torch.rand(S, E + 3, generator=g) < 0.4).to(torch.int32)
+    mask[:, 2] = 0                                   # an expert nobody chose
+    wg = [(torch.randn(I, D, generator=g) * 0.06).to(torch.bfloat16) for _ in range(E)]
+    wu = [(torch.randn(I, D, generator=g) * 0.06).to(torch.bfloat16) for _ in range(E)]
+    wd = [(torch.randn(D, I, generator=g) * 0.06).to(torch.bfloat16) for _ in range(E)]
+    xd = x.to(dev)
+    disp = ops.dispatch_build(mask.to(dev), E)
+    slots = int(disp["offsets"][E].item())
+    hbuf = torch.zeros(slots, I, dtype=torch.bfloat16, device=dev)
+    ybuf = torch.zeros(slots, D, dtype=torch.bfloat16, device=dev)
+    g1 = [dict(w=wg[e].to(dev), w2=wu[e].to(dev), rows=disp["slot_token"], row_off=disp["offsets"][e:e + 1], count=disp["counts"][e:e + 1])
+          for e in range(E)]
+    g2 = [dict(w=wd[e].to(dev), row_off=disp["offsets"][e:e + 1], count=disp["counts"][e:e + 1]) for e in range(E)]
+    ops.tiled_gemm(g1, xd, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU)
+    ops.tiled_gemm(g2, hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16)
+    st, off, cnt = disp["slot_token"].cpu(), disp["offsets"].cpu(), disp["counts"].cpu()
+    assert int(cnt[2]) == 0
+    for e in range(E):
+        rows = st[int(off[e]): int(off[e]) + int(cnt[e])].long()
+        assert torch.equal(rows, torch.nonzero(mask[:, e]).flatten())          # token order preserved
+        if rows.numel() == 0:
+            continue
+        ref = OD.swiglu_mlp(x[rows], wg[e], wu[e], wd[e])
+        got = ybuf[int(off[e]): int(off[e]) + int(cnt[e])].cpu()
+        err = (got.float() - ref.float()).norm() / ref.float().norm()
+        assert err < 2 ** -7, (e, float(err))
+
+
 @pytest.mark.parametrize("S,K,N", [(16, 2048, 2560), (5, 2048, 2048), (40, 2752, 2048), (16, 1376, 2048),
                                    (16, 2048, 12324), (16, 64, 96), (3, 96, 64), (33, 128, 48)])
 def test_linear_plain_bias_resid(dev, S, K, N):

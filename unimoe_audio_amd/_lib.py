@@ -50,6 +50,16 @@ class GemmArgs(C.Structure):
                 ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32), ("waves", i32), ("ksplit", i32), ("part_stride", C.c_long), ("groups_host", vp), ("cache_policy", i32)]
 
 
+class TGroup(C.Structure):
+    _fields_ = [("w", vp), ("w2", vp), ("bias", vp), ("rows", vp), ("row_off", vp), ("count", vp), ("static_count", i32),
+                ("a_row_base", i32), ("out_row_base", i32), ("n", i32), ("k", i32), ("ldw", i32), ("a_col_off", i32)]
+
+
+class TGemmArgs(C.Structure):
+    _fields_ = [("groups", vp), ("num_groups", i32), ("max_rows", i32), ("a", vp), ("lda", i32), ("resid", vp), ("out", vp),
+                ("ldo", i32), ("epilogue", i32)]
+
+
 class CombineArgs(C.Structure):
     _fields_ = [("y_slots", vp), ("slot_of", vp), ("moe_w", vp), ("y_shared", vp), ("global_w", vp), ("resid", vp),
                 ("out", vp), ("S", i32), ("D", i32), ("n_real", i32), ("n_dyn", i32), ("n_fix", i32), ("y_parts", vp), ("n_parts", i32), ("part_stride", C.c_long),
@@ -102,7 +112,7 @@ EXPORTS = [
     "umoe_codec_embed_sum", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_codec_ce_fwd", "umoe_codec_ce_bwd", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
     "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
-    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch",
+    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm",
 ]
 
 

@@ -329,3 +329,35 @@ def prefetch(t: torch.Tensor, wgs: int = 256, nbytes: Optional[int] = None):
     """Warm the Infinity Cache with the bytes of `t` (plain loads, nothing stored)."""
     n = t.numel() * t.element_size() if nbytes is None else nbytes
     L.check(L.lib().umoe_prefetch(_p(t), n, wgs, _stream()), "umoe_prefetch")
+
+
+def tiled_gemm(groups: Sequence[dict], a: torch.Tensor, out: torch.Tensor, *, max_rows: int, epilogue=EPI_BF16, resid=None):
+    """Compute-bound grouped GEMM on ROW-MAJOR weights (umoe_tiled_gemm): each group dict has w [N, K] (and w2 for SwiGLU),
+    optional bias / rows / row_off / count tensors and static_count / a_row_base / out_row_base ints."""
+    arr = (L.TGroup * len(groups))()
+    keep = []
+    for i, g in enumerate(groups):
+        w = g["w"]
+        assert w.dim() == 2 and w.stride(1) == 1
+        for k in ("w", "w2", "bias", "rows", "row_off", "count"):
+            t = g.get(k)
+            if t is not None:
+                keep.append(t)
+                setattr(arr[i], k, t.data_ptr())
+        arr[i].static_count = int(g.get("static_count", 0))
+        arr[i].a_row_base = int(g.get("a_row_base", 0))
+        arr[i].out_row_base = int(g.get("out_row_base", 0))
+        arr[i].n, arr[i].k, arr[i].ldw = int(w.shape[0]), int(g.get("k", w.shape[1])), int(w.stride(0))
+        arr[i].a_col_off = int(g.get("a_col_off", 0))
+    args = L.TGemmArgs(groups=C.cast(arr, C.c_void_p), num_groups=len(groups), max_rows=max_rows, a=_p(a), lda=a.stride(0),
+                       resid=_p(resid), out=_p(out), ldo=out.stride(-2), epilogue=epilogue)
+    L.check(L.lib().umoe_tiled_gemm(C.byref(args), _stream()), "umoe_tiled_gemm")
+    return out
+
+
+def tlinear(x: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, resid=None, out_f32=False) -> torch.Tensor:
+    """y = x @ w^T (+bias) (+resid) with row-major w [N, K]: the tiled MFMA path for many rows."""
+    S = x.shape[0]
+    out = torch.empty((S, w.shape[0]), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    epi = EPI_F32 if out_f32 else (EPI_BF16_RESID if resid is not None else EPI_BF16)
+    return tiled_gemm([dict(w=w, bias=bias, static_count=S)], x, out, max_rows=S, epilogue=epi, resid=resid)
