@@ -359,6 +359,16 @@ typedef struct {
     const uint16_t* const* exp_dn; /* host array [n_real]: WP16 down */
     const uint16_t* const* sh_gu;  /* host array [n_fix] */
     const uint16_t* const* sh_dn;  /* host array [n_fix] */
+    /* optional ROW-MAJOR copies (the reference's own nn.Linear tensors) for the tiled MFMA path of the prefill; all or none.
+     * rm_qkv = cat(q,k,v) [QKV][D], rm_o [D][H*hd]; per expert gate/up [I][D] and down [D][I]. */
+    const uint16_t* rm_qkv;
+    const uint16_t* rm_o;
+    const uint16_t* const* rm_exp_gate;  /* host arrays [n_real] */
+    const uint16_t* const* rm_exp_up;
+    const uint16_t* const* rm_exp_down;
+    const uint16_t* const* rm_sh_gate;   /* host arrays [n_fix] */
+    const uint16_t* const* rm_sh_up;
+    const uint16_t* const* rm_sh_down;
 } umoe_layer_weights;
 
 typedef struct umoe_engine umoe_engine;

@@ -97,7 +97,10 @@ class EngineCfg(C.Structure):
 
 class LayerWeights(C.Structure):
     _fields_ = [("in_norm", vp), ("qkv_w", vp), ("qkv_b", vp), ("o_w", vp), ("post_norm", vp), ("gate_w", vp),
-                ("exp_gu", C.POINTER(vp)), ("exp_dn", C.POINTER(vp)), ("sh_gu", C.POINTER(vp)), ("sh_dn", C.POINTER(vp))]
+                ("exp_gu", C.POINTER(vp)), ("exp_dn", C.POINTER(vp)), ("sh_gu", C.POINTER(vp)), ("sh_dn", C.POINTER(vp)),
+                ("rm_qkv", vp), ("rm_o", vp), ("rm_exp_gate", C.POINTER(vp)), ("rm_exp_up", C.POINTER(vp)),
+                ("rm_exp_down", C.POINTER(vp)), ("rm_sh_gate", C.POINTER(vp)), ("rm_sh_up", C.POINTER(vp)),
+                ("rm_sh_down", C.POINTER(vp))]
 
 
 class DecodeIO(C.Structure):

@@ -18,6 +18,8 @@ namespace {
 struct LayerDev {
     umoe_layer_weights w;
     std::vector<const uint16_t*> exp_gu, exp_dn, sh_gu, sh_dn;
+    std::vector<const uint16_t*> rm_eg, rm_eu, rm_ed, rm_sg, rm_su, rm_sd;   // row-major copies (tiled prefill path)
+    bool has_rm = false;
     bool set = false;
 };
 
@@ -74,6 +76,7 @@ struct umoe_engine {
     // decode with >= 6 rows: every routed expert is hit with probability ~1, so each expert computes ALL rows (no gather
     // lists, no dispatch kernel, no device-produced row counts in the GEMM prologues) and the combine selects by mask
     bool dense_experts = true;
+    bool tiled_prefill = true;   // UMOE_TILED_PREFILL=0: weight-streaming kernels for every row count (A/B, tests)
     bool overlap_shared = false;  // measured on MI355X: 1429 vs 1825 tok/s -- cross-stream graph edges cost more than they hide
     // optional per-kernel-class timing of one eager step (hipEvents on the launch stream)
     bool prof = false;
@@ -233,6 +236,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     }
     if (const char* v = getenv("UMOE_OVERLAP_SHARED")) e->overlap_shared = atoi(v) != 0;
     if (const char* v = getenv("UMOE_DENSE_EXPERTS")) e->dense_experts = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_TILED_PREFILL")) e->tiled_prefill = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -261,6 +265,18 @@ extern "C" int umoe_engine_set_layer(umoe_engine* e, int layer, const umoe_layer
     L.exp_dn.assign(w->exp_dn, w->exp_dn + e->c.n_real);
     L.sh_gu.assign(w->sh_gu, w->sh_gu + e->c.n_fix);
     L.sh_dn.assign(w->sh_dn, w->sh_dn + e->c.n_fix);
+    L.has_rm = w->rm_qkv && w->rm_o && w->rm_exp_gate && w->rm_exp_up && w->rm_exp_down &&
+               (e->c.n_fix == 0 || (w->rm_sh_gate && w->rm_sh_up && w->rm_sh_down));
+    if (L.has_rm) {
+        L.rm_eg.assign(w->rm_exp_gate, w->rm_exp_gate + e->c.n_real);
+        L.rm_eu.assign(w->rm_exp_up, w->rm_exp_up + e->c.n_real);
+        L.rm_ed.assign(w->rm_exp_down, w->rm_exp_down + e->c.n_real);
+        if (e->c.n_fix) {
+            L.rm_sg.assign(w->rm_sh_gate, w->rm_sh_gate + e->c.n_fix);
+            L.rm_su.assign(w->rm_sh_up, w->rm_sh_up + e->c.n_fix);
+            L.rm_sd.assign(w->rm_sh_down, w->rm_sh_down + e->c.n_fix);
+        }
+    }
     L.set = true;
     e->groups_for_tok = -1;
     return 0;
@@ -316,7 +332,19 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     a.a = e->hin; a.lda = D; a.out = e->qkv; a.ldo = QKV; a.n_valid = QKV;   // hin = RMSNorm(x) from the previous combine
     a.prologue = UMOE_PRO_PLAIN; a.epilogue = UMOE_EPI_BF16;
     PROF(-1);
-    if ((rc = umoe_grouped_gemm(&a, s))) return rc;
+    // many rows (prefill): the compute-bound tiled MFMA kernel on the row-major weights; decode: weight streaming
+    const bool tiled = L.has_rm && n_tok >= 64 && e->tiled_prefill;
+    if (tiled) {
+        umoe_tgroup_t tg{};
+        tg.w = L.w.rm_qkv; tg.bias = L.w.qkv_b; tg.static_count = n_tok; tg.n = QKV; tg.k = D; tg.ldw = D;
+        umoe_tgemm_args ta{};
+        ta.groups = &tg; ta.num_groups = 1; ta.max_rows = n_tok; ta.a = e->hin; ta.lda = D; ta.out = e->qkv; ta.ldo = QKV;
+        ta.epilogue = UMOE_EPI_BF16;
+        rc = umoe_tiled_gemm(&ta, s);
+    } else {
+        rc = umoe_grouped_gemm(&a, s);
+    }
+    if (rc) return rc;
     PROF(K_QKV);
     // 2. mRoPE + KV append
     umoe_rope_args r{};
@@ -345,7 +373,17 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     o.groups = g + 1; o.groups_host = gh + 1; o.num_groups = 1; o.max_rows = n_tok; o.max_n_blocks = D / 16; o.max_k = HD;
     o.a = e->attn_out; o.lda = HD; o.resid = e->x; o.out = e->x1; o.ldo = D; o.n_valid = D;
     o.prologue = UMOE_PRO_PLAIN; o.epilogue = UMOE_EPI_BF16_RESID;
-    if ((rc = umoe_grouped_gemm(&o, s))) return rc;
+    if (tiled) {
+        umoe_tgroup_t tg{};
+        tg.w = L.w.rm_o; tg.static_count = n_tok; tg.n = D; tg.k = HD; tg.ldw = HD;
+        umoe_tgemm_args ta{};
+        ta.groups = &tg; ta.num_groups = 1; ta.max_rows = n_tok; ta.a = e->attn_out; ta.lda = HD; ta.resid = e->x; ta.out = e->x1;
+        ta.ldo = D; ta.epilogue = UMOE_EPI_BF16_RESID;
+        rc = umoe_tiled_gemm(&ta, s);
+    } else {
+        rc = umoe_grouped_gemm(&o, s);
+    }
+    if (rc) return rc;
     PROF(K_OPROJ);
     if (e->overlap_shared && c.n_fix > 0) {   // fork: shared experts on s2 (x1 -> RMSNorm -> SwiGLU -> down)
         UMOE_HIP(hipEventRecord(e->ev_fork, s));
@@ -390,14 +428,51 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // (dense mode with the post-attention RMSNorm in this launch's staging prologue, so that it would not wait for the
     //  router at all, was measured: 46.9 vs 37.7 us per launch -- 387 workgroups redoing the norm of all 16 rows costs
     //  more than the dependency it removes; the router kernel writes the normalised rows h2 once instead)
-    if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
+    if (tiled && !ov && G <= 12) {
+        umoe_tgroup_t tg[12];
+        memset(tg, 0, sizeof(tg));
+        for (int x = 0; x < G; ++x) {
+            const umoe_group_t& src = gh[2 + x];     // same row tables as the weight-streaming groups
+            const bool sh = x >= c.n_real;
+            tg[x].w = sh ? L.rm_sg[x - c.n_real] : L.rm_eg[x];
+            tg[x].w2 = sh ? L.rm_su[x - c.n_real] : L.rm_eu[x];
+            tg[x].rows = src.rows; tg[x].row_off = src.row_off; tg[x].count = src.count; tg[x].static_count = src.static_count;
+            tg[x].a_row_base = src.a_row_base; tg[x].out_row_base = src.out_row_base;
+            tg[x].n = sh ? c.inter_shared : c.inter_dyn; tg[x].k = D; tg[x].ldw = D;
+        }
+        umoe_tgemm_args ta{};
+        ta.groups = tg; ta.num_groups = G; ta.max_rows = n_tok; ta.a = e->h2; ta.lda = D; ta.out = e->hbuf; ta.ldo = Imax;
+        ta.epilogue = UMOE_EPI_SWIGLU;
+        rc = umoe_tiled_gemm(&ta, s);
+    } else {
+        rc = umoe_grouped_gemm(&gu, s);
+    }
+    if (rc) return rc;
     PROF(K_GATEUP);
     umoe_gemm_args dn{};
     dn.groups = g + 2 + G; dn.groups_host = gh + 2 + G; dn.num_groups = ov ? c.n_real : G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16;
     dn.max_k = ov ? c.inter_dyn : Imax;
     dn.a = e->hbuf; dn.lda = Imax; dn.out = e->ybuf; dn.ldo = D; dn.n_valid = D;
     dn.prologue = UMOE_PRO_PLAIN; dn.epilogue = UMOE_EPI_BF16;
-    if ((rc = umoe_grouped_gemm(&dn, s))) return rc;
+    if (tiled && !ov && G <= 12) {
+        umoe_tgroup_t tg[12];
+        memset(tg, 0, sizeof(tg));
+        for (int x = 0; x < G; ++x) {
+            const umoe_group_t& src = gh[2 + G + x];
+            const bool sh = x >= c.n_real;
+            tg[x].w = sh ? L.rm_sd[x - c.n_real] : L.rm_ed[x];
+            tg[x].row_off = src.row_off; tg[x].count = src.count; tg[x].static_count = src.static_count;
+            tg[x].a_row_base = src.a_row_base; tg[x].out_row_base = src.out_row_base;
+            tg[x].n = D; tg[x].k = sh ? c.inter_shared : c.inter_dyn; tg[x].ldw = tg[x].k;
+        }
+        umoe_tgemm_args ta{};
+        ta.groups = tg; ta.num_groups = G; ta.max_rows = n_tok; ta.a = e->hbuf; ta.lda = Imax; ta.out = e->ybuf; ta.ldo = D;
+        ta.epilogue = UMOE_EPI_BF16;
+        rc = umoe_tiled_gemm(&ta, s);
+    } else {
+        rc = umoe_grouped_gemm(&dn, s);
+    }
+    if (rc) return rc;
     PROF(K_DOWN);
     if (ov) UMOE_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
     // 9. combine + residual -> next layer input                   core.py:488,342-351; model.py:242

@@ -95,6 +95,9 @@ class UniMoEAudioMoE(nn.Module):
         self.deepspeed_moe._set_ep_group(ep_group)
 
 
+TILED_MIN_ROWS = 64      # from this many rows on the expert GEMMs are compute-bound: umoe_tiled_gemm
+
+
 class UniMoEAudioSparseMoeBlock(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -197,8 +200,25 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
                                       n_blocks=D // 16, k=I_s))
             hbuf = torch.empty((slots + n_fix * S, Imax), dtype=torch.bfloat16, device=x.device)
             ybuf = torch.empty((slots + n_fix * S, D), dtype=torch.bfloat16, device=x.device)
-            ops.grouped_gemm(ops.GroupTable(groups_gu, x.device), x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Imax)
-            ops.grouped_gemm(ops.GroupTable(groups_dn, x.device), hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D)
+            if S >= TILED_MIN_ROWS and n_real + n_fix <= 12:
+                # many rows (prefill / training shapes): compute-bound tiled MFMA kernel straight on the nn.Linear tensors
+                ex, sh = self._experts(), self.fixed_real_moe
+                tg_gu, tg_dn = [], []
+                for e in range(n_real):
+                    off, cnt = disp["offsets"][e:e + 1], disp["counts"][e:e + 1]
+                    tg_gu.append(dict(w=ex[e].gate_proj.weight.data, w2=ex[e].up_proj.weight.data, rows=disp["slot_token"],
+                                      row_off=off, count=cnt))
+                    tg_dn.append(dict(w=ex[e].down_proj.weight.data, row_off=off, count=cnt))
+                for i in range(n_fix):
+                    tg_gu.append(dict(w=sh[i].gate_proj.weight.data, w2=sh[i].up_proj.weight.data, static_count=S,
+                                      out_row_base=slots + i * S))
+                    tg_dn.append(dict(w=sh[i].down_proj.weight.data, static_count=S, a_row_base=slots + i * S,
+                                      out_row_base=slots + i * S))
+                ops.tiled_gemm(tg_gu, x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU)
+                ops.tiled_gemm(tg_dn, hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16)
+            else:
+                ops.grouped_gemm(ops.GroupTable(groups_gu, x.device), x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Imax)
+                ops.grouped_gemm(ops.GroupTable(groups_dn, x.device), hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D)
             out = ops.combine(ybuf, disp["slot_of"], moe_w, ybuf[slots:] if n_fix else None, global_w, None, n_dyn, n_fix)
         out = out.reshape(B, T, D)
         if (not self.training) and self.avg_hidden_states_last:               # core.py:355-356

@@ -161,8 +161,9 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
         layers = []
         for layer in self.language_model.layers:
             a = layer.self_attn
+            qkv_rm = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()
             layers.append(dict(
-                qkv_w=ops.pack_weight(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()),
+                qkv_rm=qkv_rm, qkv_w=ops.pack_weight(qkv_rm),
                 qkv_b=torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).float().contiguous(),
                 o_w=ops.pack_weight(a.o_proj.weight.data.contiguous()), moe=layer.mlp.prepare()))
         self._pk = dict(layers=layers, head=ops.pack_weight(self.codec_head.weight.data.contiguous()),
@@ -198,10 +199,13 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
         stats = dict(logits=[], top_k=[], expert_mask=[], weight=[], aux=[])
         for li, layer in enumerate(layers):
             lp = pk["layers"][li]
-            qkv = ops.linear(h, lp["qkv_w"], (H + 2 * KVH) * hd, bias=lp["qkv_b"])
+            tiled = B * T >= 64                      # compute-bound: tiled MFMA kernel on the row-major tensors
+            qkv = (ops.tlinear(h, lp["qkv_rm"], bias=lp["qkv_b"]) if tiled
+                   else ops.linear(h, lp["qkv_w"], (H + 2 * KVH) * hd, bias=lp["qkv_b"]))
             q = ops.qkv_mrope_kvappend(qkv, cos, sin, pos3, kv_pos, T, H, KVH, hd, cfg.mrope_section, kc, vc)
             ao = ops.attention(q, kc, vc, first_valid, q0, T, H, splits=1)
-            x1 = ops.linear(ao, lp["o_w"], D, resid=x)                                   # model.py:238
+            x1 = (ops.tlinear(ao, layer.self_attn.o_proj.weight.data, resid=x) if tiled
+                  else ops.linear(ao, lp["o_w"], D, resid=x))                             # model.py:238
             h2 = ops.rmsnorm(x1, layer.post_attention_layernorm.weight.data, cfg.rms_norm_eps)
             out = layer.mlp(h2.view(B, T, D), padding_token_mask, aux_balance_weight)    # model.py:241
             nxt = layers[li + 1].input_layernorm.weight.data if li + 1 < len(layers) else self.language_model.norm.weight.data
@@ -243,8 +247,9 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
                                 bool(output_router_logits_and_topk))
         B, T, D = out.last_hidden_state.shape
         C, V = self.num_channels, self.codec_vocab_size
-        codec_logits = ops.linear(out.last_hidden_state.reshape(B * T, D).contiguous(), self.packed()["head"], C * V,
-                                  out_f32=True).view(B, T, C, V)                            # model.py:818-819
+        hs = out.last_hidden_state.reshape(B * T, D).contiguous()
+        codec_logits = (ops.tlinear(hs, self.codec_head.weight.data, out_f32=True) if B * T >= 64
+                        else ops.linear(hs, self.packed()["head"], C * V, out_f32=True)).view(B, T, C, V)   # model.py:818-819
         loss = aux_mean = None
         if labels is not None and codec_labels is not None:
             aux_mean = torch.stack([a.float() for a in out.all_aux_loss]).mean()            # model.py:824-826
@@ -347,9 +352,19 @@ class DecodeEngine:
             n_real, n_fix = cfg.mlp_dynamic_expert_num, cfg.mlp_fixed_expert_num
             arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
             eg, ed, sg, sd = arr(pk["exp_gu"]), arr(pk["exp_dn"]), arr(pk["sh_gu"]), arr(pk["sh_dn"])
+            # row-major originals (the module's own parameters) for the tiled MFMA kernels of the prefill
+            ex = layer.mlp.dynamic_real_moe.deepspeed_moe.experts.deepspeed_experts
+            sh = layer.mlp.fixed_real_moe
+            rm = [p for mods in (ex, sh) for m_ in mods for p in (m_.gate_proj.weight, m_.up_proj.weight, m_.down_proj.weight)]
+            if not all(p.is_contiguous() for p in rm + [layer.self_attn.o_proj.weight]):
+                raise L.UmoeError("engine weights must be contiguous")
+            reg, reu, red = arr([m_.gate_proj.weight for m_ in ex]), arr([m_.up_proj.weight for m_ in ex]), arr([m_.down_proj.weight for m_ in ex])
+            rsg, rsu, rsd = arr([m_.gate_proj.weight for m_ in sh]), arr([m_.up_proj.weight for m_ in sh]), arr([m_.down_proj.weight for m_ in sh])
             w = L.LayerWeights(in_norm=layer.input_layernorm.weight.data_ptr(), qkv_w=qkv_w.data_ptr(), qkv_b=qkv_b.data_ptr(),
                                o_w=o_w.data_ptr(), post_norm=layer.post_attention_layernorm.weight.data_ptr(),
-                               gate_w=layer.mlp.gate.weight.data_ptr(), exp_gu=eg, exp_dn=ed, sh_gu=sg, sh_dn=sd)
+                               gate_w=layer.mlp.gate.weight.data_ptr(), exp_gu=eg, exp_dn=ed, sh_gu=sg, sh_dn=sd,
+                               rm_qkv=lp["qkv_rm"].data_ptr(), rm_o=layer.self_attn.o_proj.weight.data_ptr(),
+                               rm_exp_gate=reg, rm_exp_up=reu, rm_exp_down=red, rm_sh_gate=rsg, rm_sh_up=rsu, rm_sh_down=rsd)
             L.check(lib.umoe_engine_set_layer(self.h, li, C.byref(w)), "umoe_engine_set_layer")
         emb, head = mpk["emb"], mpk["head"]
         max_pos = self.Lmax + 8
