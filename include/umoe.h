@@ -87,6 +87,12 @@ int umoe_aux_loss_fwd(const void* logits, int logits_bf16, const int32_t* expert
  *   counts[n_real], offsets[n_real+1], slot_token[S*n_real], slot_of[S][n_real] (-1 = unrouted) */
 int umoe_dispatch_build(const int32_t* expert_mask, int S, int ld_mask, int n_real, int32_t* counts,
                         int32_t* offsets, int32_t* slot_token, int32_t* slot_of, umoe_stream_t stream);
+/* same tables with every expert's slot range starting on a multiple of `align` (power of two): offsets[e] % align == 0,
+ * offsets[n_real] = padded total, padding slots carry token 0 and are not counted.  slot_token needs
+ * S*n_real + n_real*(align-1) entries.  Used by training: the weight-gradient GEMMs contract over slot columns of
+ * transposed buffers in 16-byte chunks. */
+int umoe_dispatch_build_aligned(const int32_t* expert_mask, int S, int ld_mask, int n_real, int align, int32_t* counts,
+                                int32_t* offsets, int32_t* slot_token, int32_t* slot_of, umoe_stream_t stream);
 
 /* router + dispatch tables in one call: a single fused launch when S <= 16 (decode), two launches otherwise */
 int umoe_router_dispatch_fwd(const umoe_router_args* a, int32_t* counts, int32_t* offsets, int32_t* slot_token,
@@ -174,6 +180,8 @@ typedef struct {
     int a_row_base, out_row_base;
     int n, k, ldw;            /* output features, contraction length (k % 8 == 0), elements between weight rows */
     int a_col_off;
+    const int32_t* k_off;     /* optional device scalars: contract over columns [*k_off, *k_off + roundup8(*k_count)) of BOTH */
+    const int32_t* k_count;   /* operands instead of [0, k) -- weight gradients over one expert's (8-aligned) slot range */
 } umoe_tgroup_t;
 
 typedef struct {
@@ -186,6 +194,8 @@ typedef struct {
     void* out;                /* bf16 (or fp32 for UMOE_EPI_F32 / _RAW) [*, ldo] */
     int ldo;
     int epilogue;             /* UMOE_EPI_* */
+    uint16_t* aux_out;        /* UMOE_EPI_SWIGLU with aux_out != NULL (training): also store the bf16 pre-activations, */
+    int ld_aux;               /* gate at aux_out[row][col], up at aux_out[row][n + col] (what autograd would save) */
 } umoe_tgemm_args;
 int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream);
 
@@ -221,6 +231,51 @@ typedef struct {
     int mask_ld, dense_rows;    /* used iff expert_mask[s*mask_ld + e] != 0 (every expert computed all rows; decode, S <= 16) */
 } umoe_combine_args;
 int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_stream_t stream);
+
+/* ------------------------------------------------------------------ backward pieces (training, BASELINE config 3)
+ * The contractions run on umoe_tiled_gemm (operands K-contiguous): dX = dY * W uses a transposed weight copy, dW = dY^T X
+ * contracts over the slot columns of transposed, 8-aligned, zero-padded buffers built by umoe_transpose_slots
+ * (umoe_dispatch_build_aligned + umoe_tgroup_t.k_off / k_count).  Everything below is per-token / elementwise. */
+
+/* dst[c][off_g + r] = src[row(off_g + r)][c], r < counts[g]; zeros up to the next multiple of 8.  row(s) = rows ? rows[s] : s.
+ * counts/offsets NULL: one group of max_rows rows at offset 0 (plain transpose).  Replaces autograd's implicit
+ * transposes in Linear.backward (core.py:21-49 via torch.nn.functional.linear). */
+int umoe_transpose_slots(const uint16_t* src, int ld_src, int C, const int32_t* rows, const int32_t* counts,
+                         const int32_t* offsets, int n_groups, int max_rows, uint16_t* dst, int ld_dst, umoe_stream_t stream);
+
+/* SwiGLU backward, core.py:31,49: gu [rows][2I] = (gate | up) pre-activations saved by the forward
+ * (umoe_tgemm_args.aux_out), dh [rows][I] -> dgu [rows][2I] = (dgate | dup).  total_rows: device scalar or NULL. */
+int umoe_swiglu_bwd(const uint16_t* dh, int ld_dh, const uint16_t* gu, int ld_gu, int I, const int32_t* total_rows,
+                    int max_rows, uint16_t* dgu, int ld_dgu, umoe_stream_t stream);
+
+/* backward of umoe_unpermute_combine_fwd (einsum core.py:488, shared adds :349-351): per selected (token, expert)
+ * dy[slot] = bf16(w * dout[s]) and d_moe_w[s][e] = <dout[s], y[slot]>; same for the shared experts with global_w. */
+int umoe_unpermute_combine_bwd(const uint16_t* dout, const umoe_combine_args* a, uint16_t* dy_slots, uint16_t* dy_shared,
+                               float* d_moe_w, float* d_gw_shared, umoe_stream_t stream);
+
+/* backward of the dispatch gather (compress_matrix, utils.py:436-485): dx[s] = sum of the slot rows of token s
+ * (+ the shared experts' input gradients [n_fix][S][D], + an optional extra [S][D] term), fp32 accumulate, one rounding. */
+int umoe_permute_bwd(const uint16_t* dxe, const int32_t* slot_of, int n_real, const uint16_t* dx_shared, int n_fix, int S, int D,
+                     const uint16_t* extra, uint16_t* dx, umoe_stream_t stream);
+
+/* router backward, shipped configuration (ignore_differentiable_router, core.py:272): d(moe_w), d(shared global weights)
+ * -> d_logits [S][E] fp32 through the per-round softmax multipliers (core.py:115-119), the renormalisation (:284) and the
+ * global softmax (:178-193).  sel / top_k / expert_mask are the forward's integer outputs; d_logits_in is added (aux loss). */
+int umoe_router_bwd(const void* logits, int logits_bf16, const int32_t* sel, const int64_t* top_k, const int32_t* expert_mask,
+                    const float* d_moe_w, const float* d_gw_shared, const float* d_logits_in, int S, int n_dyn, int n_real,
+                    int n_fix, double jitter_eps, float* d_logits, umoe_stream_t stream);
+
+/* backward of umoe_aux_loss_fwd (core.py:361-389): d_logits [S][E] fp32 = *d_aux * d aux / d logits (zero on the columns the
+ * mask removed and on the shared columns); ws: 17 floats of scratch (per-expert token fractions, weight sum). */
+int umoe_aux_loss_bwd(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S, int E,
+                      int n_dyn, const float* d_aux, float* d_logits, float* ws, umoe_stream_t stream);
+
+/* Qwen2RMSNorm backward (model.py:206-207): h [S][D] the normalised tensor's input, dy the gradient of w * bf16(h * rs);
+ * dh = rs * (dy*w - xh * mean(dy*w*xh)) + dsum (gradient arriving on h through the residual path, optional), dw [D].
+ * ws: fp32 scratch of min(S,512)*D floats. */
+int umoe_rmsnorm_residual_bwd(const uint16_t* h, const uint16_t* w, const uint16_t* dy, const uint16_t* dsum, float eps, int S,
+                              int D, uint16_t* dh, uint16_t* dw, float* ws, size_t ws_floats, umoe_stream_t stream);
+
 
 /* ------------------------------------------------------------------ norm / rope / attention
  * umoe_rmsnorm_residual_fwd: y = w * bf16((x [+ r]) * rsqrt(mean((x+r)^2) + eps)); also writes x+r.

@@ -193,6 +193,60 @@ def gen_dcmoe(ref, out):
         save(os.path.join(out, f"dcmoe_{name}.npz"), **d)
 
 
+def gen_dcmoe_bwd(ref, out):
+    """Reference block forward + autograd backward (training, shipped ignore_differentiable_router=True): gradients of
+    loss = sum(out * G) + aux_coef * aux with respect to the input and every parameter."""
+    core = ref.core
+    variants = dict(
+        train_fp32gate=dict(_train=True),
+        eval_bf16gate=dict(_train=False),
+        train_pad_auxw=dict(_train=True, _pad=True, _auxw=True),
+        train_topk2=dict(_train=True, mlp_dynamic_top_p=0.0, mlp_dynamic_top_k=2),
+    )
+    for vi, (name, over) in enumerate(variants.items()):
+        over = dict(over)
+        train = over.pop("_train")
+        pad = over.pop("_pad", False)
+        auxw = over.pop("_auxw", False)
+        c = block_cfg(**over)
+        torch.manual_seed(900 + vi)
+        blk = core.UniMoEAudioSparseMoeBlock(c)
+        with torch.no_grad():
+            for n, p in blk.named_parameters():
+                p.normal_(0, 0.35 if n == "gate.weight" else 0.08)
+        blk = blk.to(torch.bfloat16)
+        blk.train(train)
+        B, T = 3, 24
+        x = torch.randn(B, T, c.hidden_size).to(torch.bfloat16).requires_grad_(True)
+        G = torch.randn(B, T, c.hidden_size).to(torch.bfloat16)
+        am = aw = None
+        if pad:
+            am = torch.ones(B, T, dtype=torch.bool)
+            am[0, :5] = False
+            am[2, :2] = False
+        if auxw:
+            aw = torch.rand(B, T)
+        aux_coef = 0.3
+        with MixerRecorder(core) as rec:
+            o = blk(x, am, aw)
+        loss = (o[0].float() * G.float()).sum() + aux_coef * o[5].float()
+        loss.backward()
+        d = {"in_x": x.detach(), "in_G": G, "aux_coef": np.array(aux_coef, dtype=np.float32), "out_hidden": o[0].detach(),
+             "out_logits": o[1].detach(), "out_top_k": o[2], "out_mask": o[3], "out_weight": o[4].detach(), "out_aux": o[5].detach(),
+             "out_sel": rec.selection(o[2].long(), c.mlp_dynamic_expert_num + c.mlp_dynamic_null_expert_num),
+             "grad_x": x.grad}
+        if am is not None:
+            d["in_attention_mask"] = am
+        if aw is not None:
+            d["in_aux_balance_weight"] = aw
+        for n, p in blk.named_parameters():
+            d["w." + n] = p.detach()
+            d["g." + n] = p.grad if p.grad is not None else torch.zeros_like(p)
+        d["cfg_json"] = np.frombuffer(__import__("json").dumps({k: v for k, v in c.__dict__.items()}).encode(), dtype=np.uint8)
+        d["train"] = np.array(int(train))
+        save(os.path.join(out, f"dcmoebwd_{name}.npz"), **d)
+
+
 def gen_compress(ref, out):
     mu = ref.moe_utils
     torch.manual_seed(300)
@@ -454,7 +508,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     ref = _ref_shim.load_reference(True)
-    gens = dict(router=gen_router_ids, dcmoe=gen_dcmoe, compress=gen_compress, delay=gen_delay,
+    gens = dict(router=gen_router_ids, dcmoe=gen_dcmoe, dcmoebwd=gen_dcmoe_bwd, compress=gen_compress, delay=gen_delay,
                 sampler=gen_sampler, generate=gen_generate, attn=gen_attn)
     for k, fn in gens.items():
         if a.only and k not in a.only.split(","):

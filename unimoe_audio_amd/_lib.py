@@ -52,12 +52,12 @@ class GemmArgs(C.Structure):
 
 class TGroup(C.Structure):
     _fields_ = [("w", vp), ("w2", vp), ("bias", vp), ("rows", vp), ("row_off", vp), ("count", vp), ("static_count", i32),
-                ("a_row_base", i32), ("out_row_base", i32), ("n", i32), ("k", i32), ("ldw", i32), ("a_col_off", i32)]
+                ("a_row_base", i32), ("out_row_base", i32), ("n", i32), ("k", i32), ("ldw", i32), ("a_col_off", i32), ("k_off", vp), ("k_count", vp)]
 
 
 class TGemmArgs(C.Structure):
     _fields_ = [("groups", vp), ("num_groups", i32), ("max_rows", i32), ("a", vp), ("lda", i32), ("resid", vp), ("out", vp),
-                ("ldo", i32), ("epilogue", i32)]
+                ("ldo", i32), ("epilogue", i32), ("aux_out", vp), ("ld_aux", i32)]
 
 
 class CombineArgs(C.Structure):
@@ -115,7 +115,8 @@ EXPORTS = [
     "umoe_codec_embed_sum", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_codec_ce_fwd", "umoe_codec_ce_bwd", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
     "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
-    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm",
+    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm", "umoe_dispatch_build_aligned", "umoe_transpose_slots", "umoe_swiglu_bwd",
+    "umoe_unpermute_combine_bwd", "umoe_permute_bwd", "umoe_router_bwd", "umoe_rmsnorm_residual_bwd", "umoe_aux_loss_bwd",
 ]
 
 
@@ -141,6 +142,14 @@ def lib():
         L.umoe_dispatch_build.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.umoe_aux_loss_fwd.argtypes = [vp, i32, vp, vp, i32, i32, i32, vp, vp]
         L.umoe_prefetch.argtypes = [vp, C.c_size_t, i32, vp]
+        L.umoe_transpose_slots.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp]
+        L.umoe_swiglu_bwd.argtypes = [vp, i32, vp, i32, i32, vp, i32, vp, i32, vp]
+        L.umoe_unpermute_combine_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.umoe_permute_bwd.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp, vp]
+        L.umoe_router_bwd.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp]
+        L.umoe_rmsnorm_residual_bwd.argtypes = [vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, C.c_size_t, vp]
+        L.umoe_dispatch_build_aligned.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+        L.umoe_aux_loss_bwd.argtypes = [vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp]
         L.umoe_router_dispatch_fwd.argtypes = [C.POINTER(RouterArgs), vp, vp, vp, vp, vp]
         L.umoe_permute_fwd.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.umoe_grouped_gemm.argtypes = [C.POINTER(GemmArgs), vp]

@@ -1,0 +1,561 @@
+// Backward pieces of the DCMoE block and of the decoder layer's norms (the *_bwd entry points).
+// The contractions (dX = dY W, dW = dY^T X) run on umoe_tiled_gemm: its operands are K-contiguous, so the weight
+// gradients contract over SLOT COLUMNS of transposed buffers built here (8-aligned slot ranges, zero padded), and the
+// input gradients use transposed weight copies.  Everything else -- SwiGLU, combine, permute, router, RMSNorm -- is
+// elementwise / per-token work: HBM bound, fp32 arithmetic, one rounding to bf16 where autograd would round.
+#include "umoe_common.h"
+
+// ------------------------------------------------------------------------------------ transposes
+// dst[c][off_g + r] = src[row(off_g + r)][c] for r < cnt_g, 0 for cnt_g <= r < roundup8(cnt_g); row(s) = rows ? rows[s] : s.
+// grid = (slot tiles of 64, column tiles of 64, groups).  counts == NULL: one group of `static_rows` rows at offset 0.
+__global__ __launch_bounds__(256) void transpose_slots_kernel(const uint16_t* __restrict__ src, int ld_src, int C,
+                                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ counts,
+                                                              const int32_t* __restrict__ offsets, int static_rows,
+                                                              uint16_t* __restrict__ dst, int ld_dst) {
+    __shared__ uint16_t tile[64][72];   // [slot][col], 144-byte rows: 16-byte aligned chunks, bank spread
+    const int g = blockIdx.z;
+    const int cnt = counts ? counts[g] : static_rows;
+    const int off = offsets ? offsets[g] : 0;
+    const int pad = (cnt + 7) & ~7;
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    if (r0 >= pad) return;
+    const int tid = threadIdx.x;
+    // load: thread (tr = tid / 8, ch = tid % 8) reads 8 columns of slots tr and tr + 32
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int r = (tid >> 3) + 32 * ps, ch = tid & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const int c = c0 + ch * 8;
+        if (r0 + r < cnt && c < C) {
+            const long srow = rows ? (long)rows[off + r0 + r] : (long)(off + r0 + r);
+            const uint16_t* sp = src + srow * ld_src + c;
+            if (c + 8 <= C && (ld_src & 7) == 0) {
+                v = ld16(sp);
+            } else {
+                uint16_t t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = (c + j < C) ? sp[j] : (uint16_t)0;
+                v = make_uint4((uint32_t)t[0] | ((uint32_t)t[1] << 16), (uint32_t)t[2] | ((uint32_t)t[3] << 16),
+                               (uint32_t)t[4] | ((uint32_t)t[5] << 16), (uint32_t)t[6] | ((uint32_t)t[7] << 16));
+            }
+        }
+        *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = v;
+    }
+    __syncthreads();
+    // store: thread (c = tid / 8 (+32), sc = tid % 8) writes 8 consecutive slots of column c
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int c = (tid >> 3) + 32 * ps, sc = tid & 7;
+        if (c0 + c >= C || r0 + sc * 8 >= pad) continue;
+        uint16_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = tile[sc * 8 + j][c];
+        const uint4 v = make_uint4((uint32_t)t[0] | ((uint32_t)t[1] << 16), (uint32_t)t[2] | ((uint32_t)t[3] << 16),
+                                   (uint32_t)t[4] | ((uint32_t)t[5] << 16), (uint32_t)t[6] | ((uint32_t)t[7] << 16));
+        st16(dst + (size_t)(c0 + c) * ld_dst + off + r0 + sc * 8, v);
+    }
+}
+
+extern "C" int umoe_transpose_slots(const uint16_t* src, int ld_src, int C, const int32_t* rows, const int32_t* counts,
+                                    const int32_t* offsets, int n_groups, int max_rows, uint16_t* dst, int ld_dst,
+                                    umoe_stream_t stream) {
+    UMOE_REQUIRE(src && dst && C > 0 && max_rows >= 0 && (ld_dst & 7) == 0, "umoe_transpose_slots: bad argument (ld_dst %% 8)");
+    UMOE_REQUIRE((counts == nullptr) == (offsets == nullptr), "umoe_transpose_slots: counts and offsets come together");
+    if (max_rows == 0) return 0;
+    const int G = counts ? n_groups : 1;
+    UMOE_REQUIRE(G >= 1 && G <= 65535, "umoe_transpose_slots: bad group count");
+    dim3 grid((unsigned)ceil_div(((max_rows + 7) & ~7), 64), (unsigned)ceil_div(C, 64), (unsigned)G);
+    transpose_slots_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, ld_src, C, rows, counts, offsets, max_rows, dst, ld_dst);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ SwiGLU backward
+// h = silu(g) * u (core.py:31,49).  autograd on bf16 tensors: d_silu = bf16(dh * u), du = bf16(dh * silu(g)),
+// dg = bf16(d_silu * sigmoid(g) * (1 + g * (1 - sigmoid(g)))) (torch's silu backward, fp32 inside).
+// gu [rows][2I] = (g | u) saved by the forward; dgu [rows][2I] = (dg | du).  Rows are the slot rows [0, *total).
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const uint16_t* __restrict__ dh, int ld_dh, const uint16_t* __restrict__ gu,
+                                                         int ld_gu, int I, const int32_t* __restrict__ total, int static_rows,
+                                                         uint16_t* __restrict__ dgu, int ld_dgu) {
+    const int rows = total ? *total : static_rows;
+    const int nch = I >> 3;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < (long)rows * nch; idx += (long)gridDim.x * 256) {
+        const long r = idx / nch;
+        const int c = (int)(idx - r * nch) * 8;
+        float d[8], g[8], u[8], og[8], ou[8];
+        unpack8(ld16(dh + r * ld_dh + c), d);
+        unpack8(ld16(gu + r * ld_gu + c), g);
+        unpack8(ld16(gu + r * ld_gu + I + c), u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sg = 1.0f / (1.0f + expf(-g[j]));
+            const float silu = rbf(g[j] * sg);
+            ou[j] = d[j] * silu;
+            const float ds = rbf(d[j] * u[j]);
+            og[j] = ds * (sg * (1.0f + g[j] * (1.0f - sg)));
+        }
+        st16(dgu + r * ld_dgu + c, pack8(og));
+        st16(dgu + r * ld_dgu + I + c, pack8(ou));
+    }
+}
+
+extern "C" int umoe_swiglu_bwd(const uint16_t* dh, int ld_dh, const uint16_t* gu, int ld_gu, int I, const int32_t* total_rows,
+                               int max_rows, uint16_t* dgu, int ld_dgu, umoe_stream_t stream) {
+    UMOE_REQUIRE(dh && gu && dgu && I > 0 && I % 8 == 0 && (ld_dh & 7) == 0 && (ld_gu & 7) == 0 && (ld_dgu & 7) == 0,
+                 "umoe_swiglu_bwd: bad argument (I and leading dimensions must be multiples of 8)");
+    if (max_rows <= 0) return 0;
+    const long work = (long)max_rows * (I >> 3);
+    const unsigned blocks = (unsigned)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+    swiglu_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dh, ld_dh, gu, ld_gu, I, total_rows, max_rows, dgu, ld_dgu);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ combine backward
+// forward (umoe_unpermute_combine_fwd): out[s] = sum_e w[s][e] * y[slot(s,e)] + sum_i gw[s][n_dyn+i] * ysh[i][s] (+ resid).
+// backward per token s: dy[slot] = bf16(w * dout[s]), dw[s][e] = <dout[s], y[slot]>, same for the shared experts.
+__global__ __launch_bounds__(256) void combine_bwd_kernel(const uint16_t* __restrict__ dout, const umoe_combine_args a,
+                                                          uint16_t* __restrict__ dy_slots, uint16_t* __restrict__ dy_shared,
+                                                          float* __restrict__ d_moe_w, float* __restrict__ d_gw_shared) {
+    __shared__ float sh[4];
+    const int s = blockIdx.x, E = a.n_dyn + a.n_fix;
+    const int nch = a.D >> 3;
+    for (int e = 0; e < a.n_real + a.n_fix; ++e) {
+        const bool shd = e >= a.n_real;
+        const int i = e - a.n_real;
+        long row;
+        float w;
+        if (!shd) {
+            const int slot = a.slot_of[(size_t)s * a.n_real + e];
+            if (slot < 0) {
+                if (threadIdx.x == 0) d_moe_w[(size_t)s * a.n_real + e] = 0.f;
+                continue;
+            }
+            row = slot;
+            w = a.moe_w[(size_t)s * a.n_real + e];
+        } else {
+            if (!a.y_shared) break;
+            row = (long)i * a.S + s;
+            w = a.global_w[(size_t)s * E + a.n_dyn + i];
+        }
+        const uint16_t* y = (shd ? a.y_shared : a.y_slots) + row * a.D;
+        uint16_t* dy = (shd ? dy_shared : dy_slots) + row * a.D;
+        float dot = 0.f;
+        for (int c = threadIdx.x; c < nch; c += 256) {
+            float d[8], yv[8], o[8];
+            unpack8(ld16(dout + (size_t)s * a.D + c * 8), d);
+            unpack8(ld16(y + c * 8), yv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dot += d[j] * yv[j];
+                o[j] = w * d[j];
+            }
+            st16(dy + c * 8, pack8(o));
+        }
+        dot = block_sum_256(dot, sh);
+        if (threadIdx.x == 0) {
+            if (!shd) d_moe_w[(size_t)s * a.n_real + e] = dot;
+            else d_gw_shared[(size_t)s * a.n_fix + i] = dot;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int umoe_unpermute_combine_bwd(const uint16_t* dout, const umoe_combine_args* a, uint16_t* dy_slots,
+                                          uint16_t* dy_shared, float* d_moe_w, float* d_gw_shared, umoe_stream_t stream) {
+    UMOE_REQUIRE(dout && a && a->y_slots && a->slot_of && a->moe_w && dy_slots && d_moe_w && a->D % 8 == 0,
+                 "umoe_unpermute_combine_bwd: bad argument");
+    UMOE_REQUIRE(!a->y_shared || (a->global_w && dy_shared && d_gw_shared), "umoe_unpermute_combine_bwd: shared experts need global_w and outputs");
+    if (a->S == 0) return 0;
+    combine_bwd_kernel<<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(dout, *a, dy_slots, dy_shared, d_moe_w, d_gw_shared);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ permute backward
+// dx[s] = bf16( sum_{e: slot(s,e) >= 0} dxe[slot] + sum_i dxsh[i][s] + extra[s] ), fp32 accumulation in expert order.
+__global__ __launch_bounds__(256) void permute_bwd_kernel(const uint16_t* __restrict__ dxe, const int32_t* __restrict__ slot_of,
+                                                          int n_real, const uint16_t* __restrict__ dxsh, int n_fix, int S, int D,
+                                                          const uint16_t* __restrict__ extra, uint16_t* __restrict__ dx) {
+    const int s = blockIdx.x;
+    for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int e = 0; e < n_real; ++e) {
+            const int slot = slot_of[(size_t)s * n_real + e];
+            if (slot < 0) continue;
+            float v[8];
+            unpack8(ld16(dxe + (size_t)slot * D + c * 8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+        for (int i = 0; i < n_fix; ++i) {
+            float v[8];
+            unpack8(ld16(dxsh + ((size_t)i * S + s) * D + c * 8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+        if (extra) {
+            float v[8];
+            unpack8(ld16(extra + (size_t)s * D + c * 8), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+        st16(dx + (size_t)s * D + c * 8, pack8(acc));
+    }
+}
+
+extern "C" int umoe_permute_bwd(const uint16_t* dxe, const int32_t* slot_of, int n_real, const uint16_t* dx_shared, int n_fix,
+                                int S, int D, const uint16_t* extra, uint16_t* dx, umoe_stream_t stream) {
+    UMOE_REQUIRE(dxe && slot_of && dx && D % 8 == 0 && n_real >= 0 && (n_fix == 0 || dx_shared), "umoe_permute_bwd: bad argument");
+    if (S == 0) return 0;
+    permute_bwd_kernel<<<dim3((unsigned)S), 256, 0, (hipStream_t)stream>>>(dxe, slot_of, n_real, dx_shared, n_fix, S, D, extra, dx);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ router backward
+// Gradient of (moe_w, shared global weights) with respect to the router logits, shipped configuration
+// (ignore_differentiable_router: the mixer runs its eval branch, core.py:115-119,272; gradients flow through the
+// per-round softmax multipliers, the renormalisation core.py:284 and the global softmax core.py:178-193).
+// One thread per token; the forward chain is recomputed in fp32 from the saved logits and selection order.
+//   rounds j < k: A_j = {unselected a : (max_j - z_a) / max(|z_a|, |max_j|) <= 2 eps}, p_j = softmax_{A_j}(z), rw[e_j] = p_j[e_j]
+//   r = rw / (sum rw + 1e-6);  G = softmax_{mask != 0}(z over all E);  Gd = sum_{e < n_dyn} G[e]
+//   gw[e < n_dyn] = r[e] * Gd,  gw[n_dyn + i] = G[n_dyn + i];  moe_w[e < n_real] = gw[e] * mask[e]
+__global__ __launch_bounds__(256) void router_bwd_kernel(const void* __restrict__ logits, int logits_bf16, const int32_t* __restrict__ sel,
+                                                         const int64_t* __restrict__ top_k, const int32_t* __restrict__ mask,
+                                                         const float* __restrict__ d_moe_w, const float* __restrict__ d_gw_shared,
+                                                         const float* __restrict__ d_logits_in, int S, int n_dyn, int n_real, int n_fix,
+                                                         float jitter_eps, float* __restrict__ d_logits) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const int E = n_dyn + n_fix;
+    float z[UMOE_MAXE], dz[UMOE_MAXE], rw[UMOE_MAXE], drw[UMOE_MAXE];
+    int m[UMOE_MAXE];
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) {
+        z[e] = -INFINITY; dz[e] = 0.f; rw[e] = 0.f; drw[e] = 0.f; m[e] = 0;
+        if (e < E) {
+            z[e] = logits_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(logits)[(size_t)s * E + e])
+                               : reinterpret_cast<const float*>(logits)[(size_t)s * E + e];
+            m[e] = mask[(size_t)s * E + e];
+        }
+    }
+    const int k = (int)top_k[s];
+    // ---- forward recompute: routing weights of the selected columns ----
+    {
+        bool taken[UMOE_MAXE];
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e) taken[e] = false;
+        for (int j = 0; j < k; ++j) {
+            const int ej = sel[(size_t)s * n_dyn + j];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e)
+                if (e < n_dyn && !taken[e]) mx = fmaxf(mx, z[e]);
+            float den = 0.f;
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e)
+                if (e < n_dyn && !taken[e]) {
+                    const float f = fmaxf(fabsf(z[e]), fabsf(mx));
+                    if (!((mx - z[e]) / f > 2.f * jitter_eps)) den += expf(z[e] - mx);
+                }
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e)
+                if (e == ej) {
+                    rw[e] = expf(z[e] - mx) / den;
+                    taken[e] = true;
+                }
+        }
+    }
+    float R = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < n_dyn) R += rw[e];
+    const float Rinv = 1.f / (R + 1e-6f);
+    // global softmax over the active columns
+    float G[UMOE_MAXE];
+    float gmx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < E && m[e]) gmx = fmaxf(gmx, z[e]);
+    float gden = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) {
+        G[e] = (e < E && m[e]) ? expf(z[e] - gmx) : 0.f;
+        gden += G[e];
+    }
+    float Gd = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) {
+        G[e] = gden > 0.f ? G[e] / gden : 0.f;
+        if (e < n_dyn) Gd += G[e];
+    }
+    // ---- backward ----
+    float dG[UMOE_MAXE], dr[UMOE_MAXE];
+    float dGd = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) {
+        dr[e] = 0.f;
+        dG[e] = 0.f;
+        if (e < n_real) {
+            const float dgw = d_moe_w[(size_t)s * n_real + e] * (float)(m[e] != 0);   // moe_w = gw * mask
+            dr[e] = dgw * Gd;
+            dGd += dgw * rw[e] * Rinv;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) {
+        if (e < n_dyn) dG[e] = dGd;
+        else if (e < E) dG[e] = d_gw_shared ? d_gw_shared[(size_t)s * n_fix + (e - n_dyn)] : 0.f;
+    }
+    float gdot = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) gdot += G[e] * dG[e];
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) dz[e] += G[e] * (dG[e] - gdot);
+    // renormalisation: r = rw * Rinv
+    float rdot = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) rdot += dr[e] * rw[e];
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < n_dyn) drw[e] = dr[e] * Rinv - rdot * Rinv * Rinv;
+    // per-round softmax multipliers
+    {
+        bool taken[UMOE_MAXE];
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e) taken[e] = false;
+        for (int j = 0; j < k; ++j) {
+            const int ej = sel[(size_t)s * n_dyn + j];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e)
+                if (e < n_dyn && !taken[e]) mx = fmaxf(mx, z[e]);
+            float pj[UMOE_MAXE];
+            float den = 0.f;
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e) {
+                pj[e] = 0.f;
+                if (e < n_dyn && !taken[e]) {
+                    const float f = fmaxf(fabsf(z[e]), fabsf(mx));
+                    if (!((mx - z[e]) / f > 2.f * jitter_eps)) pj[e] = expf(z[e] - mx);
+                }
+                den += pj[e];
+            }
+            float dwj = 0.f, psel = 0.f;
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e) {
+                pj[e] /= den;
+                if (e == ej) {
+                    dwj = drw[e];
+                    psel = pj[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e) {
+                dz[e] += dwj * psel * ((e == ej ? 1.f : 0.f) - pj[e]);
+                if (e == ej) taken[e] = true;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < E) d_logits[(size_t)s * E + e] = dz[e] + (d_logits_in ? d_logits_in[(size_t)s * E + e] : 0.f);
+}
+
+extern "C" int umoe_router_bwd(const void* logits, int logits_bf16, const int32_t* sel, const int64_t* top_k,
+                               const int32_t* expert_mask, const float* d_moe_w, const float* d_gw_shared,
+                               const float* d_logits_in, int S, int n_dyn, int n_real, int n_fix, double jitter_eps,
+                               float* d_logits, umoe_stream_t stream) {
+    UMOE_REQUIRE(logits && sel && top_k && expert_mask && d_moe_w && d_logits, "umoe_router_bwd: null argument");
+    UMOE_REQUIRE(n_dyn >= 1 && n_dyn + n_fix <= UMOE_MAXE && n_real <= n_dyn && (n_fix == 0 || d_gw_shared),
+                 "umoe_router_bwd: bad sizes n_dyn=%d n_real=%d n_fix=%d", n_dyn, n_real, n_fix);
+    if (S == 0) return 0;
+    router_bwd_kernel<<<dim3((unsigned)ceil_div(S, 256)), 256, 0, (hipStream_t)stream>>>(
+        logits, logits_bf16, sel, top_k, expert_mask, d_moe_w, d_gw_shared, d_logits_in, S, n_dyn, n_real, n_fix, (float)jitter_eps,
+        d_logits);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ RMSNorm (+ residual) backward
+// forward: h = r + x (optional residual), y = w * bf16(h * rs), rs = rsqrt(mean(h^2) + eps)   (Qwen2RMSNorm, model.py:206-207)
+// backward: with xh = h * rs, gy = dy * w:  dh = rs * (gy - xh * mean(gy * xh)) (+ dsum, the gradient arriving on h itself)
+//           dw[c] = sum_s dy[s][c] * bf16(xh[s][c])   (two stages: per-workgroup partials, then a fixed-order reduction)
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __restrict__ h, const uint16_t* __restrict__ w,
+                                                          const uint16_t* __restrict__ dy, const uint16_t* __restrict__ dsum, float eps,
+                                                          int S, int D, int rows_per_wg, uint16_t* __restrict__ dh,
+                                                          float* __restrict__ dw_part) {
+    __shared__ float sh[4];
+    const int nch = D >> 3;
+    const int s0 = blockIdx.x * rows_per_wg;
+    // per-thread column chunks stay fixed over the rows of this workgroup: dw partials accumulate in registers
+    float dwacc[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwacc[q][j] = 0.f;
+    for (int s = s0; s < min(s0 + rows_per_wg, S); ++s) {
+        float ss = 0.f, dot = 0.f;
+        float hv[4][8], gv[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = threadIdx.x + 256 * q;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[q][j] = gv[q][j] = 0.f;
+            if (c < nch) {
+                float wv[8], d[8];
+                unpack8(ld16(h + (size_t)s * D + c * 8), hv[q]);
+                unpack8(ld16(w + c * 8), wv);
+                unpack8(ld16(dy + (size_t)s * D + c * 8), d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    ss += hv[q][j] * hv[q][j];
+                    gv[q][j] = d[j] * wv[j];
+                }
+            }
+        }
+        ss = block_sum_256(ss, sh);
+        __syncthreads();
+        const float rs = rsqrtf(ss / (float)D + eps);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dot += gv[q][j] * hv[q][j] * rs;
+        dot = block_sum_256(dot, sh);
+        __syncthreads();
+        const float mean = dot / (float)D;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = threadIdx.x + 256 * q;
+            if (c < nch) {
+                float o[8], d[8], ds[8];
+                unpack8(ld16(dy + (size_t)s * D + c * 8), d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ds[j] = 0.f;
+                if (dsum) unpack8(ld16(dsum + (size_t)s * D + c * 8), ds);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = hv[q][j] * rs;
+                    o[j] = rs * (gv[q][j] - xh * mean) + ds[j];
+                    dwacc[q][j] += d[j] * rbf(xh);
+                }
+                st16(dh + (size_t)s * D + c * 8, pack8(o));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = threadIdx.x + 256 * q;
+        if (c < nch) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dw_part[(size_t)blockIdx.x * D + c * 8 + j] = dwacc[q][j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int n_part, int D, uint16_t* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float acc = 0.f;
+    for (int p = 0; p < n_part; ++p) acc += part[(size_t)p * D + c];
+    out[c] = f2bf(acc);
+}
+
+extern "C" int umoe_rmsnorm_residual_bwd(const uint16_t* h, const uint16_t* w, const uint16_t* dy, const uint16_t* dsum, float eps,
+                                         int S, int D, uint16_t* dh, uint16_t* dw, float* ws, size_t ws_floats,
+                                         umoe_stream_t stream) {
+    UMOE_REQUIRE(h && w && dy && dh && dw && ws && D % 8 == 0 && D <= 8192, "umoe_rmsnorm_residual_bwd: bad argument (D %% 8, D <= 8192)");
+    if (S == 0) return 0;
+    const int n_wg = S < 512 ? S : 512;
+    const int rpw = ceil_div(S, n_wg);
+    const int used = ceil_div(S, rpw);
+    UMOE_REQUIRE(ws_floats >= (size_t)used * D, "umoe_rmsnorm_residual_bwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)used * D);
+    rmsnorm_bwd_kernel<<<dim3((unsigned)used), 256, 0, (hipStream_t)stream>>>(h, w, dy, dsum, eps, S, D, rpw, dh, ws);
+    UMOE_LAUNCH_CHECK();
+    colsum_kernel<<<dim3((unsigned)ceil_div(D, 256)), 256, 0, (hipStream_t)stream>>>(ws, used, D, dw);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ aux loss backward
+// aux = n_dyn * sum_e f_e * P_e,  f_e = sum_s w_s mask[s][e] / W (no gradient),  P_e = sum_s w_s p[s][e] / W,
+// p[s] = softmax over the n_dyn columns of masked_fill(logits, mask == 0, finfo.min)  (core.py:361-389)
+// d aux / d z[s][e] = n_dyn * (w_s / W) * p[s][e] * (f_e - sum_a f_a p[s][a]) on the columns that kept their logit.
+__global__ __launch_bounds__(256) void aux_frac_kernel(const int32_t* __restrict__ mask, const float* __restrict__ tok_w, int S, int E,
+                                                       int n_dyn, float* __restrict__ ws) {
+    __shared__ float sh[4];
+    float fm[UMOE_MAXE];
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) fm[e] = 0.f;
+    float wsum = 0.f;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        const float w = tok_w ? tok_w[s] : 1.f;
+        wsum += w;
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < n_dyn) fm[e] += w * (float)mask[(size_t)s * E + e];
+    }
+    wsum = block_sum_256(wsum, sh);
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < n_dyn) {
+            const float a = block_sum_256(fm[e], sh);
+            if (threadIdx.x == 0) ws[e] = a / wsum;
+        }
+    if (threadIdx.x == 0) ws[UMOE_MAXE] = wsum;
+}
+
+__global__ __launch_bounds__(256) void aux_bwd_kernel(const void* __restrict__ logits, int logits_bf16, const int32_t* __restrict__ mask,
+                                                      const float* __restrict__ tok_w, const float* __restrict__ ws,
+                                                      const float* __restrict__ d_aux, int S, int E, int n_dyn,
+                                                      float* __restrict__ d_logits) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    float x[UMOE_MAXE], p[UMOE_MAXE];
+    bool keep[UMOE_MAXE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) {
+        keep[e] = false;
+        x[e] = -INFINITY;
+        if (e < n_dyn) {
+            const float l = logits_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(logits)[(size_t)s * E + e])
+                                        : reinterpret_cast<const float*>(logits)[(size_t)s * E + e];
+            keep[e] = mask[(size_t)s * E + e] != 0;
+            x[e] = keep[e] ? l : (logits_bf16 ? -3.3895313892515355e38f : -3.4028234663852886e38f);
+            mx = fmaxf(mx, x[e]);
+        }
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) {
+        p[e] = e < n_dyn ? expf(x[e] - mx) : 0.f;
+        sm += p[e];
+    }
+    float fdot = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) {
+        p[e] /= sm;
+        if (e < n_dyn) fdot += ws[e] * p[e];
+    }
+    const float scale = (*d_aux) * (float)n_dyn * (tok_w ? tok_w[s] : 1.f) / ws[UMOE_MAXE];
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < E) d_logits[(size_t)s * E + e] = (e < n_dyn && keep[e]) ? scale * p[e] * (ws[e] - fdot) : 0.f;
+}
+
+extern "C" int umoe_aux_loss_bwd(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S,
+                                 int E, int n_dyn, const float* d_aux, float* d_logits, float* ws, umoe_stream_t stream) {
+    UMOE_REQUIRE(logits && expert_mask && d_aux && d_logits && ws && n_dyn >= 1 && n_dyn <= E && E <= UMOE_MAXE,
+                 "umoe_aux_loss_bwd: bad argument");
+    if (S == 0) return 0;
+    aux_frac_kernel<<<1, 256, 0, (hipStream_t)stream>>>(expert_mask, token_weight, S, E, n_dyn, ws);
+    UMOE_LAUNCH_CHECK();
+    aux_bwd_kernel<<<dim3((unsigned)ceil_div(S, 256)), 256, 0, (hipStream_t)stream>>>(logits, logits_bf16, expert_mask, token_weight, ws,
+                                                                                      d_aux, S, E, n_dyn, d_logits);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}

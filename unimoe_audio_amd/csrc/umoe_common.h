@@ -154,4 +154,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// fixed-order sum over a 256-thread workgroup (sh: 4 floats of LDS)
+#if defined(__HIPCC__)
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+#endif
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

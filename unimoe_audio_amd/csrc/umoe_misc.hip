@@ -14,15 +14,6 @@ void umoe_set_error(const char* fmt, ...) {
 extern "C" const char* umoe_last_error(void) { return g_err; }
 extern "C" int umoe_abi_version(void) { return 1; }
 
-// ------------------------------------------------------------------------------------ block reduce
-__device__ __forceinline__ float block_sum_256(float v, float* sh) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float r = sh[0] + sh[1] + sh[2] + sh[3];
-    __syncthreads();
-    return r;
-}
 
 // ------------------------------------------------------------------------------------ rmsnorm
 // transformers Qwen2RMSNorm (reference model.py:206-207,307): w * bf16(x * rsqrt(mean(x^2) + eps))

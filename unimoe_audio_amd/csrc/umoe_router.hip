@@ -530,7 +530,9 @@ extern "C" int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream) 
 // ------------------------------------------------------------------------------------ dispatch
 // grid = n_real workgroups of 256.  Every workgroup counts all experts (to know its own offset),
 // then assigns slots for its expert in token order with ballot/popcount prefix sums.
-__global__ __launch_bounds__(256) void dispatch_kernel(const int32_t* __restrict__ mask, int S, int ld, int n_real,
+// `align` (power of two): every expert's slot range starts on a multiple of it (training: the transposed slot buffers
+// of the weight-gradient GEMMs are read in 16-byte chunks); the padding slots point at token 0 and are never counted
+__global__ __launch_bounds__(256) void dispatch_kernel(const int32_t* __restrict__ mask, int S, int ld, int n_real, int align,
                                                        int32_t* counts, int32_t* offsets, int32_t* slot_token,
                                                        int32_t* slot_of) {
     __shared__ int wave_cnt[4];
@@ -547,12 +549,14 @@ __global__ __launch_bounds__(256) void dispatch_kernel(const int32_t* __restrict
     }
     __syncthreads();
     int off = 0;
-    for (int ee = 0; ee < e; ++ee) off += tot[ee];
+    for (int ee = 0; ee < e; ++ee) off += (tot[ee] + align - 1) & ~(align - 1);
+    const int padded = (tot[e] + align - 1) & ~(align - 1);
     if (tid == 0) {
         counts[e] = tot[e];
         offsets[e] = off;
-        if (e == n_real - 1) offsets[n_real] = off + tot[e];
+        if (e == n_real - 1) offsets[n_real] = off + padded;
     }
+    if (tid < padded - tot[e]) slot_token[off + tot[e] + tid] = 0;
     // pass 2: slots in token order
     int base = off;
     for (int s0 = 0; s0 < S; s0 += 256) {
@@ -580,7 +584,20 @@ extern "C" int umoe_dispatch_build(const int32_t* expert_mask, int S, int ld_mas
     UMOE_REQUIRE(expert_mask && counts && offsets && slot_token && slot_of, "umoe_dispatch_build: null argument");
     UMOE_REQUIRE(n_real >= 1 && n_real <= UMOE_MAXE && ld_mask >= n_real && S >= 0 && S < (1 << 24),
                  "umoe_dispatch_build: bad sizes S=%d n_real=%d ld=%d", S, n_real, ld_mask);
-    dispatch_kernel<<<dim3((unsigned)n_real), 256, 0, (hipStream_t)stream>>>(expert_mask, S, ld_mask, n_real, counts,
+    dispatch_kernel<<<dim3((unsigned)n_real), 256, 0, (hipStream_t)stream>>>(expert_mask, S, ld_mask, n_real, 1, counts,
+                                                                            offsets, slot_token, slot_of);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int umoe_dispatch_build_aligned(const int32_t* expert_mask, int S, int ld_mask, int n_real, int align,
+                                           int32_t* counts, int32_t* offsets, int32_t* slot_token, int32_t* slot_of,
+                                           umoe_stream_t stream) {
+    UMOE_REQUIRE(expert_mask && counts && offsets && slot_token && slot_of, "umoe_dispatch_build_aligned: null argument");
+    UMOE_REQUIRE(n_real >= 1 && n_real <= UMOE_MAXE && ld_mask >= n_real && S >= 0 && S < (1 << 24),
+                 "umoe_dispatch_build_aligned: bad sizes S=%d n_real=%d ld=%d", S, n_real, ld_mask);
+    UMOE_REQUIRE(align >= 1 && align <= 256 && (align & (align - 1)) == 0, "umoe_dispatch_build_aligned: align must be a power of two <= 256");
+    dispatch_kernel<<<dim3((unsigned)n_real), 256, 0, (hipStream_t)stream>>>(expert_mask, S, ld_mask, n_real, align, counts,
                                                                             offsets, slot_token, slot_of);
     UMOE_LAUNCH_CHECK();
     return 0;

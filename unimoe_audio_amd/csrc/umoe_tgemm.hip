@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
     constexpr int NTILE = SW ? 64 : 128;
     const int n0 = blockIdx.x * NTILE;
     if (n0 >= g.n) return;
-    const int K = g.k;
+    const int koff = g.k_off ? *g.k_off : 0;                       // multiple of 8 (aligned dispatch)
+    const int K = g.k_count ? ((*g.k_count + 7) & ~7) : g.k;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
         aok[ps] = r < count;
         long arow = 0;
         if (aok[ps]) arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
-        ap[ps] = p.a + arow * (long)p.lda + g.a_col_off + ch * 8;
+        ap[ps] = p.a + arow * (long)p.lda + g.a_col_off + koff + ch * 8;
         const int tr = lr + 32 * ps;   // tile row 0..127
         int n;
         const uint16_t* wb = g.w;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
             n = n0 + tr;
         }
         wok[ps] = n < g.n;
-        wp[ps] = wb + (long)(wok[ps] ? n : 0) * g.ldw + ch * 8;
+        wp[ps] = wb + (long)(wok[ps] ? n : 0) * g.ldw + koff + ch * 8;
     }
     uint4 ra[4], rw[4];
     auto gload = [&](int k0) {
@@ -142,6 +143,10 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
                     const float up = rbf(acc[j + 2][i][q]);
                     const float si = rbf(gt / (1.0f + expf(-gt)));
                     y[q] = f2bf(si * up);
+                    if (p.aux_out && col + q < g.n) {
+                        p.aux_out[orow * p.ld_aux + col + q] = f2bf(gt);
+                        p.aux_out[orow * p.ld_aux + g.n + col + q] = f2bf(up);
+                    }
                 }
                 uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + col;
                 if (col + 3 < g.n && (p.ldo & 3) == 0) {
@@ -212,7 +217,7 @@ extern "C" int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream) {
     int max_n = 0;
     for (int i = 0; i < a->num_groups; ++i) {
         const umoe_tgroup_t& g = a->groups[i];
-        UMOE_REQUIRE(g.w && g.n > 0 && g.k > 0 && g.k % 8 == 0 && g.ldw % 8 == 0 && g.ldw >= g.k && (g.a_col_off & 7) == 0,
+        UMOE_REQUIRE(g.w && g.n > 0 && (g.k_count || (g.k > 0 && g.k % 8 == 0 && g.ldw >= g.k)) && g.ldw % 8 == 0 && (g.a_col_off & 7) == 0,
                      "umoe_tiled_gemm: group %d: need w, n > 0, k %% 8 == 0, ldw %% 8 == 0 (n=%d k=%d ldw=%d)", i, g.n, g.k, g.ldw);
         UMOE_REQUIRE(a->epilogue != UMOE_EPI_SWIGLU || g.w2, "umoe_tiled_gemm: SwiGLU needs w2 (up_proj)");
         if (g.n > max_n) max_n = g.n;

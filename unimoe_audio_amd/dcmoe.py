@@ -162,8 +162,20 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         x = hidden_states.reshape(S, D).contiguous()
         if x.dtype != torch.bfloat16:
             raise L.UmoeError("hidden_states must be bfloat16")
-        pk = self.prepare()
         n_dyn, n_real, n_fix = self.mlp_dynamic_expert_num, self.mlp_dynamic_real_expert_num, self.mlp_fixed_expert_num
+        if torch.is_grad_enabled() and (hidden_states.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training: forward + backward on the HIP kernels (shipped configuration)
+            if self.token_drop or int(self.dynamic_real_moe.ep_size) > 1 or not self.ignore_differentiable_router:
+                raise NotImplementedError("HIP backward covers the shipped configuration: ignore_differentiable_router=True, "
+                                          "token_drop=False, ep_size=1")
+            if self.training and self.input_jitter_noise > 0:
+                raise NotImplementedError("input_jitter_noise > 0 in training is not on the HIP path yet")
+            for p_ in self.parameters():
+                if p_.dtype != torch.bfloat16 or not p_.is_contiguous():
+                    raise L.UmoeError("training needs contiguous bfloat16 parameters")
+            out, aux, logits, top_k, expert_mask, gw = _DCMoETrainFn.apply(self, x, attention_mask, aux_balance_weight, *_train_params(self))
+            return out.reshape(B, T, D), logits, top_k, expert_mask, gw, aux
+        pk = self.prepare()
         fp32_gate = bool(self.training and self.fp32_gate)                     # core.py:240-249
         if self.training and self.input_jitter_noise > 0:
             raise NotImplementedError("input_jitter_noise > 0 in training is not on the HIP path yet")
@@ -300,3 +312,160 @@ def aux_loss(expert_mask, n_dyn, full_logits, aux_balance_weight=None):
         layers = full_logits.shape[0] // (b * t)                     # core.py:381-383
         tw = aux_balance_weight.reshape(1, b * t).expand(layers, -1).reshape(-1).to(full_logits.device)
     return ops.aux_loss(full_logits, expert_mask, n_dyn, tw)
+
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Training path: forward + backward of the block on the HIP kernels (torch.autograd.Function).
+# Shipped configuration only (ignore_differentiable_router, no token drop, ep_size 1): gradients reach the gate through
+# the softmax multipliers of the mixer's eval branch, the renormalisation and the global routing weight
+# (core.py:115-119,284,178-193), exactly the graph the reference's autograd walks.
+class _DCMoETrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, blk, x, attention_mask, aux_balance_weight, *params):
+        S, D = x.shape
+        n_dyn, n_real, n_fix = blk.mlp_dynamic_expert_num, blk.mlp_dynamic_real_expert_num, blk.mlp_fixed_expert_num
+        I_d, I_s = blk.dynamic_intermediate_size, blk.shared_intermediate_size
+        Imax = max(I_d, I_s if n_fix else 0)
+        gate_w = params[0]
+        ex = [params[1 + 3 * e: 4 + 3 * e] for e in range(n_real)]
+        sh = [params[1 + 3 * n_real + 3 * i: 4 + 3 * n_real + 3 * i] for i in range(n_fix)]
+        fp32_gate = bool(blk.training and blk.fp32_gate)
+        r = ops.router_fwd(x, gate_w, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, top_p=float(blk.mlp_dynamic_top_p),
+                           fixed_top_k=int(blk.mlp_dynamic_top_k), jitter_eps=float(blk.router_jitter_noise),
+                           attn_mask=attention_mask, logits_bf16=not fp32_gate)
+        logits, mask, moe_w, global_w = r["logits"], r["expert_mask"], r["moe_weight"], r["global_weight"]
+        tw = None
+        if aux_balance_weight is not None:
+            b, t = aux_balance_weight.shape
+            tw = aux_balance_weight.reshape(1, b * t).expand(S // (b * t), -1).reshape(-1).to(x.device).float().contiguous()
+        aux = ops.aux_loss(logits, mask, n_dyn, tw)
+        disp = ops.dispatch_build_aligned(mask, n_real, 8)
+        cap = ops._r8(disp["cap"])                       # routed slot rows [0, cap); shared expert i at cap + i*S
+        rows_total = cap + n_fix * S
+        dev = x.device
+        hbuf = torch.empty((rows_total, Imax), dtype=torch.bfloat16, device=dev)
+        gu = torch.empty((rows_total, 2 * Imax), dtype=torch.bfloat16, device=dev)
+        ybuf = torch.empty((rows_total, D), dtype=torch.bfloat16, device=dev)
+        g_gu, g_dn = [], []
+        for e in range(n_real):
+            off, cnt = disp["offsets"][e:e + 1], disp["counts"][e:e + 1]
+            g_gu.append(dict(w=ex[e][0], w2=ex[e][1], rows=disp["slot_token"], row_off=off, count=cnt))
+            g_dn.append(dict(w=ex[e][2], row_off=off, count=cnt))
+        for i in range(n_fix):
+            g_gu.append(dict(w=sh[i][0], w2=sh[i][1], static_count=S, out_row_base=cap + i * S))
+            g_dn.append(dict(w=sh[i][2], static_count=S, a_row_base=cap + i * S, out_row_base=cap + i * S))
+        ops.tiled_gemm(g_gu, x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, aux_out=gu)
+        ops.tiled_gemm(g_dn, hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16)
+        y_sh = ybuf[cap:] if n_fix else None
+        out = ops.combine(ybuf, disp["slot_of"], moe_w, y_sh, global_w, None, n_dyn, n_fix)
+        ctx.blk, ctx.dims = blk, (S, D, n_dyn, n_real, n_fix, I_d, I_s, Imax, cap, rows_total)
+        ctx.disp, ctx.tw = disp, tw
+        ctx.save_for_backward(x, logits, r["sel"], r["top_k"], mask, moe_w, global_w, hbuf, gu, ybuf, *params)
+        top_k = r["top_k"] if blk.mlp_dynamic_top_p != 0 else r["top_k"].to(torch.int32)
+        gw_out = global_w.to(x.dtype)
+        ctx.mark_non_differentiable(logits, top_k, mask, gw_out)
+        return out, aux, logits, top_k, mask, gw_out
+
+    @staticmethod
+    def backward(ctx, d_out, d_aux, *unused):
+        blk, disp = ctx.blk, ctx.disp
+        S, D, n_dyn, n_real, n_fix, I_d, I_s, Imax, cap, rows_total = ctx.dims
+        x, logits, sel, top_k, mask, moe_w, global_w, hbuf, gu, ybuf, *params = ctx.saved_tensors
+        ex = [params[1 + 3 * e: 4 + 3 * e] for e in range(n_real)]
+        sh = [params[1 + 3 * n_real + 3 * i: 4 + 3 * n_real + 3 * i] for i in range(n_fix)]
+        dev, bf = x.device, torch.bfloat16
+        if d_out is None:
+            d_out = torch.zeros((S, D), dtype=bf, device=dev)
+        d_out = d_out.to(bf).contiguous()
+        offs, cnts = disp["offsets"], disp["counts"]
+        total = offs[n_real:n_real + 1]
+        # 1. combine backward: gradients of the expert outputs and of the routing weights
+        dy = torch.empty((rows_total, D), dtype=bf, device=dev)
+        y_sh = ybuf[cap:] if n_fix else None
+        d_mw, d_gs = ops.combine_bwd(d_out, ybuf, disp["slot_of"], moe_w, y_sh, global_w, n_dyn, n_fix, dy, dy[cap:] if n_fix else None)
+        # 2. down projection: dH = dY * Wd  (transposed weight copies as the K-contiguous operand)
+        dh = torch.empty((rows_total, Imax), dtype=bf, device=dev)
+        g = [dict(w=ops.transpose(ex[e][2]), k=D, row_off=offs[e:e + 1], count=cnts[e:e + 1]) for e in range(n_real)]
+        g += [dict(w=ops.transpose(sh[i][2]), k=D, static_count=S, a_row_base=cap + i * S, out_row_base=cap + i * S) for i in range(n_fix)]
+        ops.tiled_gemm(g, dy, dh, max_rows=S, epilogue=ops.EPI_BF16)
+        # 3. SwiGLU backward -> (dgate | dup)
+        dgu = torch.empty((rows_total, 2 * Imax), dtype=bf, device=dev)
+        ops.swiglu_bwd(dh, gu, I_d, dgu, total_rows=total, max_rows=cap)
+        if n_fix:
+            ops.swiglu_bwd(dh[cap:], gu[cap:], I_s, dgu[cap:], total_rows=None, max_rows=n_fix * S)
+        # 4. gate/up projections: dXe = dG * Wg + dU * Wu = [dG | dU] * [Wg^T | Wu^T]^T
+        def gu_t(wg, wu):
+            I = wg.shape[0]
+            t = torch.empty((D, 2 * I), dtype=bf, device=dev)
+            ops.transpose_slots(wg, t[:, :I])
+            ops.transpose_slots(wu, t[:, I:])
+            return t
+        dxe = torch.empty((rows_total, D), dtype=bf, device=dev)
+        g = [dict(w=gu_t(ex[e][0], ex[e][1]), row_off=offs[e:e + 1], count=cnts[e:e + 1]) for e in range(n_real)]
+        g += [dict(w=gu_t(sh[i][0], sh[i][1]), static_count=S, a_row_base=cap + i * S, out_row_base=cap + i * S) for i in range(n_fix)]
+        ops.tiled_gemm(g, dgu, dxe, max_rows=S, epilogue=ops.EPI_BF16)
+        # 5. weight gradients: contraction over the slot columns of transposed buffers
+        Sp = ops._r8(S)
+        ldT = cap + n_fix * Sp
+        def slots_t(src, Ccols, gather=None):
+            t = torch.empty((Ccols, ldT), dtype=bf, device=dev)
+            ops.transpose_slots(src, t, rows=gather, counts=cnts, offsets=offs, n_groups=n_real, max_rows=S, C_cols=Ccols)
+            for i in range(n_fix):
+                s0 = None if gather is not None else src[cap + i * S:]
+                ops.transpose_slots(x if gather is not None else s0, t[:, cap + i * Sp:], max_rows=S, C_cols=Ccols)
+            return t
+        dyT = slots_t(dy, D)
+        hT = slots_t(hbuf, Imax)
+        dguT = slots_t(dgu, 2 * Imax)
+        xeT = slots_t(x, D, gather=disp["slot_token"])
+        grads = [None] * len(params)
+        if n_real:
+            dWd = torch.empty((n_real * D, I_d), dtype=bf, device=dev)
+            ops.tiled_gemm([dict(w=hT[:I_d], static_count=D, out_row_base=e * D, k_off=offs[e:e + 1], k_count=cnts[e:e + 1]) for e in range(n_real)],
+                           dyT, dWd, max_rows=D, epilogue=ops.EPI_BF16)
+            dWg = torch.empty((n_real * I_d, D), dtype=bf, device=dev)
+            dWu = torch.empty((n_real * I_d, D), dtype=bf, device=dev)
+            ops.tiled_gemm([dict(w=xeT, static_count=I_d, out_row_base=e * I_d, k_off=offs[e:e + 1], k_count=cnts[e:e + 1]) for e in range(n_real)],
+                           dguT, dWg, max_rows=I_d, epilogue=ops.EPI_BF16)
+            ops.tiled_gemm([dict(w=xeT, static_count=I_d, a_row_base=I_d, out_row_base=e * I_d, k_off=offs[e:e + 1], k_count=cnts[e:e + 1])
+                            for e in range(n_real)], dguT, dWu, max_rows=I_d, epilogue=ops.EPI_BF16)
+            for e in range(n_real):
+                grads[1 + 3 * e], grads[2 + 3 * e], grads[3 + 3 * e] = dWg[e * I_d:(e + 1) * I_d], dWu[e * I_d:(e + 1) * I_d], dWd[e * D:(e + 1) * D]
+        for i in range(n_fix):
+            c0 = cap + i * Sp
+            a_dy, w_h, a_dgu, w_x = dyT[:, c0:c0 + Sp], hT[:I_s, c0:c0 + Sp], dguT[:, c0:c0 + Sp], xeT[:, c0:c0 + Sp]
+            dWd_i = torch.empty((D, I_s), dtype=bf, device=dev)
+            dWg_i = torch.empty((I_s, D), dtype=bf, device=dev)
+            dWu_i = torch.empty((I_s, D), dtype=bf, device=dev)
+            ops.tiled_gemm([dict(w=w_h, static_count=D)], a_dy, dWd_i, max_rows=D)
+            ops.tiled_gemm([dict(w=w_x, static_count=I_s)], a_dgu, dWg_i, max_rows=I_s)
+            ops.tiled_gemm([dict(w=w_x, static_count=I_s, a_row_base=I_s)], a_dgu, dWu_i, max_rows=I_s)
+            b0 = 1 + 3 * n_real + 3 * i
+            grads[b0], grads[b0 + 1], grads[b0 + 2] = dWg_i, dWu_i, dWd_i
+        # 6. router: d(moe_w), d(shared weights), d(aux) -> d(logits) -> gate weight and input gradients
+        d_lg_aux = None
+        if d_aux is not None:
+            d_lg_aux = ops.aux_loss_bwd(logits, mask, n_dyn, ctx.tw, d_aux)
+        d_lg = ops.router_bwd(logits, sel, top_k, mask, d_mw, d_gs, d_lg_aux, n_dyn, n_real, n_fix, float(blk.router_jitter_noise))
+        E = n_dyn + n_fix
+        dl16 = torch.zeros((S, 16), dtype=bf, device=dev)
+        dl16[:, :E] = d_lg.to(bf)
+        xT = xeT[:, cap:cap + Sp] if n_fix else ops.transpose(x)            # [D][Sp]: the shared experts' gather is the identity
+        dlT = ops.transpose(dl16)                                            # [16][Sp]
+        dWgate = torch.empty((16, D), dtype=bf, device=dev)
+        ops.tiled_gemm([dict(w=xT, static_count=16)], dlT, dWgate, max_rows=16)
+        grads[0] = dWgate[:E]
+        dx_router = ops.tlinear(dl16, ops.transpose(params[0]))              # [S][16] x [D][16]^T
+        # 7. input gradient: slot rows back to tokens + shared experts + router
+        dx = ops.permute_bwd(dxe, disp["slot_of"], dxe[cap:] if n_fix else None, n_fix, extra=dx_router)
+        return (None, dx, None, None, *[gr.contiguous() if gr is not None else None for gr in grads])
+
+
+def _train_params(blk):
+    ps = [blk.gate.weight]
+    for m in blk._experts():
+        ps += [m.gate_proj.weight, m.up_proj.weight, m.down_proj.weight]
+    for m in blk.fixed_real_moe:
+        ps += [m.gate_proj.weight, m.up_proj.weight, m.down_proj.weight]
+    return ps

@@ -20,6 +20,17 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _pv(t: Optional[torch.Tensor]):
+    """pointer of a 2-d row-strided view (unit stride in the last dimension); the kernel gets the row stride separately"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L.UmoeError("umoe ops need device tensors (there is no CPU path in the product)")
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise L.UmoeError("umoe ops need unit stride in the last dimension")
+    return t.data_ptr()
+
+
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
@@ -136,6 +147,19 @@ def dispatch_build(expert_mask: torch.Tensor, n_real: int) -> dict:
              slot_of=torch.empty((S, n_real), dtype=torch.int32, device=dev))
     L.check(L.lib().umoe_dispatch_build(_p(expert_mask), S, ld, n_real, _p(o["counts"]), _p(o["offsets"]),
                                         _p(o["slot_token"]), _p(o["slot_of"]), _stream()), "umoe_dispatch_build")
+    return o
+
+
+def dispatch_build_aligned(expert_mask: torch.Tensor, n_real: int, align: int = 8) -> dict:
+    """Dispatch tables with every expert's slot range starting on a multiple of `align` (training)."""
+    S, ld = expert_mask.shape
+    dev = expert_mask.device
+    cap = S * n_real + n_real * (align - 1)
+    o = dict(counts=torch.zeros(16, dtype=torch.int32, device=dev), offsets=torch.zeros(17, dtype=torch.int32, device=dev),
+             slot_token=torch.zeros(max(1, cap), dtype=torch.int32, device=dev),
+             slot_of=torch.empty((S, n_real), dtype=torch.int32, device=dev), cap=cap)
+    L.check(L.lib().umoe_dispatch_build_aligned(_p(expert_mask), S, ld, n_real, align, _p(o["counts"]), _p(o["offsets"]),
+                                                _p(o["slot_token"]), _p(o["slot_of"]), _stream()), "umoe_dispatch_build_aligned")
     return o
 
 
@@ -331,7 +355,8 @@ def prefetch(t: torch.Tensor, wgs: int = 256, nbytes: Optional[int] = None):
     L.check(L.lib().umoe_prefetch(_p(t), n, wgs, _stream()), "umoe_prefetch")
 
 
-def tiled_gemm(groups: Sequence[dict], a: torch.Tensor, out: torch.Tensor, *, max_rows: int, epilogue=EPI_BF16, resid=None):
+def tiled_gemm(groups: Sequence[dict], a: torch.Tensor, out: torch.Tensor, *, max_rows: int, epilogue=EPI_BF16, resid=None,
+               aux_out: Optional[torch.Tensor] = None):
     """Compute-bound grouped GEMM on ROW-MAJOR weights (umoe_tiled_gemm): each group dict has w [N, K] (and w2 for SwiGLU),
     optional bias / rows / row_off / count tensors and static_count / a_row_base / out_row_base ints."""
     arr = (L.TGroup * len(groups))()
@@ -339,7 +364,7 @@ def tiled_gemm(groups: Sequence[dict], a: torch.Tensor, out: torch.Tensor, *, ma
     for i, g in enumerate(groups):
         w = g["w"]
         assert w.dim() == 2 and w.stride(1) == 1
-        for k in ("w", "w2", "bias", "rows", "row_off", "count"):
+        for k in ("w", "w2", "bias", "rows", "row_off", "count", "k_off", "k_count"):
             t = g.get(k)
             if t is not None:
                 keep.append(t)
@@ -349,8 +374,9 @@ def tiled_gemm(groups: Sequence[dict], a: torch.Tensor, out: torch.Tensor, *, ma
         arr[i].out_row_base = int(g.get("out_row_base", 0))
         arr[i].n, arr[i].k, arr[i].ldw = int(w.shape[0]), int(g.get("k", w.shape[1])), int(w.stride(0))
         arr[i].a_col_off = int(g.get("a_col_off", 0))
-    args = L.TGemmArgs(groups=C.cast(arr, C.c_void_p), num_groups=len(groups), max_rows=max_rows, a=_p(a), lda=a.stride(0),
-                       resid=_p(resid), out=_p(out), ldo=out.stride(-2), epilogue=epilogue)
+    args = L.TGemmArgs(groups=C.cast(arr, C.c_void_p), num_groups=len(groups), max_rows=max_rows, a=_pv(a), lda=a.stride(0),
+                       resid=_p(resid), out=_pv(out), ldo=out.stride(-2), epilogue=epilogue, aux_out=_p(aux_out),
+                       ld_aux=0 if aux_out is None else aux_out.stride(0))
     L.check(L.lib().umoe_tiled_gemm(C.byref(args), _stream()), "umoe_tiled_gemm")
     return out
 
@@ -361,3 +387,84 @@ def tlinear(x: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = 
     out = torch.empty((S, w.shape[0]), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     epi = EPI_F32 if out_f32 else (EPI_BF16_RESID if resid is not None else EPI_BF16)
     return tiled_gemm([dict(w=w, bias=bias, static_count=S)], x, out, max_rows=S, epilogue=epi, resid=resid)
+
+
+# ----------------------------------------------------------------------------- backward pieces (training)
+def _r8(n: int) -> int:
+    return (n + 7) & ~7
+
+
+def transpose_slots(src: torch.Tensor, dst: torch.Tensor, *, rows=None, counts=None, offsets=None, n_groups: int = 1,
+                    max_rows: Optional[int] = None, C_cols: Optional[int] = None):
+    """dst[c][off_g + r] = src[row(off_g + r)][c] (zeros up to the next multiple of 8 columns); plain transpose of the
+    first max_rows rows when counts/offsets are None.  dst may be a column view of a wider buffer (stride(0) % 8 == 0)."""
+    ncol = src.shape[1] if C_cols is None else C_cols
+    mr = src.shape[0] if max_rows is None else max_rows
+    L.check(L.lib().umoe_transpose_slots(_pv(src), src.stride(0), ncol, _p(rows), _p(counts), _p(offsets), n_groups, mr, _pv(dst),
+                                         dst.stride(0), _stream()), "umoe_transpose_slots")
+    return dst
+
+
+def transpose(src: torch.Tensor) -> torch.Tensor:
+    """[R][C] -> [C][roundup8(R)] (zero padded columns): transposed weight copies for the input-gradient GEMMs."""
+    R, Cc = src.shape
+    dst = torch.empty((Cc, _r8(R)), dtype=src.dtype, device=src.device)
+    return transpose_slots(src, dst)
+
+
+def swiglu_bwd(dh: torch.Tensor, gu: torch.Tensor, I: int, dgu: torch.Tensor, *, total_rows: Optional[torch.Tensor], max_rows: int):
+    L.check(L.lib().umoe_swiglu_bwd(_p(dh), dh.stride(0), _p(gu), gu.stride(0), I, _p(total_rows), max_rows, _p(dgu), dgu.stride(0),
+                                    _stream()), "umoe_swiglu_bwd")
+    return dgu
+
+
+def combine_bwd(dout, y_slots, slot_of, moe_w, y_shared, global_w, n_dyn: int, n_fix: int, dy_slots, dy_shared):
+    S, n_real = slot_of.shape
+    D = dout.shape[-1]
+    d_mw = torch.empty((S, n_real), dtype=torch.float32, device=dout.device)
+    d_gs = torch.empty((S, max(1, n_fix)), dtype=torch.float32, device=dout.device) if n_fix else None
+    a = L.CombineArgs(y_slots=_p(y_slots), slot_of=_p(slot_of), moe_w=_p(moe_w), y_shared=_p(y_shared), global_w=_p(global_w),
+                      S=S, D=D, n_real=n_real, n_dyn=n_dyn, n_fix=n_fix, shared_row0=-1)
+    L.check(L.lib().umoe_unpermute_combine_bwd(_p(dout), C.byref(a), _p(dy_slots), _p(dy_shared), _p(d_mw), _p(d_gs), _stream()),
+            "umoe_unpermute_combine_bwd")
+    return d_mw, d_gs
+
+
+def permute_bwd(dxe, slot_of, dx_shared, n_fix: int, extra=None):
+    S, n_real = slot_of.shape
+    D = dxe.shape[-1]
+    dx = torch.empty((S, D), dtype=torch.bfloat16, device=dxe.device)
+    L.check(L.lib().umoe_permute_bwd(_p(dxe), _p(slot_of), n_real, _p(dx_shared), n_fix, S, D, _p(extra), _p(dx), _stream()),
+            "umoe_permute_bwd")
+    return dx
+
+
+def router_bwd(logits, sel, top_k, expert_mask, d_moe_w, d_gw_shared, d_logits_in, n_dyn: int, n_real: int, n_fix: int,
+               jitter_eps: float) -> torch.Tensor:
+    S, E = logits.shape
+    out = torch.empty((S, E), dtype=torch.float32, device=logits.device)
+    L.check(L.lib().umoe_router_bwd(_p(logits), int(logits.dtype == torch.bfloat16), _p(sel), _p(top_k), _p(expert_mask), _p(d_moe_w),
+                                    _p(d_gw_shared), _p(d_logits_in), S, n_dyn, n_real, n_fix, float(jitter_eps), _p(out), _stream()),
+            "umoe_router_bwd")
+    return out
+
+
+def aux_loss_bwd(logits, expert_mask, n_dyn: int, token_weight, d_aux: torch.Tensor) -> torch.Tensor:
+    S, E = logits.shape
+    out = torch.empty((S, E), dtype=torch.float32, device=logits.device)
+    ws = torch.empty(17, dtype=torch.float32, device=logits.device)
+    tw = None if token_weight is None else token_weight.reshape(-1).float().contiguous()
+    L.check(L.lib().umoe_aux_loss_bwd(_p(logits), int(logits.dtype == torch.bfloat16), _p(expert_mask), _p(tw), S, E, n_dyn,
+                                      _p(d_aux.reshape(1).float().contiguous()), _p(out), _p(ws), _stream()), "umoe_aux_loss_bwd")
+    return out
+
+
+def rmsnorm_bwd(h: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, dsum: Optional[torch.Tensor] = None):
+    """Qwen2RMSNorm backward: returns (dh, dw)."""
+    S, D = h.shape
+    dh = torch.empty_like(h)
+    dw = torch.empty_like(w)
+    ws = torch.empty(min(S, 512) * D, dtype=torch.float32, device=h.device)
+    L.check(L.lib().umoe_rmsnorm_residual_bwd(_p(h), _p(w), _p(dy), _p(dsum), eps, S, D, _p(dh), _p(dw), _p(ws), ws.numel(), _stream()),
+            "umoe_rmsnorm_residual_bwd")
+    return dh, dw
