@@ -150,6 +150,50 @@ if "tiled" in which:
         t = timeit(lambda i: ops.linear(xin, wp, 2560), iters=5)
         print(f"weight-streaming qkv M={M}: {t:.1f} us  {2*M*2560*D/t/1e6:.0f} TFLOP/s", flush=True)
 
+if "train" in which:
+    # BASELINE configs[2] shape for ONE DCMoE block: 6240 tokens, full utils/config.json sizes, forward + backward
+    from unimoe_audio_amd.config import UniMoEAudioConfig
+    from unimoe_audio_amd.dcmoe import UniMoEAudioSparseMoeBlock
+    import time
+    cfg = UniMoEAudioConfig()
+    torch.set_default_dtype(torch.bfloat16)
+    with torch.device(dev):
+        blk = UniMoEAudioSparseMoeBlock(cfg)
+    torch.set_default_dtype(torch.float32)
+    with torch.no_grad():
+        for n, p_ in blk.named_parameters():
+            p_.normal_(0, 0.02)
+    blk.train(True)
+    for M in (1560, 6240):
+        xt = (torch.randn(1, M, D, device=dev) * 1.0).to(torch.bfloat16).requires_grad_(True)
+        Gt = torch.randn(1, M, D, device=dev).to(torch.bfloat16)
+        def step():
+            for p_ in blk.parameters():
+                p_.grad = None
+            o = blk(xt, None, None)
+            ((o[0].float() * Gt.float()).sum() + 0.01 * o[5].float()).backward()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_it = 5
+        for _ in range(n_it):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_it
+        with torch.no_grad():
+            o = blk(xt.detach(), None, None)
+            kreal = float(o[3][:, :8].sum()) / M
+        flops = 3 * 2 * M * (kreal * 3 * Id * D + 2 * 3 * Is * D)       # fwd + 2x bwd, routed k_real + 2 shared experts
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_it):
+            with torch.no_grad():
+                blk(xt.detach(), None, None)
+        torch.cuda.synchronize()
+        dtf = (time.perf_counter() - t0) / n_it
+        print(f"DCMoE block M={M}: fwd+bwd {dt*1e3:.2f} ms ({flops/dt/1e12:.0f} TFLOP/s algorithmic, k_real={kreal:.2f}), fwd only {dtf*1e3:.2f} ms", flush=True)
+
 if "router" in which:
     gw = rnd(11, D)
     nw = torch.ones(D, device=dev, dtype=torch.bfloat16)

@@ -342,6 +342,54 @@ def test_dcmoe_block_backward_vs_reference_autograd(dev, path):
     assert worst[1] < 0.03, (worst, errs)
 
 
+def test_dcmoe_block_backward_multitile_vs_autograd_oracle(dev):
+    """Many rows per expert (several 128-row tiles, several 64-deep K steps in the weight-gradient contractions),
+    padding mask and aux weights: HIP forward/backward against the differentiable CPU oracle (itself pinned to the
+    reference's autograd by the dcmoebwd fixtures)."""
+    from oracle import dcmoe_autograd as OA
+    cfgd = dict(hidden_size=256, mlp_dynamic_expert_num=8, mlp_dynamic_null_expert_num=1, mlp_dynamic_top_p=0.7,
+                mlp_dynamic_top_k=2, mlp_fixed_expert_num=2, ignore_differentiable_router=True, ep_size=1,
+                router_jitter_noise=0.01, input_jitter_noise=0.0, min_capacity=8, capacity_factor=6.0, token_drop=False,
+                drop_policy="probs", avg_hidden_states_last=False, drop_token_num_print=False, fp32_gate=True,
+                dynamic_intermediate_size=352, shared_intermediate_size=176, hidden_act="silu",
+                enable_expert_tensor_parallelism=False)
+    cfg = types.SimpleNamespace(**cfgd)
+    gen = torch.Generator().manual_seed(77)
+    D, Id, Is = 256, 352, 176
+    w = {"gate.weight": (torch.randn(11, D, generator=gen) * 0.2).to(torch.bfloat16)}
+    for e in range(8):
+        for p_, shp in (("gate", (Id, D)), ("up", (Id, D)), ("down", (D, Id))):
+            w[OA.EXPERT_FMT.format(e=e, p=p_)] = (torch.randn(*shp, generator=gen) * 0.05).to(torch.bfloat16)
+    for i in range(2):
+        for p_, shp in (("gate", (Is, D)), ("up", (Is, D)), ("down", (D, Is))):
+            w[OA.SHARED_FMT.format(i=i, p=p_)] = (torch.randn(*shp, generator=gen) * 0.05).to(torch.bfloat16)
+    B, T = 2, 450
+    x = torch.randn(B, T, D, generator=gen).to(torch.bfloat16)
+    G = torch.randn(B, T, D, generator=gen).to(torch.bfloat16)
+    am = torch.ones(B, T, dtype=torch.bool)
+    am[0, :37] = False
+    aw = torch.rand(B, T, generator=gen)
+    wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    xo = x.clone().requires_grad_(True)
+    ro = OA.forward(cfg, wo, xo, am, aw, training=True)
+    ((ro[0].float() * G.float()).sum() + 0.5 * ro[5].float()).backward()
+    blk = _mk_block(cfgd, w, dev)
+    blk.train(True)
+    for p_ in blk.parameters():
+        p_.requires_grad_(True)
+    xg = x.to(dev).requires_grad_(True)
+    rg = blk(xg, am.to(dev), aw.to(dev))
+    ((rg[0].float() * G.to(dev).float()).sum() + 0.5 * rg[5].float()).backward()
+    same = (rg[3].cpu() == ro[3]).all(-1)
+    assert same.float().mean() > 0.97            # fp32 gate logits differ in the last bits: a few near-ties may flip
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+    assert rel(rg[0].detach().cpu().reshape(-1, D)[same], ro[0].detach().reshape(-1, D)[same]) < 0.01
+    tol = 0.03 if bool(same.all()) else 0.08     # a flipped token moves one row between two experts' gradients
+    assert rel(xg.grad.cpu().reshape(-1, D)[same], xo.grad.reshape(-1, D)[same]) < tol
+    for n, p_ in blk.named_parameters():
+        assert rel(p_.grad.cpu(), wo[n].grad) < tol, (n, rel(p_.grad.cpu(), wo[n].grad))
+
+
 def test_dcmoe_block_fullsize_vs_oracle(dev):
     """Full utils/config.json sizes, 16 rows (decode shape) and 300 rows, against the CPU oracle."""
     from oracle.dcmoe import DCMoEOracle

@@ -168,8 +168,6 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
             if self.token_drop or int(self.dynamic_real_moe.ep_size) > 1 or not self.ignore_differentiable_router:
                 raise NotImplementedError("HIP backward covers the shipped configuration: ignore_differentiable_router=True, "
                                           "token_drop=False, ep_size=1")
-            if self.training and self.input_jitter_noise > 0:
-                raise NotImplementedError("input_jitter_noise > 0 in training is not on the HIP path yet")
             for p_ in self.parameters():
                 if p_.dtype != torch.bfloat16 or not p_.is_contiguous():
                     raise L.UmoeError("training needs contiguous bfloat16 parameters")
@@ -177,9 +175,11 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
             return out.reshape(B, T, D), logits, top_k, expert_mask, gw, aux
         pk = self.prepare()
         fp32_gate = bool(self.training and self.fp32_gate)                     # core.py:240-249
-        if self.training and self.input_jitter_noise > 0:
-            raise NotImplementedError("input_jitter_noise > 0 in training is not on the HIP path yet")
-        r = ops.router_fwd(x, self.gate.weight.data, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix,
+        xg = x
+        if self.training and self.input_jitter_noise > 0:                      # core.py:243-244: the gate's copy only
+            xg = (x.float() * torch.empty((S, D), dtype=torch.float32, device=x.device).uniform_(
+                1.0 - self.input_jitter_noise, 1.0 + self.input_jitter_noise)).to(torch.bfloat16)
+        r = ops.router_fwd(xg, self.gate.weight.data, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix,
                            top_p=float(self.mlp_dynamic_top_p), fixed_top_k=int(self.mlp_dynamic_top_k),
                            jitter_eps=float(self.router_jitter_noise), attn_mask=attention_mask,
                            logits_bf16=not fp32_gate)
@@ -331,7 +331,15 @@ class _DCMoETrainFn(torch.autograd.Function):
         ex = [params[1 + 3 * e: 4 + 3 * e] for e in range(n_real)]
         sh = [params[1 + 3 * n_real + 3 * i: 4 + 3 * n_real + 3 * i] for i in range(n_fix)]
         fp32_gate = bool(blk.training and blk.fp32_gate)
-        r = ops.router_fwd(x, gate_w, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, top_p=float(blk.mlp_dynamic_top_p),
+        # input jitter (core.py:243-244): multiplicative uniform noise on the GATE's copy of the input only; the noise
+        # tensor is drawn with torch's device RNG (a stochastic regulariser: no bit parity with the CPU generator exists)
+        noise = None
+        xg = x
+        if blk.training and blk.input_jitter_noise > 0:
+            noise = torch.empty((S, D), dtype=torch.float32, device=x.device).uniform_(1.0 - blk.input_jitter_noise,
+                                                                                       1.0 + blk.input_jitter_noise)
+            xg = (x.float() * noise).to(torch.bfloat16)
+        r = ops.router_fwd(xg, gate_w, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, top_p=float(blk.mlp_dynamic_top_p),
                            fixed_top_k=int(blk.mlp_dynamic_top_k), jitter_eps=float(blk.router_jitter_noise),
                            attn_mask=attention_mask, logits_bf16=not fp32_gate)
         logits, mask, moe_w, global_w = r["logits"], r["expert_mask"], r["moe_weight"], r["global_weight"]
@@ -360,7 +368,7 @@ class _DCMoETrainFn(torch.autograd.Function):
         y_sh = ybuf[cap:] if n_fix else None
         out = ops.combine(ybuf, disp["slot_of"], moe_w, y_sh, global_w, None, n_dyn, n_fix)
         ctx.blk, ctx.dims = blk, (S, D, n_dyn, n_real, n_fix, I_d, I_s, Imax, cap, rows_total)
-        ctx.disp, ctx.tw = disp, tw
+        ctx.disp, ctx.tw, ctx.noise = disp, tw, noise
         ctx.save_for_backward(x, logits, r["sel"], r["top_k"], mask, moe_w, global_w, hbuf, gu, ybuf, *params)
         top_k = r["top_k"] if blk.mlp_dynamic_top_p != 0 else r["top_k"].to(torch.int32)
         gw_out = global_w.to(x.dtype)
@@ -451,12 +459,18 @@ class _DCMoETrainFn(torch.autograd.Function):
         E = n_dyn + n_fix
         dl16 = torch.zeros((S, 16), dtype=bf, device=dev)
         dl16[:, :E] = d_lg.to(bf)
-        xT = xeT[:, cap:cap + Sp] if n_fix else ops.transpose(x)            # [D][Sp]: the shared experts' gather is the identity
+        noise = ctx.noise
+        if noise is not None:
+            xT = ops.transpose((x.float() * noise).to(bf))                   # the gate saw the jittered input
+        else:
+            xT = xeT[:, cap:cap + Sp] if n_fix else ops.transpose(x)        # [D][Sp]: the shared experts' gather is the identity
         dlT = ops.transpose(dl16)                                            # [16][Sp]
         dWgate = torch.empty((16, D), dtype=bf, device=dev)
         ops.tiled_gemm([dict(w=xT, static_count=16)], dlT, dWgate, max_rows=16)
         grads[0] = dWgate[:E]
         dx_router = ops.tlinear(dl16, ops.transpose(params[0]))              # [S][16] x [D][16]^T
+        if noise is not None:
+            dx_router = (dx_router.float() * noise).to(bf)
         # 7. input gradient: slot rows back to tokens + shared experts + router
         dx = ops.permute_bwd(dxe, disp["slot_of"], dxe[cap:] if n_fix else None, n_fix, extra=dx_router)
         return (None, dx, None, None, *[gr.contiguous() if gr is not None else None for gr in grads])
