@@ -182,6 +182,7 @@ typedef struct {
     int a_col_off;
     const int32_t* k_off;     /* optional device scalars: contract over columns [*k_off, *k_off + roundup8(*k_count)) of BOTH */
     const int32_t* k_count;   /* operands instead of [0, k) -- weight gradients over one expert's (8-aligned) slot range */
+    int out_col_off;          /* element offset added to every output row of this group (attention heads side by side) */
 } umoe_tgroup_t;
 
 typedef struct {
@@ -303,6 +304,21 @@ typedef struct {
     uint16_t* v_cache;
 } umoe_rope_args;
 int umoe_qkv_mrope_kvappend(const umoe_rope_args* a, umoe_stream_t stream);
+
+/* Attention backward, training path (reference: eager_attention_forward of the transformers dependency called at
+ * model.py:228-237; fp32 softmax, probabilities cast to bf16).  The contractions run on umoe_tiled_gemm over materialised
+ * score tiles; these are the row-wise pieces.  scores [heads*Tp][ld] fp32 raw Q K^T, row h*Tp + t sees keys [kv_start, t]:
+ * p_out = bf16(softmax(scale * scores)), zero elsewhere (including the padding columns up to ld_p).
+ * backward: ds = bf16(scale * p o (dp - sum_j dp_j p_j)). */
+int umoe_attn_softmax_fwd(const float* scores, int ld, int heads, int T, int Tp, int kv_start, float scale, uint16_t* p_out,
+                          int ld_p, umoe_stream_t stream);
+int umoe_attn_softmax_bwd(const uint16_t* p, const uint16_t* dp, int ld, int heads, int T, int Tp, float scale, uint16_t* ds,
+                          umoe_stream_t stream);
+/* backward of umoe_qkv_mrope_kvappend: dq [n_tok][H*hd], dk / dv in cache layout -> d(qkv) [n_tok][(H+2KVH)*hd] */
+int umoe_qkv_mrope_bwd(const umoe_rope_args* a, const uint16_t* dq, const uint16_t* dk_cache, const uint16_t* dv_cache,
+                       uint16_t* dqkv, umoe_stream_t stream);
+
+
 
 /* Attention over the cache for nq query tokens per row (nq=1 decode, nq=T causal prefill).
  * q [rows*nq][H*hd]; query t of a row sees cache slots [kv_start[row], q_pos0[row] + t].

@@ -38,16 +38,24 @@ def _top_p_count(dyn_logits: torch.Tensor, top_p: float) -> torch.Tensor:
         return (~(ps.cumsum(dim=-1) >= top_p)).sum(dim=-1) + 1
 
 
-def routing_weights(dyn_logits: torch.Tensor, k: torch.Tensor, jitter_eps: float):
-    """-> (weights [S, n_dyn] differentiable, selection mask [S, n_dyn] int): round j acts on the tokens with k > j."""
+def routing_weights(dyn_logits: torch.Tensor, k: torch.Tensor, jitter_eps: float, forced_set: Optional[torch.Tensor] = None):
+    """-> (weights [S, n_dyn] differentiable, selection mask [S, n_dyn] int): round j acts on the tokens with k > j.
+    forced_set [S, n_dyn] bool (tests only): rows whose set has exactly k members pick inside that set -- teacher forcing of
+    the integer decisions when two runs are compared whose logits differ in the last bits (near-ties would flip)."""
     S, n = dyn_logits.shape
     taken = torch.zeros((S, n), dtype=torch.bool)
     w = torch.zeros_like(dyn_logits)
+    use = None
+    if forced_set is not None:
+        use = (forced_set.sum(-1) == k).unsqueeze(-1)
     for j in range(int(k.max()) if S else 0):
         live = (k > j).unsqueeze(-1)
         masked = dyn_logits.masked_fill(taken, float("-inf"))
         with torch.no_grad():
             mx, idx = masked.max(dim=-1, keepdim=True)
+            if use is not None:
+                _, idx_f = masked.masked_fill(~forced_set, float("-inf")).max(dim=-1, keepdim=True)
+                idx = torch.where(use & live, idx_f, idx)       # the threshold reference mx stays the row maximum
             factor = dyn_logits.abs().clamp(min=mx.abs())
             far = ((mx - dyn_logits) / factor) > (2 * jitter_eps)
         p = torch.softmax(masked.masked_fill(far, float("-inf")), dim=-1)
@@ -69,7 +77,7 @@ def aux_loss(mask: torch.Tensor, n_dyn: int, logits: torch.Tensor, aux_balance_w
 
 
 def forward(cfg, weights: Dict[str, torch.Tensor], hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-            aux_balance_weight: Optional[torch.Tensor] = None, training: bool = True):
+            aux_balance_weight: Optional[torch.Tensor] = None, training: bool = True, forced=None):
     """-> (out [B,T,D], logits, top_k, expert_mask, global_weight, aux); differentiable in hidden_states and weights."""
     assert cfg.ignore_differentiable_router and not cfg.token_drop
     B, T, D = hidden_states.shape
@@ -86,7 +94,11 @@ def forward(cfg, weights: Dict[str, torch.Tensor], hidden_states: torch.Tensor, 
         k = _top_p_count(dyn, float(cfg.mlp_dynamic_top_p))
     else:
         k = torch.full((dyn.shape[0],), int(cfg.mlp_dynamic_top_k), dtype=torch.int64)
-    rw, sel = routing_weights(dyn, k, float(cfg.router_jitter_noise))
+    forced_set = None
+    if forced is not None:                                     # (top_k [S], expert_mask [S, E]) of another run: teacher forcing
+        k = forced[0].long()
+        forced_set = forced[1][:, :n_dyn] != 0
+    rw, sel = routing_weights(dyn, k, float(cfg.router_jitter_noise), forced_set)
     rw = rw / (rw.sum(dim=-1, keepdim=True) + 1e-6)
     mask = torch.cat([sel, torch.zeros((sel.shape[0], n_fix), dtype=torch.int32)], dim=-1)
     if attention_mask is not None:

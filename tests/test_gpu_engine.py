@@ -235,3 +235,59 @@ def test_model_forward_hidden_router_stats_and_loss(dev):
     ref_loss = ce + cfg.l_aux_weight * aux
     assert abs(float(out.loss) - float(ref_loss)) < 0.03 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
     assert gm.training_steps == 1 and gm.cur_aux_weight < cfg.l_aux_weight
+
+
+# ----------------------------------------------------------------------------- training step (BASELINE configs[2] path)
+def test_training_step_vs_autograd_oracle(dev):
+    """Forward + backward of the whole model (embeddings -> 2 decoder layers -> codec head -> shifted per-channel CE +
+    aux) on the HIP kernels (unimoe_audio_amd/train.py) against the differentiable CPU oracle (oracle/train_autograd.py):
+    loss within 1 %, parameter gradients by relative Frobenius error (bf16 chains on both sides; left padding, ragged
+    experts, GQA, mRoPE all exercised): dense parameters < 10 % (median < 4 %), routed experts / gates median < 6 %."""
+    from unimoe_audio_amd import train as TR
+    from oracle import train_autograd as OT
+    cfg = small_cfg()
+    m, w = build(cfg, 3, 0.05)
+    B, T = 2, 40
+    ids, am, codec = prompt(cfg, 1, T, 5, [6, 0])
+    torch.manual_seed(9)
+    labels = torch.randint(0, 1024, (B, T, cfg.codec_channels))
+    labels[:, :8] = -100
+    labels[0, :, 7:] = -100
+    labels[1, :, 10:] = -100                      # channels 10, 11 have no valid label at all in row 1 only
+    labels[:, :, 11] = -100                       # channel 11: no labels anywhere -> skipped (model.py:837-838)
+    gm = m.to(dev).train()
+    for p_ in gm.parameters():
+        p_.requires_grad_(True)
+    auxw = float(gm.cur_aux_weight)
+    loss, closs, auxm, routing = TR.forward_train(gm, ids, codec, am, labels, return_routing=True)
+    loss.backward()
+    wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    # teacher-forced integer routing: the GPU's fp32 gate logits differ from the CPU's in the last bits, and a token that
+    # flips between two experts on a near-tie changes whole gradient tensors of small experts -- integers are compared
+    # separately (bit-exact given identical logits, test_gpu_ops.py), here they are forced so that the FLOAT path is compared
+    forced = [(k_.cpu(), m_.cpu()) for k_, m_ in routing]
+    lo, clo, auxo, _ = OT.forward_loss(cfg, wo, ids, codec, am, labels, auxw, training=True, forced=forced)
+    lo.backward()
+    lo_free, _, _, _ = OT.forward_loss(cfg, {k: v for k, v in w.items()}, ids, codec, am, labels, auxw, training=True)
+    assert abs(float(loss) - float(lo_free)) < 0.01 * abs(float(lo_free))       # free-running loss agrees too
+    assert abs(float(loss) - float(lo)) < 0.01 * abs(float(lo)), (float(loss), float(lo))
+    assert abs(float(auxm) - float(auxo)) < 0.03 * abs(float(auxo)) + 1e-3
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+    worst = []
+    for n, p_ in gm.named_parameters():
+        ref = wo[n].grad
+        if ref is None or float(ref.float().norm()) == 0.0:
+            continue
+        assert p_.grad is not None, n
+        worst.append((rel(p_.grad.cpu(), ref), n))
+    worst.sort(reverse=True)
+    assert len(worst) > 40
+    # dense parameters (attention, norms, shared experts, embeddings, head, gates): every token contributes -> tight bound.
+    # routed experts: a handful of tokens each at this size; one token whose jitter-threshold membership (core.py:105-109,
+    # a discrete decision on nearly equal logits) differs between the two runs changes its routing weight by a factor,
+    # so single small experts may deviate more; their median must still be tight.
+    discrete = lambda n: "deepspeed_experts" in n or n.endswith("mlp.gate.weight")     # fed by / feeding the discrete decisions
+    dense = [e for e in worst if not discrete(e[1])]
+    routed = sorted(e[0] for e in worst if discrete(e[1]))
+    assert dense[0][0] < 0.10 and dense[len(dense) // 2][0] < 0.04, dense[:6]
+    assert routed[len(routed) // 2] < 0.06 and routed[-1] < 0.30, routed[-6:]

@@ -52,7 +52,7 @@ class GemmArgs(C.Structure):
 
 class TGroup(C.Structure):
     _fields_ = [("w", vp), ("w2", vp), ("bias", vp), ("rows", vp), ("row_off", vp), ("count", vp), ("static_count", i32),
-                ("a_row_base", i32), ("out_row_base", i32), ("n", i32), ("k", i32), ("ldw", i32), ("a_col_off", i32), ("k_off", vp), ("k_count", vp)]
+                ("a_row_base", i32), ("out_row_base", i32), ("n", i32), ("k", i32), ("ldw", i32), ("a_col_off", i32), ("k_off", vp), ("k_count", vp), ("out_col_off", i32)]
 
 
 class TGemmArgs(C.Structure):
@@ -116,7 +116,7 @@ EXPORTS = [
     "umoe_rvq_nearest", "umoe_codec_ce_fwd", "umoe_codec_ce_bwd", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
     "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
     "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm", "umoe_dispatch_build_aligned", "umoe_transpose_slots", "umoe_swiglu_bwd",
-    "umoe_unpermute_combine_bwd", "umoe_permute_bwd", "umoe_router_bwd", "umoe_rmsnorm_residual_bwd", "umoe_aux_loss_bwd",
+    "umoe_unpermute_combine_bwd", "umoe_permute_bwd", "umoe_router_bwd", "umoe_rmsnorm_residual_bwd", "umoe_aux_loss_bwd", "umoe_attn_softmax_fwd", "umoe_attn_softmax_bwd", "umoe_qkv_mrope_bwd",
 ]
 
 
@@ -150,6 +150,9 @@ def lib():
         L.umoe_rmsnorm_residual_bwd.argtypes = [vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, C.c_size_t, vp]
         L.umoe_dispatch_build_aligned.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]
         L.umoe_aux_loss_bwd.argtypes = [vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+        L.umoe_attn_softmax_fwd.argtypes = [vp, i32, i32, i32, i32, i32, f32, vp, i32, vp]
+        L.umoe_attn_softmax_bwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp]
+        L.umoe_qkv_mrope_bwd.argtypes = [C.POINTER(RopeArgs), vp, vp, vp, vp, vp]
         L.umoe_router_dispatch_fwd.argtypes = [C.POINTER(RouterArgs), vp, vp, vp, vp, vp]
         L.umoe_permute_fwd.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.umoe_grouped_gemm.argtypes = [C.POINTER(GemmArgs), vp]

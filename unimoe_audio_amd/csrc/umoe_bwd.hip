@@ -559,3 +559,114 @@ extern "C" int umoe_aux_loss_bwd(const void* logits, int logits_bf16, const int3
     UMOE_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ attention backward pieces
+// Training-path attention backward recomputes P = softmax(scale * Q K^T + causal / left-padding mask) from materialised
+// score tiles (umoe_tiled_gemm, fp32 raw epilogue) -- "unfused" on purpose for the first version: every contraction runs
+// on the verified tiled GEMM, these two kernels do the row-wise part (eager_attention_forward semantics of the
+// reference's transformers dependency: fp32 softmax, probabilities cast to bf16).
+// scores [rows][ld] fp32, row = (head-in-group, query t) at h * Tp + t; keys [kv_start, t] are visible.
+__global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restrict__ sc, int ld, int T, int Tp, int kv_start, float scale,
+                                                           uint16_t* __restrict__ p_out, int ld_p) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;                 // h * Tp + t
+    const int t = row % Tp;
+    if (t >= T) return;
+    const float* s = sc + (size_t)row * ld;
+    uint16_t* po = p_out + (size_t)row * ld_p;
+    float mx = -INFINITY;
+    for (int j = kv_start + threadIdx.x; j <= t; j += 256) mx = fmaxf(mx, s[j] * scale);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = kv_start + threadIdx.x; j <= t; j += 256) sum += expf(s[j] * scale - mx);
+    sum = block_sum_256(sum, sh);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    for (int j = threadIdx.x; j < ld_p; j += 256) {
+        float v = 0.f;
+        if (j >= kv_start && j <= t) v = expf(s[j] * scale - mx) * inv;
+        po[j] = f2bf(v);
+    }
+}
+
+// dS = scale * P o (dP - sum_j dP_j P_j)   (softmax backward in fp32, rounded to bf16; masked keys stay 0)
+__global__ __launch_bounds__(256) void attn_softmax_bwd_kernel(const uint16_t* __restrict__ p, const uint16_t* __restrict__ dp, int ld,
+                                                               int T, int Tp, float scale, uint16_t* __restrict__ ds) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x;
+    const int t = row % Tp;
+    if (t >= T) return;
+    const uint16_t* pr = p + (size_t)row * ld;
+    const uint16_t* dr = dp + (size_t)row * ld;
+    float dot = 0.f;
+    for (int j = threadIdx.x; j <= t; j += 256) dot += bf2f(pr[j]) * bf2f(dr[j]);
+    dot = block_sum_256(dot, sh);
+    uint16_t* o = ds + (size_t)row * ld;
+    for (int j = threadIdx.x; j < ld; j += 256) {
+        float v = 0.f;
+        if (j <= t) v = scale * bf2f(pr[j]) * (bf2f(dr[j]) - dot);
+        o[j] = f2bf(v);
+    }
+}
+
+extern "C" int umoe_attn_softmax_fwd(const float* scores, int ld, int heads, int T, int Tp, int kv_start, float scale, uint16_t* p_out,
+                                     int ld_p, umoe_stream_t stream) {
+    UMOE_REQUIRE(scores && p_out && heads > 0 && T > 0 && Tp >= T && ld >= T && ld_p >= T, "umoe_attn_softmax_fwd: bad argument");
+    attn_softmax_kernel<<<dim3((unsigned)(heads * Tp)), 256, 0, (hipStream_t)stream>>>(scores, ld, T, Tp, kv_start, scale, p_out, ld_p);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int umoe_attn_softmax_bwd(const uint16_t* p, const uint16_t* dp, int ld, int heads, int T, int Tp, float scale, uint16_t* ds,
+                                     umoe_stream_t stream) {
+    UMOE_REQUIRE(p && dp && ds && heads > 0 && T > 0 && Tp >= T && ld >= T, "umoe_attn_softmax_bwd: bad argument");
+    attn_softmax_bwd_kernel<<<dim3((unsigned)(heads * Tp)), 256, 0, (hipStream_t)stream>>>(p, dp, ld, T, Tp, scale, ds);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ mRoPE backward
+// forward (umoe_qkv_mrope_kvappend): q_r = q*cos + rot(q)*sin, k likewise into the cache, v copied.  The rotation is
+// orthogonal: d(x) = dy*cos - rot(dy)*sin.  Inputs: dq [n_tok][H*hd], dk / dv in cache layout [rows][KVH][Lmax][hd];
+// output d_qkv [n_tok][(H + 2 KVH)*hd] (the gradient of the bias-added QKV projection).
+__global__ __launch_bounds__(256) void rope_bwd_kernel(const umoe_rope_args a, const uint16_t* __restrict__ dq, const uint16_t* __restrict__ dk,
+                                                       const uint16_t* __restrict__ dv, uint16_t* __restrict__ dqkv) {
+    const int tok = blockIdx.x;
+    const int row = tok / a.T, t = tok - row * a.T;
+    const int hd = a.hd, half = hd >> 1;
+    const int QKV = (a.H + 2 * a.KVH) * hd;
+    const int p0 = a.pos3[tok], p1 = a.pos3[a.n_tok + tok], p2 = a.pos3[2 * a.n_tok + tok];
+    const int slot = a.kv_pos[tok];
+    for (int idx = threadIdx.x; idx < (a.H + 2 * a.KVH) * hd; idx += 256) {
+        const int head = idx / hd, d = idx - head * hd;
+        float out;
+        if (head < a.H + a.KVH) {
+            const uint16_t* src = head < a.H ? dq + (size_t)tok * a.H * hd + (size_t)head * hd
+                                             : dk + (((size_t)row * a.KVH + (head - a.H)) * a.Lmax + slot) * hd;
+            const int i = d % half;
+            const int pos = (i < a.sec0) ? p0 : (i < a.sec0 + a.sec1 ? p1 : p2);
+            const float c = bf2f(a.cos_tab[(size_t)pos * half + i]), sn = bf2f(a.sin_tab[(size_t)pos * half + i]);
+            const float y = bf2f(src[d]);
+            const float yr = d < half ? -bf2f(src[d + half]) : bf2f(src[d - half]);   // rot(dy)
+            out = rbf(y * c) - rbf(yr * sn);
+        } else {
+            out = bf2f(dv[(((size_t)row * a.KVH + (head - a.H - a.KVH)) * a.Lmax + slot) * hd + d]);
+        }
+        dqkv[(size_t)tok * QKV + idx] = f2bf(out);
+    }
+    (void)t;
+}
+
+extern "C" int umoe_qkv_mrope_bwd(const umoe_rope_args* a, const uint16_t* dq, const uint16_t* dk_cache, const uint16_t* dv_cache,
+                                  uint16_t* dqkv, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->cos_tab && a->sin_tab && a->pos3 && a->kv_pos && dq && dk_cache && dv_cache && dqkv, "umoe_qkv_mrope_bwd: null argument");
+    UMOE_REQUIRE(a->hd % 2 == 0 && a->sec0 + a->sec1 + a->sec2 == a->hd / 2 && a->T >= 1 && a->n_tok % a->T == 0,
+                 "umoe_qkv_mrope_bwd: bad head_dim/sections/T");
+    if (a->n_tok == 0) return 0;
+    rope_bwd_kernel<<<dim3((unsigned)a->n_tok), 256, 0, (hipStream_t)stream>>>(*a, dq, dk_cache, dv_cache, dqkv);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
         const int r = row0 + 64 * wm + 16 * i + c16;
         if (r >= count) continue;
         const long orow = (long)g.out_row_base + roff + r;
+        const int oc = g.out_col_off;
         if (SW) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
                         p.aux_out[orow * p.ld_aux + g.n + col + q] = f2bf(up);
                     }
                 }
-                uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + col;
-                if (col + 3 < g.n && (p.ldo & 3) == 0) {
+                uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + oc + col;
+                if (col + 3 < g.n && ((p.ldo | oc) & 3) == 0) {
                     *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
                 } else {
 #pragma unroll
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = acc[j][i][q] + ((g.bias && col + q < g.n) ? g.bias[col + q] : 0.f);
                 if (EPI == UMOE_EPI_F32 || EPI == UMOE_EPI_F32_RAW) {
-                    float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + col;
+                    float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + oc + col;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         if (col + q < g.n) o[q] = (EPI == UMOE_EPI_F32) ? rbf(v[q]) : v[q];
@@ -175,11 +176,11 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float x = rbf(v[q]);
-                        if (EPI == UMOE_EPI_BF16_RESID && col + q < g.n) x = bf2f(p.resid[orow * p.ldo + col + q]) + x;
+                        if (EPI == UMOE_EPI_BF16_RESID && col + q < g.n) x = bf2f(p.resid[orow * p.ldo + oc + col + q]) + x;
                         y[q] = f2bf(x);
                     }
-                    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + col;
-                    if (col + 3 < g.n && (p.ldo & 3) == 0) {
+                    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + oc + col;
+                    if (col + 3 < g.n && ((p.ldo | oc) & 3) == 0) {
                         *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
                     } else {
 #pragma unroll

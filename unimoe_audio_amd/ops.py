@@ -374,6 +374,7 @@ def tiled_gemm(groups: Sequence[dict], a: torch.Tensor, out: torch.Tensor, *, ma
         arr[i].out_row_base = int(g.get("out_row_base", 0))
         arr[i].n, arr[i].k, arr[i].ldw = int(w.shape[0]), int(g.get("k", w.shape[1])), int(w.stride(0))
         arr[i].a_col_off = int(g.get("a_col_off", 0))
+        arr[i].out_col_off = int(g.get("out_col_off", 0))
     args = L.TGemmArgs(groups=C.cast(arr, C.c_void_p), num_groups=len(groups), max_rows=max_rows, a=_pv(a), lda=a.stride(0),
                        resid=_p(resid), out=_pv(out), ldo=out.stride(-2), epilogue=epilogue, aux_out=_p(aux_out),
                        ld_aux=0 if aux_out is None else aux_out.stride(0))

@@ -1,0 +1,244 @@
+"""Training path (BASELINE configs[2]: forward + backward of the 36-layer DCMoE text model + codec head + CE).
+
+torch.autograd.Function wrappers whose forward AND backward run on the HIP kernels behind the C-ABI (include/umoe.h);
+torch itself only owns the tape, the tensors and a few glue elementwise ops (residual adds, embedding gathers).
+Reference graph: Qwen2_5_VLMoEDecoderLayer.forward utils/UniMoE_Audio_model.py:210-256, text model :319-457,
+training loss :817-854; attention / RMSNorm / mRoPE arithmetic = the transformers classes imported at :52-56.
+
+Backward of the contractions: umoe_tiled_gemm needs K-contiguous operands, so dX = dY W uses a transposed weight copy and
+dW = dY^T X contracts over token columns of transposed activations (umoe_transpose_slots).  Attention backward is the
+"unfused" first version: scores are materialised per (row, kv head) group, P is recomputed, every contraction is a tiled
+GEMM (see umoe_bwd.hip).  No CPU fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def _pad8(t: torch.Tensor) -> torch.Tensor:
+    """rows of a K-contiguous GEMM operand must start on 16-byte boundaries: pad the columns with zeros to a multiple of 8"""
+    n = t.shape[1]
+    if n % 8 == 0:
+        return t
+    out = torch.zeros((t.shape[0], ops._r8(n)), dtype=t.dtype, device=t.device)
+    out[:, :n] = t
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b): nn.Linear on the tiled MFMA GEMM, row-major weight [N][K]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return ops.tlinear(x, w, bias=None if b is None else b.float().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.to(torch.bfloat16).contiguous()
+        S = x.shape[0]
+        dx = ops.tlinear(_pad8(dy), ops.transpose(w)) if ctx.needs_input_grad[0] else None   # [S][N] x [K][N]^T
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ops.tiled_gemm([dict(w=ops.transpose(x), static_count=w.shape[0])], ops.transpose(dy), dw, max_rows=w.shape[0])
+        db = dy.float().sum(0).to(torch.bfloat16) if ctx.has_b and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class RMSNormFn(torch.autograd.Function):
+    """Qwen2RMSNorm: w * bf16(x * rsqrt(mean(x^2) + eps))."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        ctx.save_for_backward(x, w)
+        ctx.eps = eps
+        return ops.rmsnorm(x, w, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw = ops.rmsnorm_bwd(x, w, dy.to(torch.bfloat16).contiguous(), ctx.eps)
+        return dx, dw, None
+
+
+class RopeAttentionFn(torch.autograd.Function):
+    """mRoPE + causal GQA attention over one full sequence per row (no cache kept)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, pos3, kv_pos, first_valid, first_valid_host, B, T, H, KVH, hd, sections):
+        dev = qkv.device
+        kc = torch.empty((B, KVH, T, hd), dtype=torch.bfloat16, device=dev)
+        vc = torch.empty_like(kc)
+        q = ops.qkv_mrope_kvappend(qkv, cos, sin, pos3, kv_pos, T, H, KVH, hd, sections, kc, vc)
+        q0 = torch.zeros(B, dtype=torch.int32, device=dev)
+        ao = ops.attention(q, kc, vc, first_valid, q0, T, H, splits=1)
+        ctx.save_for_backward(q, kc, vc, cos, sin, pos3, kv_pos)
+        ctx.meta = (B, T, H, KVH, hd, tuple(sections), list(first_valid_host))
+        return ao
+
+    @staticmethod
+    def backward(ctx, d_ao):
+        q, kc, vc, cos, sin, pos3, kv_pos = ctx.saved_tensors
+        B, T, H, KVH, hd, sections, fv = ctx.meta
+        dev, bf = q.device, torch.bfloat16
+        d_ao = d_ao.to(bf).contiguous()
+        G = H // KVH
+        Tp = ops._r8(T)
+        scale = float(hd) ** -0.5
+        lib = L.lib()
+        dq = torch.empty_like(q)
+        dk = torch.zeros_like(kc)
+        dv = torch.zeros_like(vc)
+        # per (row, kv head): stacked buffers for the G query heads of the group, rows h*Tp + t; padding rows / columns stay 0
+        sc = torch.zeros((G * Tp, Tp), dtype=torch.float32, device=dev)
+        P = torch.zeros((G * Tp, Tp), dtype=bf, device=dev)
+        dP = torch.zeros((G * Tp, Tp), dtype=bf, device=dev)
+        dS = torch.zeros((G * Tp, Tp), dtype=bf, device=dev)
+        qsT = torch.zeros((hd, G * Tp), dtype=bf, device=dev)
+        dosT = torch.zeros((hd, G * Tp), dtype=bf, device=dev)
+        for b in range(B):
+            for g in range(KVH):
+                K_, V_ = kc[b, g], vc[b, g]                                   # [T][hd]
+                heads = [g * G + j for j in range(G)]
+                # S_h = Q_h K^T (fp32, raw), P_h = softmax over the visible keys
+                ops.tiled_gemm([dict(w=K_, static_count=T, a_row_base=b * T, a_col_off=h * hd, out_row_base=j * Tp, k=hd)
+                                for j, h in enumerate(heads)], q, sc, max_rows=T, epilogue=ops.EPI_F32_RAW)
+                L.check(lib.umoe_attn_softmax_fwd(sc.data_ptr(), Tp, G, T, Tp, int(fv[b]), scale, P.data_ptr(), Tp, ops._stream()),
+                        "umoe_attn_softmax_fwd")
+                # dP_h = dO_h V^T ; dS_h = scale * P o (dP - rowsum(dP o P))
+                ops.tiled_gemm([dict(w=V_, static_count=T, a_row_base=b * T, a_col_off=h * hd, out_row_base=j * Tp, k=hd)
+                                for j, h in enumerate(heads)], d_ao, dP, max_rows=T, epilogue=ops.EPI_BF16)
+                L.check(lib.umoe_attn_softmax_bwd(P.data_ptr(), dP.data_ptr(), Tp, G, T, Tp, scale, dS.data_ptr(), ops._stream()),
+                        "umoe_attn_softmax_bwd")
+                # dQ_h = dS_h K  (contraction over keys: K^T as the K-contiguous operand)
+                kT = ops.transpose(K_)                                        # [hd][Tp]
+                ops.tiled_gemm([dict(w=kT, static_count=T, a_row_base=j * Tp, out_row_base=b * T, out_col_off=h * hd)
+                                for j, h in enumerate(heads)], dS, dq, max_rows=T, epilogue=ops.EPI_BF16)
+                # dK = sum_h dS_h^T Q_h, dV = sum_h P_h^T dO_h: one contraction over the stacked (head, query) rows
+                for j, h in enumerate(heads):
+                    ops.transpose_slots(q[b * T:(b + 1) * T, h * hd:(h + 1) * hd], qsT[:, j * Tp:], max_rows=T, C_cols=hd)
+                    ops.transpose_slots(d_ao[b * T:(b + 1) * T, h * hd:(h + 1) * hd], dosT[:, j * Tp:], max_rows=T, C_cols=hd)
+                dST = ops.transpose(dS)                                        # [Tp][G*Tp]
+                PT = ops.transpose(P)
+                ops.tiled_gemm([dict(w=qsT, static_count=T)], dST, dk[b, g], max_rows=T, epilogue=ops.EPI_BF16)
+                ops.tiled_gemm([dict(w=dosT, static_count=T)], PT, dv[b, g], max_rows=T, epilogue=ops.EPI_BF16)
+        # mRoPE backward + scatter into the QKV row layout
+        n_tok = B * T
+        dqkv = torch.empty((n_tok, (H + 2 * KVH) * hd), dtype=bf, device=dev)
+        a = L.RopeArgs(qkv=None, cos_tab=cos.data_ptr(), sin_tab=sin.data_ptr(), pos3=pos3.data_ptr(), kv_pos=kv_pos.data_ptr(),
+                       n_tok=n_tok, T=T, H=H, KVH=KVH, hd=hd, sec0=sections[0], sec1=sections[1], sec2=sections[2], Lmax=T,
+                       q_out=None, k_cache=None, v_cache=None)
+        L.check(lib.umoe_qkv_mrope_bwd(C.byref(a), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dqkv.data_ptr(), ops._stream()),
+                "umoe_qkv_mrope_bwd")
+        return (dqkv,) + (None,) * 12
+
+
+class CodecCEFn(torch.autograd.Function):
+    """sum of the per-channel shifted cross-entropies (model.py:830-847)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        total, ch_loss, ch_cnt, dl = ops.codec_ce(logits, labels, want_grad=True)
+        ctx.save_for_backward(dl)
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+def text_forward_train(model, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor], position_ids=None,
+                       padding_token_mask=None, aux_balance_weight=None):
+    """Differentiable counterpart of UniAudioRVQQwen2_5VLMoEForConditionalGeneration.text_forward: returns
+    (last_hidden_state [B,T,D], list of per-layer aux losses, per-layer (top_k, expert_mask))."""
+    cfg, dev = model.config, inputs_embeds.device
+    B, T, D = inputs_embeds.shape
+    H, KVH, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    am = torch.ones(B, T, dtype=torch.long, device=dev) if attention_mask is None else attention_mask.to(dev).long()
+    if position_ids is None:
+        pos = (am.cumsum(-1) - 1).masked_fill(am == 0, 1)
+        position_ids = pos[None].expand(3, -1, -1)
+    elif position_ids.dim() == 2:
+        position_ids = position_ids[None].expand(3, -1, -1)
+    pos3 = position_ids.reshape(3, B * T).to(torch.int32).contiguous()
+    kv_pos = torch.arange(T, dtype=torch.int32, device=dev).repeat(B)
+    first_valid = (am != 0).float().argmax(-1).to(torch.int32).contiguous()
+    fv_host = first_valid.tolist()
+    cos, sin = ops.rope_tables(int(position_ids.max()) + 2, hd, cfg.rope_theta, dev)
+    x = inputs_embeds.reshape(B * T, D).contiguous()
+    auxes, masks = [], []
+    for layer in model.language_model.layers:
+        a = layer.self_attn
+        h = RMSNormFn.apply(x, layer.input_layernorm.weight, cfg.rms_norm_eps)
+        qkv_w = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)
+        qkv_b = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)
+        qkv = LinearFn.apply(h, qkv_w, qkv_b)
+        ao = RopeAttentionFn.apply(qkv, cos, sin, pos3, kv_pos, first_valid, fv_host, B, T, H, KVH, hd, tuple(cfg.mrope_section))
+        x1 = x + LinearFn.apply(ao, a.o_proj.weight, None)                                # model.py:238
+        h2 = RMSNormFn.apply(x1, layer.post_attention_layernorm.weight, cfg.rms_norm_eps)
+        out = layer.mlp(h2.view(B, T, D), padding_token_mask, aux_balance_weight)          # model.py:241
+        x = x1 + out[0].reshape(B * T, D)                                                 # model.py:242
+        auxes.append(out[5])
+        masks.append((out[2], out[3]))
+    hN = RMSNormFn.apply(x, model.language_model.norm.weight, cfg.rms_norm_eps)
+    return hN.view(B, T, D), auxes, masks
+
+
+def forward_train(model, input_ids, codec_input_ids, attention_mask, codec_labels, aux_balance_weight=None, position_ids=None,
+                  return_routing: bool = False):
+    """loss = sum_c CE_c(shifted codec logits) + cur_aux_weight * mean(layer aux)  (model.py:817-854), differentiable."""
+    dev = model.device
+    x = model.language_model.embed_tokens.weight[input_ids.to(dev)]
+    if codec_input_ids is not None:
+        ci = codec_input_ids.to(dev)
+        ce = sum(model.codec_embed_tokens[c].weight[ci[..., c]] for c in range(model.num_channels))   # model.py:655-661
+        m = (input_ids.to(dev) == model.codec_placeholder_value).unsqueeze(-1).expand_as(x)
+        x = x.masked_scatter(m, ce.to(x.dtype))
+    pm = None
+    if attention_mask is not None:
+        attention_mask = attention_mask.to(dev)
+        if aux_balance_weight is not None:
+            aux_balance_weight = attention_mask * aux_balance_weight.to(dev)
+        pm = attention_mask.bool()
+    hs, auxes, routing = text_forward_train(model, x, attention_mask, position_ids, pm, aux_balance_weight)
+    B, T, D = hs.shape
+    Cc, V = model.num_channels, model.codec_vocab_size
+    logits = ops_f32_head(hs.reshape(B * T, D).contiguous(), model.codec_head.weight).view(B, T, Cc, V)
+    sl = logits[:, :-1].reshape(B * (T - 1), Cc, V).contiguous()
+    lab = codec_labels.to(dev)[:, 1:].reshape(B * (T - 1), Cc).contiguous()
+    codec_loss = CodecCEFn.apply(sl, lab)
+    aux_mean = torch.stack([a_.float() for a_ in auxes]).mean()
+    loss = codec_loss + model.cur_aux_weight * aux_mean
+    return (loss, codec_loss, aux_mean, routing) if return_routing else (loss, codec_loss, aux_mean)
+
+
+class _HeadFn(torch.autograd.Function):
+    """codec head: fp32 logits = bf16-rounded x W^T held in fp32 (model.py:818-819: `.float()` of the bf16 Linear output)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return ops.tlinear(x, w, out_f32=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dyb = dy.to(torch.bfloat16).contiguous()
+        dx = ops.tlinear(_pad8(dyb), ops.transpose(w))
+        dw = torch.empty_like(w)
+        ops.tiled_gemm([dict(w=ops.transpose(x), static_count=w.shape[0])], ops.transpose(dyb), dw, max_rows=w.shape[0])
+        return dx, dw
+
+
+def ops_f32_head(x, w):
+    return _HeadFn.apply(x, w)
