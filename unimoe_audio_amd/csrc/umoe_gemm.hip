@@ -94,7 +94,17 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
 
     // ---- weight stream set-up: the first chunk is requested BEFORE anything that depends on device-produced data
     //      (row counts, gather lists, activations), so the HBM latency of the stream overlaps the whole prologue ----
-    const int i0 = ia + ((ib - ia) * wave) / WV, i1 = ia + ((ib - ia) * (wave + 1)) / WV;
+    // whole U-step chunks per wave when the slice divides (K = 2752: 43 chunks of 2 steps over 8 waves): a partial last
+    // chunk would re-read its clamped step (measured: +7 % HBM traffic on the down projection, profiles/r01e_pmc_traffic.md)
+    int i0, i1;
+    if ((ib - ia) % U == 0) {
+        const int units = (ib - ia) / U;
+        i0 = ia + U * ((units * wave) / WV);
+        i1 = ia + U * ((units * (wave + 1)) / WV);
+    } else {
+        i0 = ia + ((ib - ia) * wave) / WV;
+        i1 = ia + ((ib - ia) * (wave + 1)) / WV;
+    }
     f32x4_t acc[NT];
     const u32x4_t* wp[NT];
 #pragma unroll
