@@ -266,6 +266,37 @@ int umoe_router_bwd(const void* logits, int logits_bf16, const int32_t* sel, con
                     const float* d_moe_w, const float* d_gw_shared, const float* d_logits_in, int S, int n_dyn, int n_real,
                     int n_fix, double jitter_eps, float* d_logits, umoe_stream_t stream);
 
+/* Backward of the expert MLPs down(silu(gate x) * up x), core.py:16-49,406-416, over up to 12 groups per call:
+ *   dH = dY Wd ; (dG | dU) = SwiGLU'(G, U, dH) ; dX_slots = dG Wg + dU Wu ; dWd = dY^T H ; dWg = dG^T X ; dWu = dU^T X.
+ * umoe_grouped_swiglu_bwd: routed experts, ragged rows (counts/offsets from umoe_dispatch_build_aligned with align 8,
+ * slot_token = gather list of x).  umoe_shared_swiglu_bwd: shared experts, counts/offsets NULL, group g owns slot rows
+ * [row_base + g*max_rows, +max_rows) (both multiples of 8) and reads x by identity.  All weights row-major (nn.Linear). */
+typedef struct {
+    int num_groups;
+    const uint16_t* const* w_gate;   /* host arrays [num_groups] of device pointers: [I][D], [I][D], [D][I] */
+    const uint16_t* const* w_up;
+    const uint16_t* const* w_down;
+    int D, I;
+    const int32_t* counts;           /* device [num_groups] or NULL */
+    const int32_t* offsets;          /* device [num_groups + 1] (8-aligned, last = padded total) or NULL */
+    const int32_t* slot_token;       /* device gather list (slot -> token) or NULL */
+    int max_rows;                    /* tokens S: upper bound of rows per group */
+    int slot_rows;                   /* rows of the slot buffers (h, gu, dy, dx_slots) */
+    int row_base;                    /* static groups: first slot row of group 0 */
+    const uint16_t* x;  int ldx;     /* [S][D] block input */
+    const uint16_t* h;  int ldh;     /* [slot_rows][I] forward silu(g)*u */
+    const uint16_t* gu; int ldgu;    /* [slot_rows][2I] forward pre-activations (umoe_tgemm_args.aux_out) */
+    const uint16_t* dy; int lddy;    /* [slot_rows][D] gradient of the expert outputs */
+    uint16_t* dx_slots; int lddx;    /* out [slot_rows][D]: gradient of the gathered inputs (-> umoe_permute_bwd) */
+    uint16_t* const* dw_gate;        /* host arrays [num_groups] of device pointers, outputs [I][D], [I][D], [D][I] */
+    uint16_t* const* dw_up;
+    uint16_t* const* dw_down;
+    void* ws; size_t ws_bytes;       /* umoe_swiglu_bwd_workspace_bytes() */
+} umoe_swiglu_bwd_args;
+size_t umoe_swiglu_bwd_workspace_bytes(const umoe_swiglu_bwd_args* a);
+int umoe_grouped_swiglu_bwd(const umoe_swiglu_bwd_args* a, umoe_stream_t stream);
+int umoe_shared_swiglu_bwd(const umoe_swiglu_bwd_args* a, umoe_stream_t stream);
+
 /* backward of umoe_aux_loss_fwd (core.py:361-389): d_logits [S][E] fp32 = *d_aux * d aux / d logits (zero on the columns the
  * mask removed and on the shared columns); ws: 17 floats of scratch (per-expert token fractions, weight sum). */
 int umoe_aux_loss_bwd(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S, int E,

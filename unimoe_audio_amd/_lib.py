@@ -60,6 +60,14 @@ class TGemmArgs(C.Structure):
                 ("ldo", i32), ("epilogue", i32), ("aux_out", vp), ("ld_aux", i32)]
 
 
+class SwigluBwdArgs(C.Structure):
+    _fields_ = [("num_groups", i32), ("w_gate", C.POINTER(vp)), ("w_up", C.POINTER(vp)), ("w_down", C.POINTER(vp)), ("D", i32), ("I", i32),
+                ("counts", vp), ("offsets", vp), ("slot_token", vp), ("max_rows", i32), ("slot_rows", i32), ("row_base", i32),
+                ("x", vp), ("ldx", i32), ("h", vp), ("ldh", i32), ("gu", vp), ("ldgu", i32), ("dy", vp), ("lddy", i32),
+                ("dx_slots", vp), ("lddx", i32), ("dw_gate", C.POINTER(vp)), ("dw_up", C.POINTER(vp)), ("dw_down", C.POINTER(vp)),
+                ("ws", vp), ("ws_bytes", C.c_size_t)]
+
+
 class CombineArgs(C.Structure):
     _fields_ = [("y_slots", vp), ("slot_of", vp), ("moe_w", vp), ("y_shared", vp), ("global_w", vp), ("resid", vp),
                 ("out", vp), ("S", i32), ("D", i32), ("n_real", i32), ("n_dyn", i32), ("n_fix", i32), ("y_parts", vp), ("n_parts", i32), ("part_stride", C.c_long),
@@ -117,6 +125,7 @@ EXPORTS = [
     "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
     "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm", "umoe_dispatch_build_aligned", "umoe_transpose_slots", "umoe_swiglu_bwd",
     "umoe_unpermute_combine_bwd", "umoe_permute_bwd", "umoe_router_bwd", "umoe_rmsnorm_residual_bwd", "umoe_aux_loss_bwd", "umoe_attn_softmax_fwd", "umoe_attn_softmax_bwd", "umoe_qkv_mrope_bwd",
+    "umoe_swiglu_bwd_workspace_bytes", "umoe_grouped_swiglu_bwd", "umoe_shared_swiglu_bwd",
 ]
 
 
@@ -153,6 +162,10 @@ def lib():
         L.umoe_attn_softmax_fwd.argtypes = [vp, i32, i32, i32, i32, i32, f32, vp, i32, vp]
         L.umoe_attn_softmax_bwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp]
         L.umoe_qkv_mrope_bwd.argtypes = [C.POINTER(RopeArgs), vp, vp, vp, vp, vp]
+        L.umoe_swiglu_bwd_workspace_bytes.argtypes = [C.POINTER(SwigluBwdArgs)]
+        L.umoe_swiglu_bwd_workspace_bytes.restype = C.c_size_t
+        L.umoe_grouped_swiglu_bwd.argtypes = [C.POINTER(SwigluBwdArgs), vp]
+        L.umoe_shared_swiglu_bwd.argtypes = [C.POINTER(SwigluBwdArgs), vp]
         L.umoe_router_dispatch_fwd.argtypes = [C.POINTER(RouterArgs), vp, vp, vp, vp, vp]
         L.umoe_permute_fwd.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.umoe_grouped_gemm.argtypes = [C.POINTER(GemmArgs), vp]

@@ -4,6 +4,7 @@
 // input gradients use transposed weight copies.  Everything else -- SwiGLU, combine, permute, router, RMSNorm -- is
 // elementwise / per-token work: HBM bound, fp32 arithmetic, one rounding to bf16 where autograd would round.
 #include "umoe_common.h"
+#include <string.h>
 
 // ------------------------------------------------------------------------------------ transposes
 // dst[c][off_g + r] = src[row(off_g + r)][c] for r < cnt_g, 0 for cnt_g <= r < roundup8(cnt_g); row(s) = rows ? rows[s] : s.
@@ -669,4 +670,149 @@ extern "C" int umoe_qkv_mrope_bwd(const umoe_rope_args* a, const uint16_t* dq, c
     rope_bwd_kernel<<<dim3((unsigned)a->n_tok), 256, 0, (hipStream_t)stream>>>(*a, dq, dk_cache, dv_cache, dqkv);
     UMOE_LAUNCH_CHECK();
     return 0;
+}
+
+// ====================================================================================================================
+// Composite backward entry points: host-side sequences of the kernels above and of umoe_tiled_gemm, with
+// a caller-provided workspace -- nothing is allocated or synchronised here.
+// ====================================================================================================================
+namespace {
+struct WsCarver {
+    char* base;
+    size_t off = 0, cap;
+    WsCarver(void* b, size_t c) : base(reinterpret_cast<char*>(b)), cap(c) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+inline int r8(int n) { return (n + 7) & ~7; }
+}  // namespace
+
+// layout of the workspace of umoe_grouped_swiglu_bwd / umoe_shared_swiglu_bwd (sizes in bf16 elements)
+static size_t swiglu_bwd_carve(const umoe_swiglu_bwd_args* a, void* ws, size_t cap, uint16_t** wdT, uint16_t** wguT, uint16_t** dh,
+                               uint16_t** dgu, uint16_t** dyT, uint16_t** hT, uint16_t** dguT, uint16_t** xeT, int* ldT_out) {
+    WsCarver k(ws, cap);
+    const int G = a->num_groups, D = a->D, I = a->I;
+    // transposed buffers: ragged groups keep the slot index as column; static groups get private 8-aligned column ranges
+    const int ldT = a->counts ? r8(a->slot_rows) : G * r8(a->max_rows);
+    *wdT = k.take<uint16_t>((size_t)G * I * r8(D));        // per group [I][r8(D)]
+    *wguT = k.take<uint16_t>((size_t)G * D * 2 * I);       // per group [D][2I]
+    *dh = k.take<uint16_t>((size_t)a->slot_rows * I);
+    *dgu = k.take<uint16_t>((size_t)a->slot_rows * 2 * I);
+    *dyT = k.take<uint16_t>((size_t)D * ldT);
+    *hT = k.take<uint16_t>((size_t)I * ldT);
+    *dguT = k.take<uint16_t>((size_t)2 * I * ldT);
+    *xeT = k.take<uint16_t>((size_t)D * ldT);
+    *ldT_out = ldT;
+    return (k.off + 255) & ~(size_t)255;
+}
+
+extern "C" size_t umoe_swiglu_bwd_workspace_bytes(const umoe_swiglu_bwd_args* a) {
+    if (!a) return 0;
+    uint16_t *p0, *p1, *p2, *p3, *p4, *p5, *p6, *p7;
+    int ldT;
+    return swiglu_bwd_carve(a, nullptr, 0, &p0, &p1, &p2, &p3, &p4, &p5, &p6, &p7, &ldT);
+}
+
+// backward of down(silu(gate x) * up x) over groups of rows (core.py:16-49,406-416):
+//   dH = dY Wd ; (dG | dU) = swiglu'(G, U, dH) ; dX_slots = dG Wg + dU Wu ; dWd = dY^T H ; dWg = dG^T X ; dWu = dU^T X
+// ragged groups (routed experts): counts/offsets (8-aligned, umoe_dispatch_build_aligned) + optional gather list for x;
+// static groups (shared experts): counts == NULL, group g owns rows [row_base + g*max_rows, +max_rows).
+static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->num_groups > 0 && a->num_groups <= 12 && a->w_gate && a->w_up && a->w_down && a->x && a->h && a->gu && a->dy &&
+                     a->dx_slots && a->dw_gate && a->dw_up && a->dw_down && a->ws,
+                 "umoe_*_swiglu_bwd: null argument or more than 12 groups");
+    UMOE_REQUIRE(a->D % 8 == 0 && a->I % 8 == 0 && a->max_rows > 0 && a->slot_rows > 0, "umoe_*_swiglu_bwd: D and I must be multiples of 8");
+    UMOE_REQUIRE((a->counts == nullptr) == (a->offsets == nullptr), "umoe_*_swiglu_bwd: counts and offsets come together");
+    const bool ragged = a->counts != nullptr;
+    uint16_t *wdT, *wguT, *dh, *dgu, *dyT, *hT, *dguT, *xeT;
+    int ldT;
+    const size_t need = swiglu_bwd_carve(a, a->ws, a->ws_bytes, &wdT, &wguT, &dh, &dgu, &dyT, &hT, &dguT, &xeT, &ldT);
+    UMOE_REQUIRE(a->ws_bytes >= need, "umoe_*_swiglu_bwd: workspace too small (%zu < %zu bytes)", a->ws_bytes, need);
+    const int G = a->num_groups, D = a->D, I = a->I, S = a->max_rows;
+    int rc;
+    // transposed weight copies: Wd^T [I][r8(D)], (Wg^T | Wu^T) [D][2I]
+    for (int g = 0; g < G; ++g) {
+        if ((rc = umoe_transpose_slots(a->w_down[g], I, I, nullptr, nullptr, nullptr, 1, D, wdT + (size_t)g * I * r8(D), r8(D), stream))) return rc;
+        uint16_t* t = wguT + (size_t)g * D * 2 * I;
+        if ((rc = umoe_transpose_slots(a->w_gate[g], D, D, nullptr, nullptr, nullptr, 1, I, t, 2 * I, stream))) return rc;
+        if ((rc = umoe_transpose_slots(a->w_up[g], D, D, nullptr, nullptr, nullptr, 1, I, t + I, 2 * I, stream))) return rc;
+    }
+    umoe_tgroup_t tg[12];
+    auto rows_of = [&](umoe_tgroup_t& t, int g) {
+        if (ragged) { t.row_off = a->offsets + g; t.count = a->counts + g; }
+        else { t.static_count = S; t.a_row_base = a->row_base + g * S; t.out_row_base = a->row_base + g * S; }
+    };
+    // dH = dY * Wd
+    memset(tg, 0, sizeof(tg));
+    for (int g = 0; g < G; ++g) { tg[g].w = wdT + (size_t)g * I * r8(D); tg[g].n = I; tg[g].k = D; tg[g].ldw = r8(D); rows_of(tg[g], g); }
+    umoe_tgemm_args ta{};
+    ta.groups = tg; ta.num_groups = G; ta.max_rows = S; ta.a = a->dy; ta.lda = a->lddy; ta.out = dh; ta.ldo = I; ta.epilogue = UMOE_EPI_BF16;
+    if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
+    // SwiGLU backward over the slot rows
+    if (ragged) {
+        if ((rc = umoe_swiglu_bwd(dh, I, a->gu, a->ldgu, I, a->offsets + G, a->slot_rows, dgu, 2 * I, stream))) return rc;
+    } else {
+        const size_t r0 = (size_t)a->row_base;
+        if ((rc = umoe_swiglu_bwd(dh + r0 * I, I, a->gu + r0 * a->ldgu, a->ldgu, I, nullptr, G * S, dgu + r0 * 2 * I, 2 * I, stream))) return rc;
+    }
+    // dX_slots = (dG | dU) * (Wg^T | Wu^T)^T
+    memset(tg, 0, sizeof(tg));
+    for (int g = 0; g < G; ++g) { tg[g].w = wguT + (size_t)g * D * 2 * I; tg[g].n = D; tg[g].k = 2 * I; tg[g].ldw = 2 * I; rows_of(tg[g], g); }
+    ta = umoe_tgemm_args{};
+    ta.groups = tg; ta.num_groups = G; ta.max_rows = S; ta.a = dgu; ta.lda = 2 * I; ta.out = a->dx_slots; ta.ldo = a->lddx; ta.epilogue = UMOE_EPI_BF16;
+    if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
+    // transposed slot buffers for the weight gradients
+    const int Sp = r8(S);
+    auto slots_t = [&](const uint16_t* src, int ld, int C, uint16_t* dst) -> int {
+        if (ragged) return umoe_transpose_slots(src, ld, C, nullptr, a->counts, a->offsets, G, S, dst, ldT, stream);
+        for (int g = 0; g < G; ++g) {
+            const size_t r0 = (size_t)a->row_base + (size_t)g * S;
+            if (int rc2 = umoe_transpose_slots(src + r0 * ld, ld, C, nullptr, nullptr, nullptr, 1, S, dst + (size_t)g * Sp, ldT, stream)) return rc2;
+        }
+        return 0;
+    };
+    if ((rc = slots_t(a->dy, a->lddy, D, dyT))) return rc;
+    if ((rc = slots_t(a->h, a->ldh, I, hT))) return rc;
+    if ((rc = slots_t(dgu, 2 * I, 2 * I, dguT))) return rc;
+    if (ragged) {
+        if ((rc = umoe_transpose_slots(a->x, a->ldx, D, a->slot_token, a->counts, a->offsets, G, S, xeT, ldT, stream))) return rc;
+    } else {
+        for (int g = 0; g < G; ++g)
+            if ((rc = umoe_transpose_slots(a->x, a->ldx, D, nullptr, nullptr, nullptr, 1, S, xeT + (size_t)g * Sp, ldT, stream))) return rc;
+    }
+    // dWd_g [D][I] = dyT[:, cols_g] * hT[:, cols_g]^T ; dWg_g [I][D] = dgT * xeT^T ; dWu_g = duT * xeT^T  (one launch per output)
+    for (int g = 0; g < G; ++g) {
+        umoe_tgroup_t t1{};
+        umoe_tgemm_args b{};
+        const int cbase = ragged ? 0 : g * Sp;
+        auto window = [&](umoe_tgroup_t& t) {
+            if (ragged) { t.k_off = a->offsets + g; t.k_count = a->counts + g; t.k = 8; }
+            else { t.k = Sp; }       // zero-padded columns
+        };
+        t1.w = hT + cbase; t1.n = I; t1.ldw = ldT; t1.static_count = D; window(t1);
+        b.groups = &t1; b.num_groups = 1; b.max_rows = D; b.a = dyT + cbase; b.lda = ldT; b.out = a->dw_down[g]; b.ldo = I; b.epilogue = UMOE_EPI_BF16;
+        if ((rc = umoe_tiled_gemm(&b, stream))) return rc;
+        t1 = umoe_tgroup_t{};
+        t1.w = xeT + cbase; t1.n = D; t1.ldw = ldT; t1.static_count = I; window(t1);
+        b.max_rows = I; b.a = dguT + cbase; b.out = a->dw_gate[g]; b.ldo = D;
+        if ((rc = umoe_tiled_gemm(&b, stream))) return rc;
+        t1.a_row_base = I;
+        b.out = a->dw_up[g];
+        if ((rc = umoe_tiled_gemm(&b, stream))) return rc;
+    }
+    return 0;
+}
+
+extern "C" int umoe_grouped_swiglu_bwd(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->counts && a->offsets, "umoe_grouped_swiglu_bwd: routed experts need counts/offsets (umoe_dispatch_build_aligned)");
+    return swiglu_bwd_impl(a, stream);
+}
+extern "C" int umoe_shared_swiglu_bwd(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && !a->counts && !a->offsets, "umoe_shared_swiglu_bwd: shared experts take every row (counts/offsets must be NULL)");
+    return swiglu_bwd_impl(a, stream);
 }

@@ -392,65 +392,22 @@ class _DCMoETrainFn(torch.autograd.Function):
         dy = torch.empty((rows_total, D), dtype=bf, device=dev)
         y_sh = ybuf[cap:] if n_fix else None
         d_mw, d_gs = ops.combine_bwd(d_out, ybuf, disp["slot_of"], moe_w, y_sh, global_w, n_dyn, n_fix, dy, dy[cap:] if n_fix else None)
-        # 2. down projection: dH = dY * Wd  (transposed weight copies as the K-contiguous operand)
-        dh = torch.empty((rows_total, Imax), dtype=bf, device=dev)
-        g = [dict(w=ops.transpose(ex[e][2]), k=D, row_off=offs[e:e + 1], count=cnts[e:e + 1]) for e in range(n_real)]
-        g += [dict(w=ops.transpose(sh[i][2]), k=D, static_count=S, a_row_base=cap + i * S, out_row_base=cap + i * S) for i in range(n_fix)]
-        ops.tiled_gemm(g, dy, dh, max_rows=S, epilogue=ops.EPI_BF16)
-        # 3. SwiGLU backward -> (dgate | dup)
-        dgu = torch.empty((rows_total, 2 * Imax), dtype=bf, device=dev)
-        ops.swiglu_bwd(dh, gu, I_d, dgu, total_rows=total, max_rows=cap)
-        if n_fix:
-            ops.swiglu_bwd(dh[cap:], gu[cap:], I_s, dgu[cap:], total_rows=None, max_rows=n_fix * S)
-        # 4. gate/up projections: dXe = dG * Wg + dU * Wu = [dG | dU] * [Wg^T | Wu^T]^T
-        def gu_t(wg, wu):
-            I = wg.shape[0]
-            t = torch.empty((D, 2 * I), dtype=bf, device=dev)
-            ops.transpose_slots(wg, t[:, :I])
-            ops.transpose_slots(wu, t[:, I:])
-            return t
+        # 2.-5. expert MLP backward (umoe_grouped_swiglu_bwd / umoe_shared_swiglu_bwd): dH = dY Wd, SwiGLU', dX_slots, dWd/dWg/dWu
         dxe = torch.empty((rows_total, D), dtype=bf, device=dev)
-        g = [dict(w=gu_t(ex[e][0], ex[e][1]), row_off=offs[e:e + 1], count=cnts[e:e + 1]) for e in range(n_real)]
-        g += [dict(w=gu_t(sh[i][0], sh[i][1]), static_count=S, a_row_base=cap + i * S, out_row_base=cap + i * S) for i in range(n_fix)]
-        ops.tiled_gemm(g, dgu, dxe, max_rows=S, epilogue=ops.EPI_BF16)
-        # 5. weight gradients: contraction over the slot columns of transposed buffers
-        Sp = ops._r8(S)
-        ldT = cap + n_fix * Sp
-        def slots_t(src, Ccols, gather=None):
-            t = torch.empty((Ccols, ldT), dtype=bf, device=dev)
-            ops.transpose_slots(src, t, rows=gather, counts=cnts, offsets=offs, n_groups=n_real, max_rows=S, C_cols=Ccols)
-            for i in range(n_fix):
-                s0 = None if gather is not None else src[cap + i * S:]
-                ops.transpose_slots(x if gather is not None else s0, t[:, cap + i * Sp:], max_rows=S, C_cols=Ccols)
-            return t
-        dyT = slots_t(dy, D)
-        hT = slots_t(hbuf, Imax)
-        dguT = slots_t(dgu, 2 * Imax)
-        xeT = slots_t(x, D, gather=disp["slot_token"])
         grads = [None] * len(params)
         if n_real:
-            dWd = torch.empty((n_real * D, I_d), dtype=bf, device=dev)
-            ops.tiled_gemm([dict(w=hT[:I_d], static_count=D, out_row_base=e * D, k_off=offs[e:e + 1], k_count=cnts[e:e + 1]) for e in range(n_real)],
-                           dyT, dWd, max_rows=D, epilogue=ops.EPI_BF16)
-            dWg = torch.empty((n_real * I_d, D), dtype=bf, device=dev)
-            dWu = torch.empty((n_real * I_d, D), dtype=bf, device=dev)
-            ops.tiled_gemm([dict(w=xeT, static_count=I_d, out_row_base=e * I_d, k_off=offs[e:e + 1], k_count=cnts[e:e + 1]) for e in range(n_real)],
-                           dguT, dWg, max_rows=I_d, epilogue=ops.EPI_BF16)
-            ops.tiled_gemm([dict(w=xeT, static_count=I_d, a_row_base=I_d, out_row_base=e * I_d, k_off=offs[e:e + 1], k_count=cnts[e:e + 1])
-                            for e in range(n_real)], dguT, dWu, max_rows=I_d, epilogue=ops.EPI_BF16)
+            dwg, dwu, dwd = ops.experts_swiglu_bwd([tuple(ex[e]) for e in range(n_real)], x=x, h=hbuf[:cap], gu=gu[:cap], dy=dy[:cap],
+                                                   dx_slots=dxe[:cap], D=D, I=I_d, max_rows=S, counts=cnts, offsets=offs,
+                                                   slot_token=disp["slot_token"])
             for e in range(n_real):
-                grads[1 + 3 * e], grads[2 + 3 * e], grads[3 + 3 * e] = dWg[e * I_d:(e + 1) * I_d], dWu[e * I_d:(e + 1) * I_d], dWd[e * D:(e + 1) * D]
-        for i in range(n_fix):
-            c0 = cap + i * Sp
-            a_dy, w_h, a_dgu, w_x = dyT[:, c0:c0 + Sp], hT[:I_s, c0:c0 + Sp], dguT[:, c0:c0 + Sp], xeT[:, c0:c0 + Sp]
-            dWd_i = torch.empty((D, I_s), dtype=bf, device=dev)
-            dWg_i = torch.empty((I_s, D), dtype=bf, device=dev)
-            dWu_i = torch.empty((I_s, D), dtype=bf, device=dev)
-            ops.tiled_gemm([dict(w=w_h, static_count=D)], a_dy, dWd_i, max_rows=D)
-            ops.tiled_gemm([dict(w=w_x, static_count=I_s)], a_dgu, dWg_i, max_rows=I_s)
-            ops.tiled_gemm([dict(w=w_x, static_count=I_s, a_row_base=I_s)], a_dgu, dWu_i, max_rows=I_s)
-            b0 = 1 + 3 * n_real + 3 * i
-            grads[b0], grads[b0 + 1], grads[b0 + 2] = dWg_i, dWu_i, dWd_i
+                grads[1 + 3 * e], grads[2 + 3 * e], grads[3 + 3 * e] = dwg[e], dwu[e], dwd[e]
+        if n_fix:
+            dwg, dwu, dwd = ops.experts_swiglu_bwd([tuple(sh[i]) for i in range(n_fix)], x=x, h=hbuf[cap:], gu=gu[cap:], dy=dy[cap:],
+                                                   dx_slots=dxe[cap:], D=D, I=I_s, max_rows=S, row_base=0)
+            for i in range(n_fix):
+                b0 = 1 + 3 * n_real + 3 * i
+                grads[b0], grads[b0 + 1], grads[b0 + 2] = dwg[i], dwu[i], dwd[i]
+        Sp = ops._r8(S)
         # 6. router: d(moe_w), d(shared weights), d(aux) -> d(logits) -> gate weight and input gradients
         d_lg_aux = None
         if d_aux is not None:
@@ -460,10 +417,7 @@ class _DCMoETrainFn(torch.autograd.Function):
         dl16 = torch.zeros((S, 16), dtype=bf, device=dev)
         dl16[:, :E] = d_lg.to(bf)
         noise = ctx.noise
-        if noise is not None:
-            xT = ops.transpose((x.float() * noise).to(bf))                   # the gate saw the jittered input
-        else:
-            xT = xeT[:, cap:cap + Sp] if n_fix else ops.transpose(x)        # [D][Sp]: the shared experts' gather is the identity
+        xT = ops.transpose((x.float() * noise).to(bf) if noise is not None else x)   # [D][Sp]; the gate saw the jittered input
         dlT = ops.transpose(dl16)                                            # [16][Sp]
         dWgate = torch.empty((16, D), dtype=bf, device=dev)
         ops.tiled_gemm([dict(w=xT, static_count=16)], dlT, dWgate, max_rows=16)

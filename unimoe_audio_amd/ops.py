@@ -469,3 +469,26 @@ def rmsnorm_bwd(h: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, 
     L.check(L.lib().umoe_rmsnorm_residual_bwd(_p(h), _p(w), _p(dy), _p(dsum), eps, S, D, _p(dh), _p(dw), _p(ws), ws.numel(), _stream()),
             "umoe_rmsnorm_residual_bwd")
     return dh, dw
+
+
+def experts_swiglu_bwd(ws_list, *, x, h, gu, dy, dx_slots, D: int, I: int, max_rows: int, counts=None, offsets=None, slot_token=None,
+                       row_base: int = 0):
+    """umoe_grouped_swiglu_bwd (counts/offsets given: routed experts) or umoe_shared_swiglu_bwd (static groups).
+    ws_list: list of (w_gate [I,D], w_up [I,D], w_down [D,I]) row-major bf16 tensors.  Returns lists (dWg, dWu, dWd)."""
+    G = len(ws_list)
+    dev = x.device
+    arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])
+    dwg = [torch.empty_like(w[0]) for w in ws_list]
+    dwu = [torch.empty_like(w[1]) for w in ws_list]
+    dwd = [torch.empty_like(w[2]) for w in ws_list]
+    keep = (arr([w[0] for w in ws_list]), arr([w[1] for w in ws_list]), arr([w[2] for w in ws_list]), arr(dwg), arr(dwu), arr(dwd))
+    a = L.SwigluBwdArgs(num_groups=G, w_gate=keep[0], w_up=keep[1], w_down=keep[2], D=D, I=I, counts=_p(counts), offsets=_p(offsets),
+                        slot_token=_p(slot_token), max_rows=max_rows, slot_rows=h.shape[0], row_base=row_base,
+                        x=_p(x), ldx=x.stride(0), h=_pv(h), ldh=h.stride(0), gu=_pv(gu), ldgu=gu.stride(0), dy=_pv(dy), lddy=dy.stride(0),
+                        dx_slots=_pv(dx_slots), lddx=dx_slots.stride(0), dw_gate=keep[3], dw_up=keep[4], dw_down=keep[5])
+    nbytes = L.lib().umoe_swiglu_bwd_workspace_bytes(C.byref(a))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    a.ws, a.ws_bytes = ws.data_ptr(), nbytes
+    fn = L.lib().umoe_grouped_swiglu_bwd if counts is not None else L.lib().umoe_shared_swiglu_bwd
+    L.check(fn(C.byref(a), _stream()), "umoe_swiglu_bwd (composite)")
+    return dwg, dwu, dwd
