@@ -345,6 +345,24 @@ int umoe_attn_softmax_fwd(const float* scores, int ld, int heads, int T, int Tp,
                           int ld_p, umoe_stream_t stream);
 int umoe_attn_softmax_bwd(const uint16_t* p, const uint16_t* dp, int ld, int heads, int T, int Tp, float scale, uint16_t* ds,
                           umoe_stream_t stream);
+/* backward of umoe_attn_prefill_fwd over full sequences (nq == T queries per row, one per key position; keys
+ * [kv_start[row], t] visible to query t): dq [rows*T][H*hd], dk / dv in cache layout (positions [0, T) written).
+ * "Unfused" first version: scores are materialised per (row, kv head) group in the workspace. */
+typedef struct {
+    const uint16_t* q;             /* [rows*T][H*hd] rotated queries (umoe_qkv_mrope_kvappend q_out) */
+    const uint16_t* k_cache;       /* [rows][KVH][Lmax][hd] */
+    const uint16_t* v_cache;
+    const int32_t* kv_start_host;  /* HOST [rows] */
+    const uint16_t* d_out;         /* [rows*T][H*hd] gradient of the attention output */
+    int rows, T, H, KVH, hd, Lmax;
+    float scale;
+    uint16_t* dq;
+    uint16_t* dk_cache;
+    uint16_t* dv_cache;
+    void* ws; size_t ws_bytes;     /* umoe_attn_prefill_bwd_workspace_bytes() */
+} umoe_attn_bwd_args;
+size_t umoe_attn_prefill_bwd_workspace_bytes(const umoe_attn_bwd_args* a);
+int umoe_attn_prefill_bwd(const umoe_attn_bwd_args* a, umoe_stream_t stream);
 /* backward of umoe_qkv_mrope_kvappend: dq [n_tok][H*hd], dk / dv in cache layout -> d(qkv) [n_tok][(H+2KVH)*hd] */
 int umoe_qkv_mrope_bwd(const umoe_rope_args* a, const uint16_t* dq, const uint16_t* dk_cache, const uint16_t* dv_cache,
                        uint16_t* dqkv, umoe_stream_t stream);

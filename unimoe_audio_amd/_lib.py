@@ -68,6 +68,12 @@ class SwigluBwdArgs(C.Structure):
                 ("ws", vp), ("ws_bytes", C.c_size_t)]
 
 
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("q", vp), ("k_cache", vp), ("v_cache", vp), ("kv_start_host", vp), ("d_out", vp), ("rows", i32), ("T", i32), ("H", i32),
+                ("KVH", i32), ("hd", i32), ("Lmax", i32), ("scale", f32), ("dq", vp), ("dk_cache", vp), ("dv_cache", vp), ("ws", vp),
+                ("ws_bytes", C.c_size_t)]
+
+
 class CombineArgs(C.Structure):
     _fields_ = [("y_slots", vp), ("slot_of", vp), ("moe_w", vp), ("y_shared", vp), ("global_w", vp), ("resid", vp),
                 ("out", vp), ("S", i32), ("D", i32), ("n_real", i32), ("n_dyn", i32), ("n_fix", i32), ("y_parts", vp), ("n_parts", i32), ("part_stride", C.c_long),
@@ -126,6 +132,7 @@ EXPORTS = [
     "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm", "umoe_dispatch_build_aligned", "umoe_transpose_slots", "umoe_swiglu_bwd",
     "umoe_unpermute_combine_bwd", "umoe_permute_bwd", "umoe_router_bwd", "umoe_rmsnorm_residual_bwd", "umoe_aux_loss_bwd", "umoe_attn_softmax_fwd", "umoe_attn_softmax_bwd", "umoe_qkv_mrope_bwd",
     "umoe_swiglu_bwd_workspace_bytes", "umoe_grouped_swiglu_bwd", "umoe_shared_swiglu_bwd",
+    "umoe_attn_prefill_bwd_workspace_bytes", "umoe_attn_prefill_bwd",
 ]
 
 
@@ -166,6 +173,9 @@ def lib():
         L.umoe_swiglu_bwd_workspace_bytes.restype = C.c_size_t
         L.umoe_grouped_swiglu_bwd.argtypes = [C.POINTER(SwigluBwdArgs), vp]
         L.umoe_shared_swiglu_bwd.argtypes = [C.POINTER(SwigluBwdArgs), vp]
+        L.umoe_attn_prefill_bwd_workspace_bytes.argtypes = [C.POINTER(AttnBwdArgs)]
+        L.umoe_attn_prefill_bwd_workspace_bytes.restype = C.c_size_t
+        L.umoe_attn_prefill_bwd.argtypes = [C.POINTER(AttnBwdArgs), vp]
         L.umoe_router_dispatch_fwd.argtypes = [C.POINTER(RouterArgs), vp, vp, vp, vp, vp]
         L.umoe_permute_fwd.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.umoe_grouped_gemm.argtypes = [C.POINTER(GemmArgs), vp]

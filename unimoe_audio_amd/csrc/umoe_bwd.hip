@@ -816,3 +816,99 @@ extern "C" int umoe_shared_swiglu_bwd(const umoe_swiglu_bwd_args* a, umoe_stream
     UMOE_REQUIRE(a && !a->counts && !a->offsets, "umoe_shared_swiglu_bwd: shared experts take every row (counts/offsets must be NULL)");
     return swiglu_bwd_impl(a, stream);
 }
+
+// ------------------------------------------------------------------------------------ attention backward (composite)
+static size_t attn_bwd_carve(const umoe_attn_bwd_args* a, void* ws, size_t cap, float** sc, uint16_t** P, uint16_t** dP, uint16_t** dS,
+                             uint16_t** qsT, uint16_t** dosT, uint16_t** kT, uint16_t** dST, uint16_t** PT) {
+    WsCarver k(ws, cap);
+    const int G = a->H / a->KVH, Tp = r8(a->T);
+    *sc = k.take<float>((size_t)G * Tp * Tp);
+    *P = k.take<uint16_t>((size_t)G * Tp * Tp);
+    *dP = k.take<uint16_t>((size_t)G * Tp * Tp);
+    *dS = k.take<uint16_t>((size_t)G * Tp * Tp);
+    *qsT = k.take<uint16_t>((size_t)a->hd * G * Tp);
+    *dosT = k.take<uint16_t>((size_t)a->hd * G * Tp);
+    *kT = k.take<uint16_t>((size_t)a->hd * Tp);
+    *dST = k.take<uint16_t>((size_t)Tp * G * Tp);
+    *PT = k.take<uint16_t>((size_t)Tp * G * Tp);
+    return (k.off + 255) & ~(size_t)255;
+}
+
+extern "C" size_t umoe_attn_prefill_bwd_workspace_bytes(const umoe_attn_bwd_args* a) {
+    if (!a || a->KVH <= 0) return 0;
+    float* f;
+    uint16_t *p1, *p2, *p3, *p4, *p5, *p6, *p7, *p8;
+    return attn_bwd_carve(a, nullptr, 0, &f, &p1, &p2, &p3, &p4, &p5, &p6, &p7, &p8);
+}
+
+// Backward of causal GQA attention over full sequences (one query per key position, left padding via kv_start):
+// per (row, kv head) group the scores of its G query heads are materialised (rows h*Tp + t), P is recomputed in fp32,
+// dP = dO V^T, dS = scale * P o (dP - rowsum(dP o P)), dQ = dS K, dK = sum_h dS_h^T Q_h, dV = sum_h P_h^T dO_h -- every
+// contraction on umoe_tiled_gemm ("unfused" first version).
+extern "C" int umoe_attn_prefill_bwd(const umoe_attn_bwd_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->q && a->k_cache && a->v_cache && a->kv_start_host && a->d_out && a->dq && a->dk_cache && a->dv_cache && a->ws,
+                 "umoe_attn_prefill_bwd: null argument");
+    UMOE_REQUIRE(a->KVH > 0 && a->H % a->KVH == 0 && a->H / a->KVH <= 12 && a->hd % 8 == 0 && a->T > 0 && a->T <= a->Lmax && a->rows > 0,
+                 "umoe_attn_prefill_bwd: bad sizes (H=%d KVH=%d hd=%d T=%d Lmax=%d)", a->H, a->KVH, a->hd, a->T, a->Lmax);
+    float* sc;
+    uint16_t *P, *dP, *dS, *qsT, *dosT, *kT, *dST, *PT;
+    const size_t need = attn_bwd_carve(a, a->ws, a->ws_bytes, &sc, &P, &dP, &dS, &qsT, &dosT, &kT, &dST, &PT);
+    UMOE_REQUIRE(a->ws_bytes >= need, "umoe_attn_prefill_bwd: workspace too small (%zu < %zu bytes)", a->ws_bytes, need);
+    const int G = a->H / a->KVH, T = a->T, Tp = r8(T), hd = a->hd, HD = a->H * hd;
+    hipStream_t s = (hipStream_t)stream;
+    // padding rows / columns of the stacked buffers must be finite zeros (they take part in the stacked contractions)
+    UMOE_HIP(hipMemsetAsync(P, 0, (size_t)G * Tp * Tp * 2, s));
+    UMOE_HIP(hipMemsetAsync(dP, 0, (size_t)G * Tp * Tp * 2, s));
+    UMOE_HIP(hipMemsetAsync(dS, 0, (size_t)G * Tp * Tp * 2, s));
+    int rc;
+    umoe_tgroup_t tg[12];
+    for (int b = 0; b < a->rows; ++b)
+        for (int g = 0; g < a->KVH; ++g) {
+            const uint16_t* K_ = a->k_cache + (((size_t)b * a->KVH + g) * a->Lmax) * hd;
+            const uint16_t* V_ = a->v_cache + (((size_t)b * a->KVH + g) * a->Lmax) * hd;
+            uint16_t* dK_ = a->dk_cache + (((size_t)b * a->KVH + g) * a->Lmax) * hd;
+            uint16_t* dV_ = a->dv_cache + (((size_t)b * a->KVH + g) * a->Lmax) * hd;
+            // S_h = Q_h K^T (raw fp32)
+            memset(tg, 0, sizeof(tg));
+            for (int j = 0; j < G; ++j) {
+                tg[j].w = K_; tg[j].n = T; tg[j].k = hd; tg[j].ldw = hd; tg[j].static_count = T; tg[j].a_row_base = b * T;
+                tg[j].a_col_off = (g * G + j) * hd; tg[j].out_row_base = j * Tp;
+            }
+            umoe_tgemm_args ta{};
+            ta.groups = tg; ta.num_groups = G; ta.max_rows = T; ta.a = a->q; ta.lda = HD; ta.out = sc; ta.ldo = Tp; ta.epilogue = UMOE_EPI_F32_RAW;
+            if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
+            if ((rc = umoe_attn_softmax_fwd(sc, Tp, G, T, Tp, a->kv_start_host[b], a->scale, P, Tp, stream))) return rc;
+            // dP_h = dO_h V^T
+            for (int j = 0; j < G; ++j) tg[j].w = V_;
+            ta.a = a->d_out; ta.out = dP; ta.epilogue = UMOE_EPI_BF16;
+            if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
+            if ((rc = umoe_attn_softmax_bwd(P, dP, Tp, G, T, Tp, a->scale, dS, stream))) return rc;
+            // dQ_h = dS_h K
+            if ((rc = umoe_transpose_slots(K_, hd, hd, nullptr, nullptr, nullptr, 1, T, kT, Tp, stream))) return rc;
+            memset(tg, 0, sizeof(tg));
+            for (int j = 0; j < G; ++j) {
+                tg[j].w = kT; tg[j].n = hd; tg[j].k = Tp; tg[j].ldw = Tp; tg[j].static_count = T; tg[j].a_row_base = j * Tp;
+                tg[j].out_row_base = b * T; tg[j].out_col_off = (g * G + j) * hd;
+            }
+            ta = umoe_tgemm_args{};
+            ta.groups = tg; ta.num_groups = G; ta.max_rows = T; ta.a = dS; ta.lda = Tp; ta.out = a->dq; ta.ldo = HD; ta.epilogue = UMOE_EPI_BF16;
+            if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
+            // stacked contractions over (head, query): dK = [dS_h]^T [Q_h], dV = [P_h]^T [dO_h]
+            for (int j = 0; j < G; ++j) {
+                const size_t off = (size_t)b * T * HD + (size_t)(g * G + j) * hd;
+                if ((rc = umoe_transpose_slots(a->q + off, HD, hd, nullptr, nullptr, nullptr, 1, T, qsT + (size_t)j * Tp, G * Tp, stream))) return rc;
+                if ((rc = umoe_transpose_slots(a->d_out + off, HD, hd, nullptr, nullptr, nullptr, 1, T, dosT + (size_t)j * Tp, G * Tp, stream))) return rc;
+            }
+            if ((rc = umoe_transpose_slots(dS, Tp, Tp, nullptr, nullptr, nullptr, 1, G * Tp, dST, G * Tp, stream))) return rc;
+            if ((rc = umoe_transpose_slots(P, Tp, Tp, nullptr, nullptr, nullptr, 1, G * Tp, PT, G * Tp, stream))) return rc;
+            umoe_tgroup_t t1{};
+            t1.w = qsT; t1.n = hd; t1.k = G * Tp; t1.ldw = G * Tp; t1.static_count = T;
+            ta = umoe_tgemm_args{};
+            ta.groups = &t1; ta.num_groups = 1; ta.max_rows = T; ta.a = dST; ta.lda = G * Tp; ta.out = dK_; ta.ldo = hd; ta.epilogue = UMOE_EPI_BF16;
+            if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
+            t1.w = dosT;
+            ta.a = PT; ta.out = dV_;
+            if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
+        }
+    return 0;
+}

@@ -91,46 +91,19 @@ class RopeAttentionFn(torch.autograd.Function):
         B, T, H, KVH, hd, sections, fv = ctx.meta
         dev, bf = q.device, torch.bfloat16
         d_ao = d_ao.to(bf).contiguous()
-        G = H // KVH
-        Tp = ops._r8(T)
         scale = float(hd) ** -0.5
         lib = L.lib()
         dq = torch.empty_like(q)
         dk = torch.zeros_like(kc)
         dv = torch.zeros_like(vc)
-        # per (row, kv head): stacked buffers for the G query heads of the group, rows h*Tp + t; padding rows / columns stay 0
-        sc = torch.zeros((G * Tp, Tp), dtype=torch.float32, device=dev)
-        P = torch.zeros((G * Tp, Tp), dtype=bf, device=dev)
-        dP = torch.zeros((G * Tp, Tp), dtype=bf, device=dev)
-        dS = torch.zeros((G * Tp, Tp), dtype=bf, device=dev)
-        qsT = torch.zeros((hd, G * Tp), dtype=bf, device=dev)
-        dosT = torch.zeros((hd, G * Tp), dtype=bf, device=dev)
-        for b in range(B):
-            for g in range(KVH):
-                K_, V_ = kc[b, g], vc[b, g]                                   # [T][hd]
-                heads = [g * G + j for j in range(G)]
-                # S_h = Q_h K^T (fp32, raw), P_h = softmax over the visible keys
-                ops.tiled_gemm([dict(w=K_, static_count=T, a_row_base=b * T, a_col_off=h * hd, out_row_base=j * Tp, k=hd)
-                                for j, h in enumerate(heads)], q, sc, max_rows=T, epilogue=ops.EPI_F32_RAW)
-                L.check(lib.umoe_attn_softmax_fwd(sc.data_ptr(), Tp, G, T, Tp, int(fv[b]), scale, P.data_ptr(), Tp, ops._stream()),
-                        "umoe_attn_softmax_fwd")
-                # dP_h = dO_h V^T ; dS_h = scale * P o (dP - rowsum(dP o P))
-                ops.tiled_gemm([dict(w=V_, static_count=T, a_row_base=b * T, a_col_off=h * hd, out_row_base=j * Tp, k=hd)
-                                for j, h in enumerate(heads)], d_ao, dP, max_rows=T, epilogue=ops.EPI_BF16)
-                L.check(lib.umoe_attn_softmax_bwd(P.data_ptr(), dP.data_ptr(), Tp, G, T, Tp, scale, dS.data_ptr(), ops._stream()),
-                        "umoe_attn_softmax_bwd")
-                # dQ_h = dS_h K  (contraction over keys: K^T as the K-contiguous operand)
-                kT = ops.transpose(K_)                                        # [hd][Tp]
-                ops.tiled_gemm([dict(w=kT, static_count=T, a_row_base=j * Tp, out_row_base=b * T, out_col_off=h * hd)
-                                for j, h in enumerate(heads)], dS, dq, max_rows=T, epilogue=ops.EPI_BF16)
-                # dK = sum_h dS_h^T Q_h, dV = sum_h P_h^T dO_h: one contraction over the stacked (head, query) rows
-                for j, h in enumerate(heads):
-                    ops.transpose_slots(q[b * T:(b + 1) * T, h * hd:(h + 1) * hd], qsT[:, j * Tp:], max_rows=T, C_cols=hd)
-                    ops.transpose_slots(d_ao[b * T:(b + 1) * T, h * hd:(h + 1) * hd], dosT[:, j * Tp:], max_rows=T, C_cols=hd)
-                dST = ops.transpose(dS)                                        # [Tp][G*Tp]
-                PT = ops.transpose(P)
-                ops.tiled_gemm([dict(w=qsT, static_count=T)], dST, dk[b, g], max_rows=T, epilogue=ops.EPI_BF16)
-                ops.tiled_gemm([dict(w=dosT, static_count=T)], PT, dv[b, g], max_rows=T, epilogue=ops.EPI_BF16)
+        kv_host = (C.c_int32 * B)(*[int(v) for v in fv])
+        a = L.AttnBwdArgs(q=q.data_ptr(), k_cache=kc.data_ptr(), v_cache=vc.data_ptr(), kv_start_host=C.cast(kv_host, C.c_void_p),
+                          d_out=d_ao.data_ptr(), rows=B, T=T, H=H, KVH=KVH, hd=hd, Lmax=T, scale=scale, dq=dq.data_ptr(),
+                          dk_cache=dk.data_ptr(), dv_cache=dv.data_ptr())
+        nbytes = lib.umoe_attn_prefill_bwd_workspace_bytes(C.byref(a))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        a.ws, a.ws_bytes = ws.data_ptr(), nbytes
+        L.check(lib.umoe_attn_prefill_bwd(C.byref(a), ops._stream()), "umoe_attn_prefill_bwd")
         # mRoPE backward + scatter into the QKV row layout
         n_tok = B * T
         dqkv = torch.empty((n_tok, (H + 2 * KVH) * hd), dtype=bf, device=dev)
