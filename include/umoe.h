@@ -233,6 +233,17 @@ typedef struct {
 } umoe_combine_args;
 int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_stream_t stream);
 
+/* ------------------------------------------------------------------ expert-parallel exchange (RCCL over xGMI)
+ * The all-to-all of DeepSpeed's _AllToAll in the reference (core.py:467,480; utils.py:332-335).  `comm` is an opaque
+ * ncclComm_t; librccl is resolved at first use.  Every rank exchanges slabs of equal size (fixed per-destination capacity
+ * of unimoe_audio_amd/ep.py): send + p*bytes goes to peer p, peer p's slab lands at recv + p*bytes; enqueued on `stream`.
+ * umoe_ep_unique_id (rank 0, 128 bytes to broadcast out of band) + umoe_ep_comm_create build a communicator where the
+ * caller has none to pass in. */
+int umoe_ep_unique_id(void* out128);
+int umoe_ep_comm_create(const void* uid128, int rank, int nranks, void** comm_out);
+int umoe_ep_comm_destroy(void* comm);
+int umoe_ep_all_to_all(void* comm, const void* send, void* recv, size_t bytes_per_peer, int nranks, umoe_stream_t stream);
+
 /* ------------------------------------------------------------------ backward pieces (training, BASELINE config 3)
  * The contractions run on umoe_tiled_gemm (operands K-contiguous): dX = dY * W uses a transposed weight copy, dW = dY^T X
  * contracts over the slot columns of transposed, 8-aligned, zero-padded buffers built by umoe_transpose_slots

@@ -671,3 +671,18 @@ def test_codec_cross_entropy_fwd_bwd(dev):
     assert torch.allclose(total.cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
     assert int(ch_cnt[7]) == 0 and torch.equal(ch_cnt.cpu().long(), (labels != -100).sum(0))
     assert torch.allclose(dl.cpu(), logits.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_ep_all_to_all_rccl_single_rank(dev):
+    """umoe_ep_all_to_all through librccl with a one-rank communicator built by umoe_ep_unique_id / umoe_ep_comm_create:
+    the exchange with oneself returns the slab unchanged (plumbing, stream ordering, error path).  The multi-rank semantics
+    of the exchange are covered by tests/test_ep_gloo.py (world size 2)."""
+    from unimoe_audio_amd import ep as EP
+    comm = EP.UmoeEpComm(None, dev)
+    assert comm.size == 1 and comm.rank == 0
+    x = torch.randn(3, 257, 64, device=dev).to(torch.bfloat16)
+    y = torch.empty_like(x)
+    comm.all_to_all(y, x)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y)
+    comm.close()

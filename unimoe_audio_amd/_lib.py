@@ -133,6 +133,7 @@ EXPORTS = [
     "umoe_unpermute_combine_bwd", "umoe_permute_bwd", "umoe_router_bwd", "umoe_rmsnorm_residual_bwd", "umoe_aux_loss_bwd", "umoe_attn_softmax_fwd", "umoe_attn_softmax_bwd", "umoe_qkv_mrope_bwd",
     "umoe_swiglu_bwd_workspace_bytes", "umoe_grouped_swiglu_bwd", "umoe_shared_swiglu_bwd",
     "umoe_attn_prefill_bwd_workspace_bytes", "umoe_attn_prefill_bwd",
+    "umoe_ep_unique_id", "umoe_ep_comm_create", "umoe_ep_comm_destroy", "umoe_ep_all_to_all",
 ]
 
 
@@ -176,6 +177,10 @@ def lib():
         L.umoe_attn_prefill_bwd_workspace_bytes.argtypes = [C.POINTER(AttnBwdArgs)]
         L.umoe_attn_prefill_bwd_workspace_bytes.restype = C.c_size_t
         L.umoe_attn_prefill_bwd.argtypes = [C.POINTER(AttnBwdArgs), vp]
+        L.umoe_ep_unique_id.argtypes = [vp]
+        L.umoe_ep_comm_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
+        L.umoe_ep_comm_destroy.argtypes = [vp]
+        L.umoe_ep_all_to_all.argtypes = [vp, vp, vp, C.c_size_t, i32, vp]
         L.umoe_router_dispatch_fwd.argtypes = [C.POINTER(RouterArgs), vp, vp, vp, vp, vp]
         L.umoe_permute_fwd.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.umoe_grouped_gemm.argtypes = [C.POINTER(GemmArgs), vp]

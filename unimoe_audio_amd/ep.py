@@ -19,7 +19,46 @@ import torch
 import torch.distributed as dist
 
 
+class UmoeEpComm:
+    """RCCL communicator behind the C-ABI (umoe_ep_comm_create / umoe_ep_all_to_all): the exchange is enqueued on the
+    caller's HIP stream by the library itself (graph-capturable), instead of going through torch.distributed.  The 128-byte
+    unique id travels over the given torch.distributed group (any backend) once, at construction."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self._C = L, C
+        self.rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+        self.size = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_char * 128)()
+            L.check(L.lib().umoe_ep_unique_id(C.cast(buf, C.c_void_p)), "umoe_ep_unique_id")
+            uid = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        if self.size > 1:
+            t = uid.to(device) if dist.get_backend(group) == "nccl" else uid
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = t.cpu()
+        raw = (C.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes()))
+        self.h = C.c_void_p()
+        L.check(L.lib().umoe_ep_comm_create(C.cast(raw, C.c_void_p), self.rank, self.size, C.byref(self.h)), "umoe_ep_comm_create")
+
+    def all_to_all(self, out: torch.Tensor, inp: torch.Tensor):
+        assert inp.is_cuda and out.is_cuda and inp.is_contiguous() and out.is_contiguous() and inp.numel() == out.numel()
+        per = inp.numel() * inp.element_size() // self.size
+        self._L.check(self._L.lib().umoe_ep_all_to_all(self.h, inp.data_ptr(), out.data_ptr(), per, self.size,
+                                                       torch.cuda.current_stream().cuda_stream), "umoe_ep_all_to_all")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.lib().umoe_ep_comm_destroy(self.h)
+            self.h = None
+
+
 def _a2a(out: torch.Tensor, inp: torch.Tensor, group):
+    if isinstance(group, UmoeEpComm):
+        return group.all_to_all(out, inp) if group.size > 1 else out.copy_(inp)
     if group is None or dist.get_world_size(group) == 1:
         out.copy_(inp)          # the reference's single-process behaviour: identity (utils.py:332-335)
     else:
