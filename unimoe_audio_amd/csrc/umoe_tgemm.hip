@@ -7,9 +7,9 @@
 //    = 4 x 4 v_mfma_f32_16x16x32_bf16 accumulators (64 registers);
 //  * K in steps of 64: the A and W tiles (16 KiB each) go global -> registers -> LDS, double-buffered, one barrier per step;
 //    the loads of step t+1 are in flight while step t is multiplied;
-//  * LDS image: 128-byte rows (64 bf16), 16-byte chunk c of row r at r*128 + ((c ^ (r & 7)) * 16): the global loads and
-//    the LDS writes are contiguous per row (8 lanes x 16 B), the ds_read_b128 operand reads (16 rows x one chunk) are
-//    spread over 8 chunk columns (2-way at worst);
+//  * LDS image: 128-byte rows (64 bf16), 16-byte chunk c of row r at r*128 + ((c ^ ((r >> 1) & 7)) * 16): the global loads
+//    and the LDS writes are contiguous per row (8 lanes x 16 B), the ds_read_b128 operand reads (16 rows x one chunk)
+//    touch every bank once;
 //  * weights are the MFMA A operand, activations the B operand (as in umoe_gemm.hip): a lane ends with 4 consecutive
 //    output features of one token -> 8-byte bf16 stores;
 //  * ragged groups: gather list / row count / row offset are read on device, workgroups beyond the count exit.
@@ -20,7 +20,10 @@
 #define TG_MAXG 12
 struct tg_pack { umoe_tgroup_t g[TG_MAXG]; };
 
-__device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+// 16-byte chunk c of tile row r.  Rows are 128 B = 32 banks, so two consecutive rows span the 64 banks; an operand read
+// takes ONE chunk column of 16 consecutive rows: rows of equal parity must land on 8 different chunk slots -> swizzle by
+// (r >> 1) & 7 (conflict-free); swizzling by r & 7 left rows r and r + 8 on the same banks (2-way).
+__device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, const tg_pack gp) {
