@@ -146,7 +146,7 @@ typedef struct {
     int ldo;
     int n_valid;              /* columns >= n_valid are not stored (N not multiple of 16) */
     int prologue, epilogue;
-    int nt;                   /* n-blocks per workgroup: 0 = auto, else 1/2/4/8 (tuning knob) */
+    int nt;                   /* n-blocks per workgroup: 0 = auto, else 1/2/4/5/6/8, SwiGLU also 14 (tuning knob) */
     int waves;                /* waves per workgroup: 0 = auto, 4, 8 (8 only with nt = 8; tuning knob) */
     int ksplit;               /* >1: K split over workgroups; needs UMOE_EPI_F32_RAW: slab s at out + s*part_stride */
     long part_stride;         /* elements between fp32 partial slabs */

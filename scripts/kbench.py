@@ -194,6 +194,31 @@ if "train" in which:
         dtf = (time.perf_counter() - t0) / n_it
         print(f"DCMoE block M={M}: fwd+bwd {dt*1e3:.2f} ms ({flops/dt/1e12:.0f} TFLOP/s algorithmic, k_real={kreal:.2f}), fwd only {dtf*1e3:.2f} ms", flush=True)
 
+if "dense" in which and "gateup" in which:
+    pass
+if "flat" in which:
+    # dense-expert decode layout (every expert computes all 16 rows): workgroup count vs CUs
+    gu = [ops.pack_gate_up(rnd(Id, D), rnd(Id, D)) for _ in range(8)] + [ops.pack_gate_up(rnd(Is, D), rnd(Is, D)) for _ in range(2)]
+    dn = [ops.pack_weight(rnd(D, Id)) for _ in range(8)] + [ops.pack_weight(rnd(D, Is)) for _ in range(2)]
+    R = 4
+    sets = []
+    for r in range(R):
+        gu_r = [g.clone() for g in gu]
+        dn_r = [g.clone() for g in dn]
+        g1 = [dict(w=gu_r[e], static_count=S, out_row_base=e * S, n_blocks=2 * (Id if e < 8 else Is) // 16, k=D) for e in range(10)]
+        g2 = [dict(w=dn_r[e], static_count=S, a_row_base=e * S, out_row_base=e * S, n_blocks=D // 16, k=(Id if e < 8 else Is)) for e in range(10)]
+        sets.append((ops.GroupTable(g1, dev), ops.GroupTable(g2, dev)))
+    hbuf = torch.zeros(10 * S, Id, device=dev, dtype=torch.bfloat16)
+    ybuf = torch.zeros(10 * S, D, device=dev, dtype=torch.bfloat16)
+    gub = (8 * 2 * Id * D + 2 * 2 * Is * D) * 2
+    dnb = (8 * Id * D + 2 * Is * D) * 2
+    for nt in (8, 14):
+        t = timeit(lambda i: ops.grouped_gemm(sets[i % R][0], x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=nt))
+        print("dense gateup nt", nt, f"{t:.2f} us  {gub/t/1e3:.0f} GB/s", flush=True)
+    for nt, wv in ((8, 8), (6, 8), (5, 8)):
+        t = timeit(lambda i: ops.grouped_gemm(sets[i % R][1], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=nt, waves=wv))
+        print("dense down nt", nt, "waves", wv, f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
+
 if "router" in which:
     gw = rnd(11, D)
     nw = torch.ones(D, device=dev, dtype=torch.bfloat16)

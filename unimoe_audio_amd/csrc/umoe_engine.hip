@@ -425,6 +425,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     gu.max_n_blocks = 2 * (ov ? c.inter_dyn : Imax) / 16; gu.max_k = D;
     gu.a = e->h2; gu.lda = D; gu.out = e->hbuf; gu.ldo = Imax; gu.n_valid = Imax;
     gu.prologue = UMOE_PRO_PLAIN; gu.epilogue = UMOE_EPI_SWIGLU;
+    if (dense) gu.nt = 14;   // at most one workgroup per CU (see umoe_gemm.hip)
     // (dense mode with the post-attention RMSNorm in this launch's staging prologue, so that it would not wait for the
     //  router at all, was measured: 46.9 vs 37.7 us per launch -- 387 workgroups redoing the norm of all 16 rows costs
     //  more than the dependency it removes; the router kernel writes the normalised rows h2 once instead)
@@ -454,6 +455,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     dn.max_k = ov ? c.inter_dyn : Imax;
     dn.a = e->hbuf; dn.lda = Imax; dn.out = e->ybuf; dn.ldo = D; dn.n_valid = D;
     dn.prologue = UMOE_PRO_PLAIN; dn.epilogue = UMOE_EPI_BF16;
+    if (dense) dn.nt = 6;    // 220 workgroups of 8 waves: 22.2 vs 23.7 us with 8 blocks per workgroup (scripts/kbench.py flat)
     if (tiled && !ov && G <= 12) {
         umoe_tgroup_t tg[12];
         memset(tg, 0, sizeof(tg));

@@ -128,6 +128,9 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     //  * ragged groups: the activation addresses hang on device-produced tables (count -> offset -> gather list), so the
     //    weight stream goes first and overlaps that chain.
     const bool ragged = g.count || g.row_off || g.rows;
+    // second register stage requested before the staging too (static groups): HBM has work queued for the whole prologue.
+    // Only where the registers allow it without spilling (checked per instantiation with -S: private_segment_fixed_size 0).
+    constexpr bool DEEP = false;   // measured: gate/up NT 14 35.3 -> 42.6 us, down 23.8 -> 29.8 us -- MORE bytes in flight made it slower
     if (ragged && i0 < i1) load_chunk(w0, i0);
     TL_MARK(KID, 4);
 
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
             if (ib0 == 0 && !ragged) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (i0 < i1) load_chunk(w0, i0);
+                if (DEEP && i0 + U < i1) load_chunk(w1, i0 + U);   // both register stages in flight while the tile is staged
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (single) {
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
         }
     };
     for (int i = i0; i < i1; i += 2 * U) {
-        if (i + U < i1) load_chunk(w1, i + U);
+        if (i + U < i1 && !(DEEP && !ragged && i == i0)) load_chunk(w1, i + U);
         compute_chunk(w0, i);
         if (i + 2 * U < i1) load_chunk(w0, i + 2 * U);
         if (i + U < i1) compute_chunk(w1, i + U);
@@ -406,7 +410,7 @@ static int launch_gemm_nt(const umoe_gemm_args* a, int nt, hipStream_t s) {
         case 6: return use8(a, 6) ? launch_gemm<6, 2, PRO, EPI, 8>(a, s) : launch_gemm<6, 2, PRO, EPI>(a, s);
         case 8: return use8(a, 8) ? launch_gemm<8, 2, PRO, EPI, 8>(a, s) : launch_gemm<8, 2, PRO, EPI>(a, s);
     }
-    UMOE_REQUIRE(false, "umoe_grouped_gemm: nt must be 1, 2, 4, 5, 6 or 8 (got %d)", nt);
+    UMOE_REQUIRE(false, "umoe_grouped_gemm: nt must be 1, 2, 4, 5, 6 or 8 (SwiGLU: also 14) (got %d)", nt);
 }
 
 static int auto_nt(const umoe_gemm_args* a, bool swiglu) {
@@ -460,6 +464,10 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
             if (nt == 2) return launch_gemm<2, 8, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
             if (nt == 4) return launch_gemm<4, 4, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
             if (nt == 6) return launch_gemm<6, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
+            // 7 gate/up pairs per 8-wave workgroup: 226 workgroups for the dense decode shape = at most ONE per CU.  The
+            // per-CU byte balance decides this kernel (scripts/kbench.py flat): NT 8 -> 387 workgroups, half of the CUs carry
+            // two: 39.3 us; NT 12 -> 262 workgroups, six CUs carry two: 51.0 us; NT 14: 35.3-37.0 us; NT 16 (198 CUs): 43.0 us
+            if (nt == 14) return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s);
             return use8(a, 8) ? launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s)
                                  : launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
         }
