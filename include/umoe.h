@@ -152,6 +152,8 @@ typedef struct {
     long part_stride;         /* elements between fp32 partial slabs */
     const umoe_group_t* groups_host; /* optional HOST copy of `groups`: with num_groups <= UMOE_GROUPS_INLINE the
                                * descriptors travel in the kernel arguments (one dependent HBM round trip less per launch) */
+    int flat_wgs;             /* SwiGLU, static groups over the same <= 16 rows (dense-expert decode): > 0 = that many workgroups
+                               * take equal slices of ALL groups' gate/up pairs (<= 7 each; per-CU byte balance) */
     int cache_policy;         /* reserved (0): the weight stream is always non-temporal -- a default-policy variant and an
                                * Infinity Cache warm-up were measured and bought nothing */
 } umoe_gemm_args;

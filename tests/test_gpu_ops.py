@@ -686,3 +686,26 @@ def test_ep_all_to_all_rccl_single_rank(dev):
     torch.cuda.synchronize()
     assert torch.equal(x, y)
     comm.close()
+
+
+@pytest.mark.parametrize("fw", [256, 231, 512])
+def test_dense_gateup_flat_slices_equal_per_group_grid(dev, fw):
+    """Flat mode of the decode gate/up launch (equal slices of all groups' pairs per workgroup, slices straddling two
+    groups) must be bit-identical to the per-group grid: same kernel arithmetic, only the work assignment changes."""
+    from unimoe_audio_amd import ops
+    gen = torch.Generator().manual_seed(21)
+    S, D, Id, Is = 16, 2048, 2752, 1376
+    x = (torch.randn(S, D, generator=gen) * 1.0).to(torch.bfloat16).to(dev)
+    sizes = [Id] * 8 + [Is] * 2
+    groups = []
+    for e, I in enumerate(sizes):
+        wg = (torch.randn(I, D, generator=gen) * 0.03).to(torch.bfloat16).to(dev)
+        wu = (torch.randn(I, D, generator=gen) * 0.03).to(torch.bfloat16).to(dev)
+        groups.append(dict(w=ops.pack_gate_up(wg, wu), static_count=S, out_row_base=e * S, n_blocks=2 * I // 16, k=D))
+    tab = ops.GroupTable(groups, dev)
+    a = torch.zeros(10 * S, Id, dtype=torch.bfloat16, device=dev)
+    b = torch.zeros_like(a)
+    ops.grouped_gemm(tab, x, a, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=14)
+    ops.grouped_gemm(tab, x, b, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=14, flat_wgs=fw)
+    assert torch.equal(a, b)
+    assert float(a[:8 * S].float().abs().sum()) > 0 and float(a[8 * S:, :Is].float().abs().sum()) > 0

@@ -76,6 +76,8 @@ struct umoe_engine {
     // decode with >= 6 rows: every routed expert is hit with probability ~1, so each expert computes ALL rows (no gather
     // lists, no dispatch kernel, no device-produced row counts in the GEMM prologues) and the combine selects by mask
     bool dense_experts = true;
+    int flat_wgs = 0;            // UMOE_FLAT_WGS: workgroups of the flat gate/up launch; measured 42.4 us (256 slices of 6-7
+                                 // pairs, the 7th slot of a 6-pair slice re-reads) vs 37.3 us for the per-group grid -> off
     bool tiled_prefill = true;   // UMOE_TILED_PREFILL=0: weight-streaming kernels for every row count (A/B, tests)
     bool overlap_shared = false;  // measured on MI355X: 1429 vs 1825 tok/s -- cross-stream graph edges cost more than they hide
     // optional per-kernel-class timing of one eager step (hipEvents on the launch stream)
@@ -237,6 +239,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (const char* v = getenv("UMOE_OVERLAP_SHARED")) e->overlap_shared = atoi(v) != 0;
     if (const char* v = getenv("UMOE_DENSE_EXPERTS")) e->dense_experts = atoi(v) != 0;
     if (const char* v = getenv("UMOE_TILED_PREFILL")) e->tiled_prefill = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_FLAT_WGS")) e->flat_wgs = atoi(v);
     *out = e;
     return 0;
 }
@@ -425,7 +428,10 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     gu.max_n_blocks = 2 * (ov ? c.inter_dyn : Imax) / 16; gu.max_k = D;
     gu.a = e->h2; gu.lda = D; gu.out = e->hbuf; gu.ldo = Imax; gu.n_valid = Imax;
     gu.prologue = UMOE_PRO_PLAIN; gu.epilogue = UMOE_EPI_SWIGLU;
-    if (dense) gu.nt = 14;   // at most one workgroup per CU (see umoe_gemm.hip)
+    if (dense) {             // per-CU byte balance decides this kernel (see umoe_gemm.hip): 7 pairs per workgroup, flat slices
+        gu.nt = 14;
+        if (e->flat_wgs > 0 && ceil_div((c.n_real * c.inter_dyn + c.n_fix * c.inter_shared) / 16, e->flat_wgs) <= 7) gu.flat_wgs = e->flat_wgs;
+    }
     // (dense mode with the post-attention RMSNorm in this launch's staging prologue, so that it would not wait for the
     //  router at all, was measured: 46.9 vs 37.7 us per launch -- 387 workgroups redoing the norm of all 16 rows costs
     //  more than the dependency it removes; the router kernel writes the normalised rows h2 once instead)

@@ -79,11 +79,35 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     (void)KID;
     TL_ENTER(KID);
     // group descriptor: from the kernel arguments when the host passed them by value (scalar loads, no HBM round trip)
-    const umoe_group_t g = p.groups_host ? gp.g[blockIdx.z] : p.groups[blockIdx.z];
+    // FLAT mode (SwiGLU, dense-expert decode: every group reads the SAME activation rows): blockIdx.x enumerates
+    // p.flat_wgs equal slices of ALL groups' gate/up pairs, so every CU streams the same number of bytes whatever the
+    // group sizes are (the per-CU byte balance decides this kernel, see the launcher).  A slice may straddle two groups.
+    const bool flat = EPI == UMOE_EPI_SWIGLU && p.flat_wgs > 0;
+    const umoe_group_t g = p.groups_host ? gp.g[flat ? 0 : blockIdx.z] : p.groups[blockIdx.z];
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int ks = blockIdx.x % ksplit;      // K-slice of this workgroup (fp32 partial slab `ks`)
     const int nb0 = (blockIdx.x / ksplit) * NT;
-    if (nb0 >= g.n_blocks) return;
+    int fp0 = 0, fnp = 0;                    // flat: first global pair and number of pairs of this workgroup
+    if (flat) {
+        int P = 0;
+        for (int i = 0; i < p.num_groups; ++i) P += gp.g[i].n_blocks >> 1;
+        fp0 = (int)(((long)blockIdx.x * P) / p.flat_wgs);
+        fnp = (int)(((long)(blockIdx.x + 1) * P) / p.flat_wgs) - fp0;
+        if (fnp <= 0) return;
+    } else if (nb0 >= g.n_blocks) {
+        return;
+    }
+    // flat: global pair -> (group, pair inside the group)
+    auto locate = [&](int pp, int& grp, int& lp) {
+        grp = 0;
+        lp = pp;
+        for (int i = 0; i + 1 < p.num_groups; ++i) {
+            const int np = gp.g[i].n_blocks >> 1;
+            if (lp < np) break;
+            lp -= np;
+            grp = i + 1;
+        }
+    };
 
     const int K = g.k, KB = K >> 5;
     // this workgroup covers MFMA k-steps [ia, ib) of every K-quarter; only those activation chunks are staged
@@ -110,8 +134,14 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const int nb = min(nb0 + t, g.n_blocks - 1);  // tail tiles re-read the last block; never stored
-        wp[t] = reinterpret_cast<const u32x4_t*>(g.w) + ((size_t)nb * KB) * 64 + lane;
+        if (flat) {
+            int grp, lp;
+            locate(fp0 + min(t >> 1, fnp - 1), grp, lp);    // pairs beyond the slice re-read its last pair; never stored
+            wp[t] = reinterpret_cast<const u32x4_t*>(gp.g[grp].w) + ((size_t)(2 * lp + (t & 1)) * KB) * 64 + lane;
+        } else {
+            const int nb = min(nb0 + t, g.n_blocks - 1);  // tail tiles re-read the last block; never stored
+            wp[t] = reinterpret_cast<const u32x4_t*>(g.w) + ((size_t)nb * KB) * 64 + lane;
+        }
     }
     u32x4_t w0[NT][U], w1[NT][U];
     auto load_chunk = [&](u32x4_t (&dst)[NT][U], int ibase) {
@@ -298,9 +328,19 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     const long orow = (long)g.out_row_base + roff + r;
     if (EPI == UMOE_EPI_SWIGLU) {
         for (int q = wave; q < NT / 2; q += WV) {
-            if (nb0 + 2 * q >= g.n_blocks) break;
+            int col;
+            long orow_q = orow;
+            if (flat) {
+                if (q >= fnp) break;
+                int grp, lp;
+                locate(fp0 + q, grp, lp);
+                col = lp * 16 + 4 * h;
+                orow_q = (long)gp.g[grp].out_row_base + roff + r;
+            } else {
+                if (nb0 + 2 * q >= g.n_blocks) break;
+                col = (nb0 / 2 + q) * 16 + 4 * h;
+            }
             const f32x4_t ga = reduced(2 * q), ua = reduced(2 * q + 1);
-            const int col = (nb0 / 2 + q) * 16 + 4 * h;
             uint16_t y[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -309,7 +349,7 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
                 const float si = rbf(gt / (1.0f + expf(-gt)));
                 y[j] = f2bf(si * up);
             }
-            uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + col;
+            uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow_q * p.ldo + col;
             *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
         }
         TL_EXIT(KID);
@@ -380,6 +420,7 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
         configured = lds;
     }
     dim3 grid((unsigned)(ceil_div(a->max_n_blocks, NT) * ksplit), (unsigned)ceil_div(a->max_rows, 16), (unsigned)a->num_groups);
+    if (EPI == UMOE_EPI_SWIGLU && a->flat_wgs > 0) grid = dim3((unsigned)a->flat_wgs, 1, 1);
     umoe_group_pack gp;
     umoe_gemm_args b = *a;
     if (a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE) {
@@ -459,6 +500,21 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
             return launch_gemm_nt<UMOE_PRO_PLAIN, UMOE_EPI_BF16_RESID>(a, auto_nt(a, false), s);
         case UMOE_EPI_SWIGLU: {
             UMOE_REQUIRE(a->max_n_blocks % 2 == 0, "umoe_grouped_gemm: SwiGLU needs gate/up block pairs");
+            if (a->flat_wgs > 0) {
+                // flat slices over all groups: static groups sharing the activation rows, descriptors by value, 7 pairs max
+                UMOE_REQUIRE(a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE && a->max_rows <= 16 && a->ksplit <= 1,
+                             "umoe_grouped_gemm: flat mode needs host group descriptors, <= 16 rows, no K split");
+                long P = 0;
+                for (int i = 0; i < a->num_groups; ++i) {
+                    const umoe_group_t& gi = a->groups_host[i];
+                    UMOE_REQUIRE(!gi.count && !gi.rows && !gi.row_off && gi.k == a->groups_host[0].k && gi.a_row_base == a->groups_host[0].a_row_base &&
+                                     gi.static_count == a->groups_host[0].static_count && gi.n_blocks % 2 == 0,
+                                 "umoe_grouped_gemm: flat mode needs static groups over the same rows and K (group %d)", i);
+                    P += gi.n_blocks / 2;
+                }
+                UMOE_REQUIRE(ceil_div((int)P, a->flat_wgs) <= 7, "umoe_grouped_gemm: flat mode: %ld pairs over %d workgroups exceed 7 per workgroup", P, a->flat_wgs);
+                return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s);
+            }
             const int nt = auto_nt(a, true);
             UMOE_REQUIRE(nt >= 2, "umoe_grouped_gemm: SwiGLU needs nt >= 2");
             if (nt == 2) return launch_gemm<2, 8, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);

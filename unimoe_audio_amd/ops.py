@@ -200,12 +200,12 @@ class GroupTable:
 
 def grouped_gemm(table: GroupTable, a: torch.Tensor, out: torch.Tensor, *, max_rows: int, prologue=PRO_PLAIN,
                  epilogue=EPI_BF16, norm_w=None, rms_eps=1e-6, resid=None, n_valid=None, nt=0, waves=0, ksplit=0, part_stride=0,
-                 cache_policy=0):
+                 cache_policy=0, flat_wgs=0):
     args = L.GemmArgs(groups=_p(table.dev), num_groups=table.n, max_rows=max_rows, max_n_blocks=table.max_n_blocks,
                       max_k=table.max_k, a=_p(a), lda=a.stride(0), norm_w=_p(norm_w), rms_eps=rms_eps, resid=_p(resid),
                       out=_p(out), ldo=out.stride(-2), n_valid=out.shape[1] if n_valid is None else n_valid,
                       prologue=prologue, epilogue=epilogue, nt=nt, waves=waves, ksplit=ksplit, part_stride=part_stride,
-                      groups_host=C.cast(table.host, C.c_void_p), cache_policy=cache_policy)
+                      groups_host=C.cast(table.host, C.c_void_p), cache_policy=cache_policy, flat_wgs=flat_wgs)
     L.check(L.lib().umoe_grouped_gemm(C.byref(args), _stream()), "umoe_grouped_gemm")
     return out
 
