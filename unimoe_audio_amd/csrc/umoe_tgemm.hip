@@ -15,23 +15,39 @@
 //  * ragged groups: gather list / row count / row offset are read on device, workgroups beyond the count exit.
 // Roofline: MFMA (2.5 PFLOP/s dense bf16).  Intensity of a 128x128 tile: 64 flop per byte moved from L2.
 #include "umoe_common.h"
+#include <stdlib.h>
 #include <string.h>
 
 #define TG_MAXG 12
 struct tg_pack { umoe_tgroup_t g[TG_MAXG]; };
 
-// 16-byte chunk c of tile row r.  Rows are 128 B = 32 banks, so two consecutive rows span the 64 banks; an operand read
-// takes ONE chunk column of 16 consecutive rows: rows of equal parity must land on 8 different chunk slots -> swizzle by
-// (r >> 1) & 7 (conflict-free); swizzling by r & 7 left rows r and r + 8 on the same banks (2-way).
-__device__ __forceinline__ int tg_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// 16-byte chunk c of tile row r, rows of BKC chunks.  An operand read takes ONE chunk column of 16 consecutive rows; rows
+// are BKC*16 B = BKC*4 banks, so 16/BKC consecutive rows span the 64 banks and the rows that share banks (every 16/BKC-th)
+// must land on different chunk slots -> swizzle by (r / (16/BKC)) % BKC: conflict-free (SQ_LDS_BANK_CONFLICT = 0).
+template <int BKC>
+__device__ __forceinline__ int tg_off(int row, int chunk) {
+    constexpr int SH = BKC == 8 ? 1 : 2;
+    return row * (BKC * 16) + ((chunk ^ ((row >> SH) & (BKC - 1))) << 4);
+}
 
-template <int EPI>
+// MI = 16-token sub-tiles per wave: 4 -> 128-token tiles, K steps of 64 (BKC 8), 64 x 64 wave tiles;
+//                                   8 -> 256-token tiles, K steps of 32 (BKC 4), 128 x 64 wave tiles (12 operand reads per 32 MFMAs
+//                                        instead of 16: the 64 x 64 wave tile is LDS-bandwidth bound at full MFMA rate)
+// one 16-byte block of zeros: the LDS-DMA source of chunks outside a tile (rows beyond the count, K tail)
+__device__ __attribute__((aligned(16))) uint4 tg_zero16;
+
+template <int EPI, int MI, int BKC, bool GLDS>
 __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, const tg_pack gp) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A 16 KiB | W 16 KiB]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile]
+    constexpr int TM = 32 * MI;                 // token rows per workgroup
+    constexpr int RPP = 256 / BKC;              // tile rows covered by one load pass of the 256 threads
+    constexpr int APS = TM / RPP, WPS = 128 / RPP;
+    constexpr int ABYTES = TM * BKC * 16, WBYTES = 128 * BKC * 16, BUF = ABYTES + WBYTES;
+    constexpr int KS = BKC / 4;                 // MFMA k-steps (32 wide) per K iteration
     const umoe_tgroup_t g = gp.g[blockIdx.z];
     const int count = g.count ? *g.count : g.static_count;
     const int roff = g.row_off ? *g.row_off : 0;
-    const int row0 = blockIdx.y * 128;
+    const int row0 = blockIdx.y * TM;
     if (row0 >= count) return;
     // SwiGLU: the tile's 128 weight rows are 64 gate rows and the 64 up rows of the same features
     constexpr bool SW = EPI == UMOE_EPI_SWIGLU;
@@ -43,19 +59,22 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- global -> register tile loads: thread (lr = tid / 8, ch = tid % 8) owns chunk ch of rows lr + 32 * pass -----
-    const int lr = tid >> 3, ch = tid & 7;
-    const uint16_t* ap[4];
-    const uint16_t* wp[4];
-    bool aok[4], wok[4];
+    // ---- global -> register tile loads: thread (lr = tid / BKC, ch = tid % BKC) owns chunk ch of rows lr + RPP * pass -----
+    const int lr = tid / BKC, ch = tid % BKC;
+    const uint16_t* ap[APS];
+    const uint16_t* wp[WPS];
+    bool aok[APS], wok[WPS];
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int r = row0 + lr + 32 * ps;
+    for (int ps = 0; ps < APS; ++ps) {
+        const int r = row0 + lr + RPP * ps;
         aok[ps] = r < count;
         long arow = 0;
         if (aok[ps]) arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
         ap[ps] = p.a + arow * (long)p.lda + g.a_col_off + koff + ch * 8;
-        const int tr = lr + 32 * ps;   // tile row 0..127
+    }
+#pragma unroll
+    for (int ps = 0; ps < WPS; ++ps) {
+        const int tr = lr + RPP * ps;   // tile row 0..127
         int n;
         const uint16_t* wb = g.w;
         if (SW) {
@@ -67,71 +86,138 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
         wok[ps] = n < g.n;
         wp[ps] = wb + (long)(wok[ps] ? n : 0) * g.ldw + koff + ch * 8;
     }
-    uint4 ra[4], rw[4];
+    uint4 ra[APS], rw[WPS];
     auto gload = [&](int k0) {
         const bool kok = k0 + ch * 8 < K;   // K % 8 == 0: a chunk is entirely inside or outside
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
+        for (int ps = 0; ps < APS; ++ps) {
             ra[ps] = make_uint4(0, 0, 0, 0);
-            rw[ps] = make_uint4(0, 0, 0, 0);
             if (kok && aok[ps]) ra[ps] = ld16(ap[ps] + k0);
+        }
+#pragma unroll
+        for (int ps = 0; ps < WPS; ++ps) {
+            rw[ps] = make_uint4(0, 0, 0, 0);
             if (kok && wok[ps]) rw[ps] = ld16(wp[ps] + k0);
         }
     };
     auto lstore = [&](int buf) {
-        char* A = smem + buf * 32768;
-        char* W = A + 16384;
+        char* A = smem + buf * BUF;
+        char* W = A + ABYTES;
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int tr = lr + 32 * ps;
-            st16(A + tg_off(tr, ch), ra[ps]);
-            st16(W + tg_off(tr, ch), rw[ps]);
+        for (int ps = 0; ps < APS; ++ps) st16(A + tg_off<BKC>(lr + RPP * ps, ch), ra[ps]);
+#pragma unroll
+        for (int ps = 0; ps < WPS; ++ps) st16(W + tg_off<BKC>(lr + RPP * ps, ch), rw[ps]);
+    };
+
+    // ---- LDS-DMA staging (global_load_lds_dwordx4): one wave-instruction writes 1 KiB of LDS at wave-uniform base +
+    //      lane * 16 = 64 / BKC whole tile rows; the swizzle goes on the per-lane SOURCE address (the LDS image is the same
+    //      as with register staging).  No data registers, no ds_write pass; chunks outside the tile read a block of zeros.
+    constexpr int RPG = 64 / BKC;                         // tile rows per wave-instruction
+    constexpr int AGW = TM / RPG / 4, WGW = 128 / RPG / 4;   // groups per wave
+    const uint16_t* gap[GLDS ? AGW : 1];
+    const uint16_t* gwp[GLDS ? WGW : 1];
+    int gch = 0;                                          // this lane's chunk (same for every group: row & swizzle mask repeats)
+    if (GLDS) {
+        const int rl = lane / BKC, slot = lane % BKC;
+#pragma unroll
+        for (int j = 0; j < AGW; ++j) {
+            const int tr = (wave + 4 * j) * RPG + rl;     // tile row
+            constexpr int SH = BKC == 8 ? 1 : 2;
+            const int c = slot ^ ((tr >> SH) & (BKC - 1));
+            gch = c;                                      // RPG * 4 is a multiple of the swizzle period: c does not depend on j
+            const int r = row0 + tr;
+            gap[j] = nullptr;
+            if (r < count) {
+                const long arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
+                gap[j] = p.a + arow * (long)p.lda + g.a_col_off + koff + c * 8;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WGW; ++j) {
+            const int tr = (wave + 4 * j) * RPG + rl;
+            constexpr int SH = BKC == 8 ? 1 : 2;
+            const int c = slot ^ ((tr >> SH) & (BKC - 1));
+            int n;
+            const uint16_t* wb = g.w;
+            if (SW) {
+                n = n0 + (tr & 63);
+                if (tr >= 64) wb = g.w2;
+            } else {
+                n = n0 + tr;
+            }
+            gwp[j] = n < g.n ? wb + (long)n * g.ldw + koff + c * 8 : nullptr;
+        }
+    }
+    auto stage = [&](int buf, int k0) {
+        const bool kok = k0 + gch * 8 < K;
+        const uint16_t* zero = reinterpret_cast<const uint16_t*>(&tg_zero16);
+        char* A = smem + buf * BUF;
+        char* W = A + ABYTES;
+#pragma unroll
+        for (int j = 0; j < AGW; ++j) {
+            const uint16_t* src = (kok && gap[j]) ? gap[j] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(A + (wave + 4 * j) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < WGW; ++j) {
+            const uint16_t* src = (kok && gwp[j]) ? gwp[j] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(W + (wave + 4 * j) * 1024), 16, 0, 0);
         }
     };
 
-    f32x4_t acc[4][4];   // [weight sub-tile j][token sub-tile i]
+    f32x4_t acc[4][MI];   // [weight sub-tile j][token sub-tile i]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int h = lane >> 4, c16 = lane & 15;
-    // wave (wm, wn): token rows [64 wm, +64); weight rows: plain [64 wn, +64); SwiGLU gate [32 wn, +32) and up [64 + 32 wn, +32)
+    // wave (wm, wn): token rows [16 MI wm, +16 MI); weight rows: plain [64 wn, +64); SwiGLU gate [32 wn, +32), up [64 + 32 wn, +32)
     int wrow[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wrow[j] = SW ? ((j < 2 ? 0 : 64) + 32 * wn + 16 * (j & 1)) : (64 * wn + 16 * j);
 
-    const int KT = (K + 63) >> 6;
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    constexpr int BK = BKC * 8;
+    const int KT = (K + BK - 1) / BK;
+    if (GLDS) {
+        stage(0, 0);
+    } else {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();     // (with an LDS-DMA in flight the barrier's fence waits vmcnt(0): the tile has landed)
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) gload((kt + 1) << 6);
-        const char* A = smem + buf * 32768;
-        const char* W = A + 16384;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8_t af[4], wf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(A + tg_off(64 * wm + 16 * i + c16, s * 4 + h)));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(W + tg_off(wrow[j] + c16, s * 4 + h)));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        if (kt + 1 < KT) {
+            if (GLDS) stage(buf ^ 1, (kt + 1) * BK);   // buffer buf^1 was last read in iteration kt-1, behind a barrier
+            else gload((kt + 1) * BK);
         }
-        if (kt + 1 < KT) lstore(buf ^ 1);
+        const char* A = smem + buf * BUF;
+        const char* W = A + ABYTES;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8_t af[MI], wf[4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(A + tg_off<BKC>(16 * MI * wm + 16 * i + c16, s * 4 + h)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(W + tg_off<BKC>(wrow[j] + c16, s * 4 + h)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        if (!GLDS && kt + 1 < KT) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: acc[j][i] lane (h, c16): token row 64 wm + 16 i + c16, features (weight rows) wrow[j] + 4 h .. +3 ----
+    // ---- epilogue: acc[j][i] lane (h, c16): token row 16 MI wm + 16 i + c16, features (weight rows) wrow[j] + 4 h .. +3 ----
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = row0 + 64 * wm + 16 * i + c16;
+    for (int i = 0; i < MI; ++i) {
+        const int r = row0 + 16 * MI * wm + 16 * i + c16;
         if (r >= count) continue;
         const long orow = (long)g.out_row_base + roff + r;
         const int oc = g.out_col_off;
@@ -196,21 +282,44 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
     }
 }
 
-template <int EPI>
-static int launch_tgemm(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
+template <int EPI, int MI, int BKC, bool GLDS>
+static int launch_tgemm_v(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
     tg_pack gp;
     memset(&gp, 0, sizeof(gp));
     memcpy(gp.g, a->groups, sizeof(umoe_tgroup_t) * a->num_groups);
+    constexpr int lds = 2 * (32 * MI * BKC * 16 + 128 * BKC * 16);
     static bool configured = false;
     if (!configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<EPI, MI, BKC, GLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
     const int ntile = EPI == UMOE_EPI_SWIGLU ? 64 : 128;
-    dim3 grid((unsigned)ceil_div(max_n, ntile), (unsigned)ceil_div(a->max_rows, 128), (unsigned)a->num_groups);
-    tgemm_kernel<EPI><<<grid, 256, 65536, s>>>(*a, gp);
+    dim3 grid((unsigned)ceil_div(max_n, ntile), (unsigned)ceil_div(a->max_rows, 32 * MI), (unsigned)a->num_groups);
+    tgemm_kernel<EPI, MI, BKC, GLDS><<<grid, 256, lds, s>>>(*a, gp);
     UMOE_LAUNCH_CHECK();
     return 0;
+}
+
+// tile choice: 256-token tiles (128 x 64 wave tiles) once there are enough rows to fill the chip with them
+static int tgemm_tm(const umoe_tgemm_args* a) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* v = getenv("UMOE_TGEMM_TM");
+        forced = v ? atoi(v) : 0;
+    }
+    if (forced == 128 || forced == 256) return forced;
+    return a->max_rows >= 1024 ? 256 : 128;
+}
+
+template <int EPI>
+static int launch_tgemm(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
+    static int glds = -1;
+    if (glds < 0) {
+        const char* v = getenv("UMOE_TGEMM_GLDS");
+        glds = v ? atoi(v) : 1;
+    }
+    if (tgemm_tm(a) == 256) return glds ? launch_tgemm_v<EPI, 8, 4, true>(a, max_n, s) : launch_tgemm_v<EPI, 8, 4, false>(a, max_n, s);
+    return glds ? launch_tgemm_v<EPI, 4, 8, true>(a, max_n, s) : launch_tgemm_v<EPI, 4, 8, false>(a, max_n, s);
 }
 
 extern "C" int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream) {
