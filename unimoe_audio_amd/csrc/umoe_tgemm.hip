@@ -5,8 +5,10 @@
 // Design (MI355X / gfx950):
 //  * one 256-thread workgroup per 128 x 128 output tile, 4 waves as 2 (rows) x 2 (columns), each wave a 64 x 64 sub-tile
 //    = 4 x 4 v_mfma_f32_16x16x32_bf16 accumulators (64 registers);
-//  * K in steps of 64: the A and W tiles (16 KiB each) go global -> registers -> LDS, double-buffered, one barrier per step;
-//    the loads of step t+1 are in flight while step t is multiplied;
+//  * tiles are staged by LDS-DMA (global_load_lds_dwordx4: no data registers, no ds_write pass; the swizzle sits on the
+//    per-lane source address); >= 1024 rows: 256-token tiles (128 x 64 wave tiles), K steps of 32, THREE LDS stages with the
+//    DMA of tile t+2 in flight across the barrier (counted vmcnt + raw s_barrier); fewer rows: 128-token tiles, K steps of 64,
+//    two stages; register staging kept as a variant;
 //  * LDS image: 128-byte rows (64 bf16), 16-byte chunk c of row r at r*128 + ((c ^ ((r >> 1) & 7)) * 16): the global loads
 //    and the LDS writes are contiguous per row (8 lanes x 16 B), the ds_read_b128 operand reads (16 rows x one chunk)
 //    touch every bank once;
@@ -36,7 +38,11 @@ __device__ __forceinline__ int tg_off(int row, int chunk) {
 // one 16-byte block of zeros: the LDS-DMA source of chunks outside a tile (rows beyond the count, K tail)
 __device__ __attribute__((aligned(16))) uint4 tg_zero16;
 
-template <int EPI, int MI, int BKC, bool GLDS>
+// NST: LDS stages.  0 = register staging (2 buffers); 2 = LDS-DMA, 2 buffers, one __syncthreads per K step (its fence waits for
+// the DMA); 3 = LDS-DMA, 3 buffers, the DMA of tile t+2 stays in flight ACROSS the barrier: counted s_waitcnt vmcnt(N) + raw s_barrier
+// (a wave waits for its own pieces of tile t, the barrier makes every wave's pieces visible; the buffer restaged after the
+// barrier was last read one iteration earlier)
+template <int EPI, int MI, int BKC, int NST>
 __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, const tg_pack gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A tile | W tile]
     constexpr int TM = 32 * MI;                 // token rows per workgroup
@@ -44,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
     constexpr int APS = TM / RPP, WPS = 128 / RPP;
     constexpr int ABYTES = TM * BKC * 16, WBYTES = 128 * BKC * 16, BUF = ABYTES + WBYTES;
     constexpr int KS = BKC / 4;                 // MFMA k-steps (32 wide) per K iteration
+    constexpr bool GLDS = NST >= 2;
     const umoe_tgroup_t g = gp.g[blockIdx.z];
     const int count = g.count ? *g.count : g.static_count;
     const int roff = g.row_off ? *g.row_off : 0;
@@ -181,16 +188,26 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
 
     constexpr int BK = BKC * 8;
     const int KT = (K + BK - 1) / BK;
-    if (GLDS) {
+    if (NST == 3) {
+        stage(0, 0);
+        if (KT > 1) stage(1, BK);
+    } else if (GLDS) {
         stage(0, 0);
     } else {
         gload(0);
         lstore(0);
     }
-    __syncthreads();     // (with an LDS-DMA in flight the barrier's fence waits vmcnt(0): the tile has landed)
+    if (NST != 3) __syncthreads();     // (with an LDS-DMA in flight the barrier's fence waits vmcnt(0): the tile has landed)
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) {
+        int buf = kt & 1;
+        if (NST == 3) {
+            buf = kt % 3;
+            // this wave's pieces of tile kt have landed once at most the NEWER tile's AGW + WGW DMAs are outstanding
+            if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AGW + WGW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < KT) stage((kt + 2) % 3, (kt + 2) * BK);
+        } else if (kt + 1 < KT) {
             if (GLDS) stage(buf ^ 1, (kt + 1) * BK);   // buffer buf^1 was last read in iteration kt-1, behind a barrier
             else gload((kt + 1) * BK);
         }
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
                 for (int i = 0; i < MI; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
         }
         if (!GLDS && kt + 1 < KT) lstore(buf ^ 1);
-        __syncthreads();
+        if (NST != 3) __syncthreads();
     }
 
     // ---- epilogue: acc[j][i] lane (h, c16): token row 16 MI wm + 16 i + c16, features (weight rows) wrow[j] + 4 h .. +3 ----
@@ -282,20 +299,20 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
     }
 }
 
-template <int EPI, int MI, int BKC, bool GLDS>
+template <int EPI, int MI, int BKC, int NST>
 static int launch_tgemm_v(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
     tg_pack gp;
     memset(&gp, 0, sizeof(gp));
     memcpy(gp.g, a->groups, sizeof(umoe_tgroup_t) * a->num_groups);
-    constexpr int lds = 2 * (32 * MI * BKC * 16 + 128 * BKC * 16);
+    constexpr int lds = (NST == 3 ? 3 : 2) * (32 * MI * BKC * 16 + 128 * BKC * 16);
     static bool configured = false;
     if (!configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<EPI, MI, BKC, GLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_kernel<EPI, MI, BKC, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
     const int ntile = EPI == UMOE_EPI_SWIGLU ? 64 : 128;
     dim3 grid((unsigned)ceil_div(max_n, ntile), (unsigned)ceil_div(a->max_rows, 32 * MI), (unsigned)a->num_groups);
-    tgemm_kernel<EPI, MI, BKC, GLDS><<<grid, 256, lds, s>>>(*a, gp);
+    tgemm_kernel<EPI, MI, BKC, NST><<<grid, 256, lds, s>>>(*a, gp);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -308,18 +325,38 @@ static int tgemm_tm(const umoe_tgemm_args* a) {
         forced = v ? atoi(v) : 0;
     }
     if (forced == 128 || forced == 256) return forced;
-    return a->max_rows >= 1024 ? 256 : 128;
+    static int minwg = -1;
+    if (minwg < 0) {
+        const char* v = getenv("UMOE_TGEMM_MINWG");
+        minwg = v ? atoi(v) : 512;
+    }
+    if (a->max_rows < 1024) return 128;
+    int max_n = 0;
+    for (int i = 0; i < a->num_groups; ++i) max_n = a->groups[i].n > max_n ? a->groups[i].n : max_n;
+    const long wgs = (long)ceil_div(a->max_rows, 256) * ceil_div(max_n, a->epilogue == UMOE_EPI_SWIGLU ? 64 : 128) * a->num_groups;
+    return wgs >= minwg ? 256 : 128;     // big tiles only when they still fill the chip (2 workgroups per CU)
 }
 
 template <int EPI>
 static int launch_tgemm(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
+    // staging variant (UMOE_TGEMM_GLDS, experiments): default = LDS-DMA; 256-token tiles with three LDS stages (the DMA of
+    // tile t+2 in flight across the barrier), 128-token tiles with two.  Measured at 4800-6240 rows (scripts/kbench.py tiled):
+    // register staging 580-650 TFLOP/s, LDS-DMA two stages 640-744, 256-token tiles + three stages 650-804; 128-token tiles
+    // with three 32 KiB stages (one workgroup per CU) 380-500; 128-token tiles, K steps of 32, three stages 525-670.
     static int glds = -1;
     if (glds < 0) {
         const char* v = getenv("UMOE_TGEMM_GLDS");
         glds = v ? atoi(v) : 1;
     }
-    if (tgemm_tm(a) == 256) return glds ? launch_tgemm_v<EPI, 8, 4, true>(a, max_n, s) : launch_tgemm_v<EPI, 8, 4, false>(a, max_n, s);
-    return glds ? launch_tgemm_v<EPI, 4, 8, true>(a, max_n, s) : launch_tgemm_v<EPI, 4, 8, false>(a, max_n, s);
+    if (glds == 43) return launch_tgemm_v<EPI, 4, 4, 3>(a, max_n, s);
+    if (tgemm_tm(a) == 256) {
+        if (glds == 0) return launch_tgemm_v<EPI, 8, 4, 0>(a, max_n, s);
+        if (glds == 2) return launch_tgemm_v<EPI, 8, 4, 2>(a, max_n, s);
+        return launch_tgemm_v<EPI, 8, 4, 3>(a, max_n, s);
+    }
+    if (glds == 0) return launch_tgemm_v<EPI, 4, 8, 0>(a, max_n, s);
+    if (glds == 3) return launch_tgemm_v<EPI, 4, 8, 3>(a, max_n, s);
+    return launch_tgemm_v<EPI, 4, 8, 2>(a, max_n, s);
 }
 
 extern "C" int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream) {
