@@ -188,6 +188,7 @@ def lib():
         L.umoe_rmsnorm_residual_fwd.argtypes = [vp, vp, vp, f32, i32, i32, vp, vp, vp]
         L.umoe_qkv_mrope_kvappend.argtypes = [C.POINTER(RopeArgs), vp]
         L.umoe_attn_decode.argtypes = [C.POINTER(AttnArgs), vp]
+        L.umoe_attn_prefill_fwd.argtypes = [C.POINTER(AttnArgs), vp]
         L.umoe_codec_embed_sum.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
         L.umoe_codec_head_cfg_sample.argtypes = [C.POINTER(SampleArgs), vp]
         L.umoe_delay_step.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]

@@ -14,6 +14,7 @@
 // Partials (m, l, O) per split are merged by attn_combine_kernel (flash-decoding).
 // Roofline: HBM (KV bytes = 2 * L * KVH * hd * 2 B per row per layer).
 #include "umoe_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ rope + append
 __global__ __launch_bounds__(256) void rope_append_kernel(const umoe_rope_args a) {
@@ -458,7 +459,214 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
 }
 
 // causal prefill over the cache (nq = T query tokens per row): same kernel family, key slices of one split by default
+
+
+// ------------------------------------------------------------------------------------ prefill / training attention (MFMA)
+// Causal GQA attention with many queries per row (nq >= 16): flash-attention forward on the matrix cores.
+//   grid = (16-query tiles, kv heads, rows); one wave per query head of the GQA group (G <= 8 waves), all waves share the
+//   K / V tiles of their kv head in LDS (64 keys per step, double buffered, 256-byte rows with the 16-byte chunks XOR-swizzled
+//   by row & 15: the ds_read_b128 K operand reads are conflict-free).
+//   S^T[key][query] = K_tile (A operand) x Q (B operand, registers) -> online softmax per query (fp32; row max / sum across
+//   the four 16-lane groups by two shuffles) -> P^T stays in registers AS the B operand of the second product (a lane holds
+//   4 consecutive keys of each 16-key tile = one 8-key slice of a 32-key MFMA step) -> O^T[d][query] += V^T x P^T with the
+//   V^T operand read straight out of the row-major V tile by ds_read_b64_tr_b16 (hardware transpose; probe:
+//   scripts/probe/tr_read_probe.hip).  Reference arithmetic: eager attention of the transformers dependency (fp32 softmax,
+//   probabilities cast to bf16 before P V), as oracle/decode.py restates it.
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int kv_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+
+template <int GP>
+__global__ __launch_bounds__(64 * GP) void attn_prefill_kernel(const umoe_attn_args a) {
+    constexpr int HD = 128, KT = 64;                       // keys per step
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K 16 KiB | V 16 KiB]
+    const int t0 = blockIdx.x * 16, kvh = blockIdx.y, row = blockIdx.z;
+    const int G = a.H / a.KVH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 4, c16 = lane & 15;
+    const int head = kvh * G + wave;
+    const bool live_wave = wave < G;
+    const int kv0 = a.kv_start[row];
+    const int qp0 = a.q_pos0[row] + t0;                    // absolute position of this tile's first query
+    const int kmax = min(qp0 + 15, a.q_pos0[row] + a.nq - 1);   // last key any query of the tile may see
+    const uint16_t* Kc = a.k_cache + ((size_t)row * a.KVH + kvh) * a.Lmax * HD;
+    const uint16_t* Vc = a.v_cache + ((size_t)row * a.KVH + kvh) * a.Lmax * HD;
+
+    // Q fragments: lane (h, q = c16) holds q[t0 + q][kb*32 + h*8 .. +8]
+    bf16x8_t qf[4];
+    {
+        const int t = min(t0 + c16, a.nq - 1);
+        const uint16_t* qp = a.q + (((size_t)row * a.nq + t) * a.H + (live_wave ? head : 0)) * HD + h * 8;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) qf[kb] = __builtin_bit_cast(bf16x8_t, ld16(qp + kb * 32));
+    }
+    const int my_qpos = qp0 + c16;                          // this lane's query position (column of S^T)
+    const bool q_ok = t0 + c16 < a.nq;
+
+    f32x4_t acc_o[8];
+#pragma unroll
+    for (int db = 0; db < 8; ++db) acc_o[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // K / V tile staging through registers: 2 tiles x 64 rows x 16 chunks = 2048 chunks over 64*GP threads
+    constexpr int NTH = 64 * GP, NLD = 2048 / NTH;
+    uint4 stg[NLD];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int idx = tid + n * NTH;
+            const int r = (idx >> 4) & 63, c = idx & 15;
+            const int key = k0 + r;
+            const uint16_t* base = (idx >> 10) ? Vc : Kc;
+            stg[n] = make_uint4(0, 0, 0, 0);
+            if (key <= kmax) stg[n] = ld16(base + (size_t)key * HD + c * 8);   // kmax < Lmax
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int idx = tid + n * NTH;
+            const int r = (idx >> 4) & 63, c = idx & 15;
+            st16(smem + buf * 32768 + (idx >> 10) * 16384 + kv_off(r, c), stg[n]);
+        }
+    };
+
+    const int kfirst = kv0 & ~(KT - 1);
+    if (kfirst <= kmax) {
+        gload(kfirst);
+        lstore(0);
+    }
+    __syncthreads();
+    int it = 0;
+    for (int k0 = kfirst; k0 <= kmax; k0 += KT, ++it) {
+        const int buf = it & 1;
+        const bool more = k0 + KT <= kmax;
+        if (more) gload(k0 + KT);
+        const char* Kt = smem + buf * 32768;
+        const char* Vt = Kt + 16384;
+        if (live_wave) {
+            // ---- S^T = K Q^T for the four 16-key tiles ----
+            f32x4_t sacc[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                sacc[kt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Kt + kv_off(kt * 16 + c16, kb * 4 + h)));
+                    sacc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kb], sacc[kt], 0, 0, 0);
+                }
+            }
+            // ---- online softmax over the 64 keys of this step (lane: query c16, keys kt*16 + 4h + r) ----
+            float sv[4][4];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + 4 * h + r;
+                    const bool ok = q_ok && key >= kv0 && key <= my_qpos;
+                    sv[kt][r] = ok ? sacc[kt][r] * a.scale : -INFINITY;
+                    tmax = fmaxf(tmax, sv[kt][r]);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+            float psum = 0.f;
+            bf16x8_t pf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint16_t pb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float s = sv[2 * ks + (j >> 2)][j & 3];
+                    const float pv = (s == -INFINITY) ? 0.f : __expf(s - m_new);
+                    psum += pv;
+                    pb[j] = f2bf(pv);
+                }
+                uint4 u;
+                u.x = (uint32_t)pb[0] | ((uint32_t)pb[1] << 16); u.y = (uint32_t)pb[2] | ((uint32_t)pb[3] << 16);
+                u.z = (uint32_t)pb[4] | ((uint32_t)pb[5] << 16); u.w = (uint32_t)pb[6] | ((uint32_t)pb[7] << 16);
+                pf[ks] = __builtin_bit_cast(bf16x8_t, u);
+            }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            // ---- O^T = O^T * alpha + V^T P^T ----
+            const int tq = c16 >> 2, tp = c16 & 3;   // transposing read: this lane supplies row tq, columns 4 tp .. 4 tp + 3 of its group's block
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                acc_o[db][0] *= alpha; acc_o[db][1] *= alpha; acc_o[db][2] *= alpha; acc_o[db][3] *= alpha;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int rA = (2 * ks) * 16 + 4 * h + tq, rB = rA + 16;
+                    const int cch = db * 2 + (tp >> 1), sub = (tp & 1) * 8;
+                    const v4s_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) v4s_t*)(Vt + kv_off(rA, cch) + sub));
+                    const v4s_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) v4s_t*)(Vt + kv_off(rB, cch) + sub));
+                    typedef short v8s_t __attribute__((ext_vector_type(8)));
+                    const v8s_t v8 = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+                    acc_o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, v8), pf[ks], acc_o[db], 0, 0, 0);
+                }
+            }
+        }
+        if (more) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- output: lane (h, q): d = db*16 + 4h + r of query t0 + q ----
+    if (live_wave && q_ok) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        uint16_t* o = a.out + (((size_t)row * a.nq + t0 + c16) * a.H + head) * HD + 4 * h;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            const uint32_t lo = (uint32_t)f2bf(acc_o[db][0] * inv) | ((uint32_t)f2bf(acc_o[db][1] * inv) << 16);
+            const uint32_t hi = (uint32_t)f2bf(acc_o[db][2] * inv) | ((uint32_t)f2bf(acc_o[db][3] * inv) << 16);
+            *reinterpret_cast<uint2*>(o + db * 16) = make_uint2(lo, hi);
+        }
+    }
+}
+
+static int prefill_mfma_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("UMOE_ATTN_PREFILL_MFMA");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+template <int GP>
+static int launch_attn_prefill(const umoe_attn_args* a, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_prefill_kernel<GP>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        configured = true;
+    }
+    dim3 grid((unsigned)ceil_div(a->nq, 16), (unsigned)a->KVH, (unsigned)a->rows);
+    attn_prefill_kernel<GP><<<grid, 64 * GP, 65536, s>>>(*a);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+// returns 1 when the shape is not handled here (caller falls back to the split-key kernel)
+static int attn_prefill_mfma(const umoe_attn_args* a, hipStream_t s) {
+    const int G = a->KVH > 0 ? a->H / a->KVH : 0;
+    if (!prefill_mfma_enabled() || a->nq < 16 || a->hd != 128 || G < 1 || G > 8 || a->qkv_raw || ceil_div(a->nq, 16) > 65535 || a->rows > 65535)
+        return 1;
+    if (G <= 1) return launch_attn_prefill<1>(a, s);
+    if (G <= 2) return launch_attn_prefill<2>(a, s);
+    if (G <= 4) return launch_attn_prefill<4>(a, s);
+    return launch_attn_prefill<8>(a, s);
+}
+
+// causal prefill over the cache (nq = T query tokens per row): MFMA flash kernel for >= 16 queries per row, else the
+// split-key kernel family of the decode path
 extern "C" int umoe_attn_prefill_fwd(const umoe_attn_args* a, umoe_stream_t stream) {
     UMOE_REQUIRE(a && !a->qkv_raw, "umoe_attn_prefill_fwd: rope fusion is decode-only; run umoe_qkv_mrope_kvappend first");
+    UMOE_REQUIRE(a->q && a->k_cache && a->v_cache && a->kv_start && a->q_pos0 && a->out, "umoe_attn_prefill_fwd: null argument");
+    const int rc = attn_prefill_mfma(a, (hipStream_t)stream);
+    if (rc <= 0) return rc;
     return umoe_attn_decode(a, stream);
 }

@@ -369,7 +369,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         t.qkv_raw = e->qkv; t.cos_tab = e->cos_tab; t.sin_tab = e->sin_tab; t.pos3 = e->pos3;
         t.sec0 = c.mrope0; t.sec1 = c.mrope1; t.sec2 = c.mrope2;
     }
-    if ((rc = umoe_attn_decode(&t, s))) return rc;
+    if ((rc = (T > 1 ? umoe_attn_prefill_fwd(&t, s) : umoe_attn_decode(&t, s)))) return rc;   // prefill: MFMA flash kernel
     PROF(K_ATTN);
     // 4. o_proj + residual                                        model.py:238
     umoe_gemm_args o{};

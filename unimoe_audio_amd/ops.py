@@ -278,7 +278,10 @@ def attention(q, k_cache, v_cache, kv_start, q_pos0, nq, H, splits=1, qkv_raw=No
                    nq=nq, H=H, KVH=KVH, hd=hd, Lmax=Lmax, splits=splits, scale=float(hd) ** -0.5, part_o=_p(po),
                    part_ml=_p(pm), out=_p(out), qkv_raw=_p(qkv_raw), cos_tab=_p(cos_tab), sin_tab=_p(sin_tab), pos3=_p(pos3),
                    sec0=sections[0], sec1=sections[1], sec2=sections[2])
-    L.check(L.lib().umoe_attn_decode(C.byref(a), _stream()), "umoe_attn_decode")
+    if nq >= 16 and qkv_raw is None:       # many queries per row: MFMA flash-attention kernel (umoe_attn_prefill_fwd)
+        L.check(L.lib().umoe_attn_prefill_fwd(C.byref(a), _stream()), "umoe_attn_prefill_fwd")
+    else:
+        L.check(L.lib().umoe_attn_decode(C.byref(a), _stream()), "umoe_attn_decode")
     return out
 
 
