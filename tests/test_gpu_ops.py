@@ -709,3 +709,29 @@ def test_dense_gateup_flat_slices_equal_per_group_grid(dev, fw):
     ops.grouped_gemm(tab, x, b, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=14, flat_wgs=fw)
     assert torch.equal(a, b)
     assert float(a[:8 * S].float().abs().sum()) > 0 and float(a[8 * S:, :Is].float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("T,H,KVH,pads", [(333, 16, 2, (70, 0)), (64, 4, 4, (0, 5)), (17, 2, 1, (3, 0)), (1560, 16, 2, (0, 40))])
+def test_attention_prefill_mfma_vs_oracle(dev, T, H, KVH, pads):
+    """umoe_attn_prefill_fwd (flash-attention forward on the matrix cores, transposing LDS reads for V^T) against the fp32
+    softmax restatement of the reference's attention (oracle/decode.py arithmetic): causal, GQA, left padding, query
+    counts that are not multiples of the 16-query / 64-key tiles."""
+    from unimoe_audio_amd import ops
+    g = torch.Generator().manual_seed(T + H)
+    B, hd = len(pads), 128
+    q = (torch.randn(B * T, H * hd, generator=g) * 1.2).to(torch.bfloat16)
+    k = (torch.randn(B, KVH, T, hd, generator=g) * 1.2).to(torch.bfloat16)
+    v = torch.randn(B, KVH, T, hd, generator=g).to(torch.bfloat16)
+    first = torch.tensor(pads, dtype=torch.int32)
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), first.to(dev), torch.zeros(B, dtype=torch.int32, device=dev), T, H, splits=1).cpu()
+    gq = H // KVH
+    qf = q.float().view(B, T, H, hd).transpose(1, 2)
+    sc = torch.matmul(qf, k.float().repeat_interleave(gq, 1).transpose(2, 3)) * hd ** -0.5
+    pos = torch.arange(T)
+    allowed = (pos.view(1, 1, 1, T) <= pos.view(1, 1, T, 1)) & (pos.view(1, 1, 1, T) >= first.view(B, 1, 1, 1))
+    p = torch.nan_to_num(torch.softmax(sc.masked_fill(~allowed, float("-inf")), -1), nan=0.0)
+    ref = torch.matmul(p.to(torch.bfloat16).float(), v.float().repeat_interleave(gq, 1)).transpose(1, 2).reshape(B * T, H * hd)
+    valid = (pos.view(1, T) >= first.view(B, 1)).reshape(-1)
+    err = (out.float()[valid] - ref[valid]).norm() / ref[valid].norm()
+    assert float(err) < 2.5 * 2 ** -8, float(err)
+    assert float(out.float()[~valid].abs().sum()) == 0.0 or not bool((~valid).any())     # fully masked queries -> 0
