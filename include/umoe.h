@@ -373,6 +373,9 @@ typedef struct {
     uint16_t* dk_cache;
     uint16_t* dv_cache;
     void* ws; size_t ws_bytes;     /* umoe_attn_prefill_bwd_workspace_bytes() */
+    const uint16_t* out;           /* optional: the forward's output [rows*T][H*hd] and its log-sum-exp [rows*T][H] (fp32,        */
+    const float* lse;              /* umoe_attn_args.lse_out).  Both given (hd 128, <= 8 heads per kv head): fused flash-style     */
+                                   /* backward, no score matrices in memory; otherwise the unfused composite.                    */
 } umoe_attn_bwd_args;
 size_t umoe_attn_prefill_bwd_workspace_bytes(const umoe_attn_bwd_args* a);
 int umoe_attn_prefill_bwd(const umoe_attn_bwd_args* a, umoe_stream_t stream);
@@ -405,6 +408,8 @@ typedef struct {
     const uint16_t* sin_tab;
     const int32_t* pos3;      /* [3][rows] */
     int sec0, sec1, sec2;
+    float* lse_out;           /* optional (umoe_attn_prefill_fwd, MFMA path): log-sum-exp per (query, head) [rows*nq][H], +inf for
+                               * queries that see no key; kept for umoe_attn_prefill_bwd */
 } umoe_attn_args;
 int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream);
 /* causal prefill (nq = T queries per row) over keys already appended by umoe_qkv_mrope_kvappend */

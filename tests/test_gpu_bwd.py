@@ -154,20 +154,22 @@ def test_rmsnorm_bwd_vs_autograd(dev):
     assert rel(dx.cpu(), xr.grad) < 2 ** -7 and rel(dw.cpu(), wr.grad) < 2 ** -6
 
 
-def test_attention_backward_composite_vs_autograd(dev):
+@pytest.mark.parametrize("B,T,H,KVH", [(2, 45, 4, 2), (2, 333, 16, 2), (1, 1100, 8, 1), (2, 9, 4, 2)])
+def test_attention_backward_composite_vs_autograd(dev, B, T, H, KVH):
     """umoe_attn_prefill_bwd + umoe_qkv_mrope_bwd (through RopeAttentionFn) against autograd of the attention oracle
-    (oracle/decode.py: mRoPE, causal GQA softmax in fp32, left padding)."""
+    (oracle/decode.py: mRoPE, causal GQA softmax in fp32, left padding).  T >= 16: the fused flash-style kernels (dQ with the
+    query tile stationary, dK / dV with the key tile stationary); T < 16: the unfused composite on the tiled GEMM."""
     from unimoe_audio_amd import ops, train as TR
     from oracle import decode as OD
-    g = torch.Generator().manual_seed(6)
-    B, T, H, KVH, hd = 2, 45, 4, 2, 128
+    g = torch.Generator().manual_seed(6 + T)
+    hd = 128
     D = H * hd
     sections = [16, 24, 24]
     cfg = types.SimpleNamespace(num_attention_heads=H, num_key_value_heads=KVH, hidden_size=D, mrope_section=sections)
     qkv = (torch.randn(B * T, (H + 2 * KVH) * hd, generator=g) * 0.7).to(torch.bfloat16)
     G_ = torch.randn(B * T, D, generator=g).to(torch.bfloat16)
     am = torch.ones(B, T, dtype=torch.long)
-    am[0, :7] = 0
+    am[0, :min(7, T // 3)] = 0
     pos = (am.cumsum(-1) - 1).masked_fill(am == 0, 1)
     # oracle: identity projections so that x -> (q, k, v) are the given tensors
     x = qkv.clone().requires_grad_(True)

@@ -613,11 +613,13 @@ __global__ __launch_bounds__(64 * GP) void attn_prefill_kernel(const umoe_attn_a
             }
         }
         if (more) lstore(buf ^ 1);
+        asm volatile("" ::: "memory");   // keeps the transposing-read builtins above the barrier (see umoe_attn_bwd.hip)
         __syncthreads();
     }
     // ---- output: lane (h, q): d = db*16 + 4h + r of query t0 + q ----
     if (live_wave && q_ok) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        if (a.lse_out && h == 0) a.lse_out[((size_t)row * a.nq + t0 + c16) * a.H + head] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
         uint16_t* o = a.out + (((size_t)row * a.nq + t0 + c16) * a.H + head) * HD + 4 * h;
 #pragma unroll
         for (int db = 0; db < 8; ++db) {

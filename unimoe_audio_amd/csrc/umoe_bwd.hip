@@ -845,9 +845,15 @@ extern "C" size_t umoe_attn_prefill_bwd_workspace_bytes(const umoe_attn_bwd_args
 // per (row, kv head) group the scores of its G query heads are materialised (rows h*Tp + t), P is recomputed in fp32,
 // dP = dO V^T, dS = scale * P o (dP - rowsum(dP o P)), dQ = dS K, dK = sum_h dS_h^T Q_h, dV = sum_h P_h^T dO_h -- every
 // contraction on umoe_tiled_gemm ("unfused" first version).
+int umoe_attn_bwd_fused(const umoe_attn_bwd_args* a, umoe_stream_t stream);   // umoe_attn_bwd.hip
+
 extern "C" int umoe_attn_prefill_bwd(const umoe_attn_bwd_args* a, umoe_stream_t stream) {
     UMOE_REQUIRE(a && a->q && a->k_cache && a->v_cache && a->kv_start_host && a->d_out && a->dq && a->dk_cache && a->dv_cache && a->ws,
                  "umoe_attn_prefill_bwd: null argument");
+    {
+        const int rcf = umoe_attn_bwd_fused(a, stream);   // flash-style path when the forward's output and log-sum-exp are given
+        if (rcf <= 0) return rcf;
+    }
     UMOE_REQUIRE(a->KVH > 0 && a->H % a->KVH == 0 && a->H / a->KVH <= 12 && a->hd % 8 == 0 && a->T > 0 && a->T <= a->Lmax && a->rows > 0,
                  "umoe_attn_prefill_bwd: bad sizes (H=%d KVH=%d hd=%d T=%d Lmax=%d)", a->H, a->KVH, a->hd, a->T, a->Lmax);
     float* sc;

@@ -80,14 +80,18 @@ class RopeAttentionFn(torch.autograd.Function):
         vc = torch.empty_like(kc)
         q = ops.qkv_mrope_kvappend(qkv, cos, sin, pos3, kv_pos, T, H, KVH, hd, sections, kc, vc)
         q0 = torch.zeros(B, dtype=torch.int32, device=dev)
-        ao = ops.attention(q, kc, vc, first_valid, q0, T, H, splits=1)
-        ctx.save_for_backward(q, kc, vc, cos, sin, pos3, kv_pos)
+        # log-sum-exp per (query, head): kept for the fused backward (written by the MFMA kernel only: T >= 16, hd 128, G <= 8)
+        fused = T >= 16 and hd == 128 and H // KVH <= 8
+        lse = torch.empty((B * T, H), dtype=torch.float32, device=dev) if fused else None
+        ao = ops.attention(q, kc, vc, first_valid, q0, T, H, splits=1, lse_out=lse)
+        ctx.fused = fused
+        ctx.save_for_backward(q, kc, vc, cos, sin, pos3, kv_pos, *((ao, lse) if fused else ()))
         ctx.meta = (B, T, H, KVH, hd, tuple(sections), list(first_valid_host))
         return ao
 
     @staticmethod
     def backward(ctx, d_ao):
-        q, kc, vc, cos, sin, pos3, kv_pos = ctx.saved_tensors
+        q, kc, vc, cos, sin, pos3, kv_pos, *extra = ctx.saved_tensors
         B, T, H, KVH, hd, sections, fv = ctx.meta
         dev, bf = q.device, torch.bfloat16
         d_ao = d_ao.to(bf).contiguous()
@@ -100,6 +104,8 @@ class RopeAttentionFn(torch.autograd.Function):
         a = L.AttnBwdArgs(q=q.data_ptr(), k_cache=kc.data_ptr(), v_cache=vc.data_ptr(), kv_start_host=C.cast(kv_host, C.c_void_p),
                           d_out=d_ao.data_ptr(), rows=B, T=T, H=H, KVH=KVH, hd=hd, Lmax=T, scale=scale, dq=dq.data_ptr(),
                           dk_cache=dk.data_ptr(), dv_cache=dv.data_ptr())
+        if ctx.fused:                                   # flash-style backward: needs the forward's output and log-sum-exp
+            a.out, a.lse = extra[0].data_ptr(), extra[1].data_ptr()
         nbytes = lib.umoe_attn_prefill_bwd_workspace_bytes(C.byref(a))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         a.ws, a.ws_bytes = ws.data_ptr(), nbytes
