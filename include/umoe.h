@@ -3,7 +3,7 @@
  * UniMoE-Audio hot path: DCMoE transformer forward + DAC-token decode loop.
  *
  * The reference (foggy-frost-forest/UniMoE-Audio) is 100% Python and has no FFI; this ABI
- * is what the repo's Python host modules (unimoe_audio_amd/*.py, which mirror the reference
+ * is what the repo's Python host modules (the .py files of unimoe_audio_amd, which mirror the reference
  * module API) bind with ctypes.  Each entry point cites the reference code it replaces
  * (paths relative to the reference root).  See INTEGRATION.md for the reference-side stub.
  *
