@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="sequences per GPU (CFG doubles the rows)")
     ap.add_argument("--prompt", type=int, default=300)
     ap.add_argument("--layers", type=int, default=0, help="debug only: override num_hidden_layers (0 = 36)")
+    ap.add_argument("--codec-channels", type=int, default=0,
+                    help="0 = the reference's 12 channels (16 kHz DAC, 50 frames/s); 9 = the 44.1 kHz reading of BASELINE (SURVEY 8d: delay [0,8..15], 86.1 frames/s)")
     ap.add_argument("--parallel", default="auto", choices=["auto", "ep", "replica"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -64,6 +66,9 @@ def gpu_run(args, rank, world, device):
     cfg = UniMoEAudioConfig()
     if args.layers:
         cfg.num_hidden_layers = args.layers
+    if args.codec_channels:
+        cfg.codec_channels = args.codec_channels
+        cfg.codec_delay_pattern = [0] + list(range(8, 8 + args.codec_channels - 1))
     B, T, K, W = args.batch, args.prompt, args.steps, args.warmup
     t0 = time.time()
     torch.set_default_dtype(torch.bfloat16)
@@ -147,6 +152,9 @@ def cpu_baseline(args):
     cfg = UniMoEAudioConfig()
     if args.layers:
         cfg.num_hidden_layers = args.layers
+    if args.codec_channels:
+        cfg.codec_channels = args.codec_channels
+        cfg.codec_delay_pattern = [0] + list(range(8, 8 + args.codec_channels - 1))
     torch.manual_seed(0)
     bf = torch.bfloat16
     D, H, KV, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
