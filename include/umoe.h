@@ -410,6 +410,9 @@ typedef struct {
     int sec0, sec1, sec2;
     float* lse_out;           /* optional (umoe_attn_prefill_fwd, MFMA path): log-sum-exp per (query, head) [rows*nq][H], +inf for
                                * queries that see no key; kept for umoe_attn_prefill_bwd */
+    int32_t* sync;            /* optional (umoe_attn_decode): [rows*nq][KVH] counters, ZERO before the first call.  When set, the
+                               * last key split of a (query, kv head) to finish merges the partials itself and the combine
+                               * launch disappears; the counters are zero again when the call completes */
 } umoe_attn_args;
 int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream);
 /* causal prefill (nq = T queries per row) over keys already appended by umoe_qkv_mrope_kvappend */

@@ -225,6 +225,17 @@ if "flat" in which:
         t = timeit(lambda i: ops.grouped_gemm(sets[i % R][1], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=nt, waves=wv))
         print("dense down nt", nt, "waves", wv, f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
 
+    # NT 5 gives 260 workgroups (4 more than CUs): does the ORDER of the groups decide which CUs carry two?
+    for name, order in (("shared last", list(range(10))), ("shared first+last", [8] + list(range(8)) + [9]), ("shared first", [8, 9] + list(range(8)))):
+        tabs = []
+        for r in range(R):
+            dn_r = [g.clone() for g in dn]
+            g2 = [dict(w=dn_r[e], static_count=S, a_row_base=e * S, out_row_base=e * S, n_blocks=D // 16, k=(Id if e < 8 else Is)) for e in order]
+            tabs.append(ops.GroupTable(g2, dev))
+        for nt in (5, 6):
+            t = timeit(lambda i: ops.grouped_gemm(tabs[i % R], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=nt, waves=8))
+            print("dense down order", name, "nt", nt, f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
+
 if "router" in which:
     gw = rnd(11, D)
     nw = torch.ones(D, device=dev, dtype=torch.bfloat16)

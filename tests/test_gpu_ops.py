@@ -486,6 +486,27 @@ def test_rope_attention_prefill_and_decode(dev):
         assert float(dk.norm() / kref.float()[sel].norm()) < 2 ** -7 and float(dk.abs().max()) < 0.07
 
 
+@pytest.mark.parametrize("rows,H,KVH,L,splits", [(16, 16, 2, 550, 8), (3, 16, 2, 37, 4), (5, 8, 8, 130, 8), (2, 4, 1, 300, 3),
+                                                 (16, 16, 2, 1, 8)])
+def test_attention_decode_single_launch_merge(dev, rows, H, KVH, L, splits):
+    """umoe_attn_args.sync: the last key split to finish merges the partials in the same launch -- bit-identical to the
+    attention + combine pair (same arithmetic, same order), also on repeated calls over the same counters."""
+    from unimoe_audio_amd import ops
+    hd, Lmax = 128, ((L + 80) // 64) * 64
+    g = torch.Generator().manual_seed(5 + rows + L)
+    kc = (torch.randn(rows, KVH, Lmax, hd, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    vc = (torch.randn(rows, KVH, Lmax, hd, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    q = torch.randn(rows, H * hd, generator=g).to(torch.bfloat16).to(dev)
+    kv_start = torch.randint(0, max(L // 3, 1), (rows,), generator=g).to(torch.int32).to(dev)
+    q0 = torch.full((rows,), L - 1, dtype=torch.int32, device=dev)
+    ref = ops.attention(q, kc, vc, kv_start, q0, 1, H, splits=splits)
+    sync = torch.zeros((rows, KVH), dtype=torch.int32, device=dev)
+    for _ in range(3):
+        got = ops.attention(q, kc, vc, kv_start, q0, 1, H, splits=splits, single_launch=sync)
+        assert torch.equal(got, ref)
+        assert int(sync.abs().sum()) == 0          # the counters are zero again after every call
+
+
 # ----------------------------------------------------------------------------- codec side
 def test_codec_embed_sum(dev):
     from unimoe_audio_amd import ops

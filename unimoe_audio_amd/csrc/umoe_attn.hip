@@ -124,6 +124,64 @@ __device__ __forceinline__ void rope32(const uint16_t* head_raw, int h4, const u
     }
 }
 
+// Merge of the key splits of one (query, kv head) by the LAST split workgroup to finish (a.sync): 256 threads, thread ->
+// (head of the group = tid >> 5, 4 value columns); every partial is requested before the first use (they were written by
+// other XCDs: each dependent load would be a trip to the Infinity Cache).  Same arithmetic and order as attn_combine_kernel.
+__device__ __forceinline__ float cld(const float* p) {   // agent-coherent load (sc1): never served from this XCD's stale L2 line
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int SP>
+__device__ __forceinline__ void merge_splits_tail(const umoe_attn_args& a, const int qi, const int kvh, const int G, const int tid) {
+    constexpr int HD = 128;
+    const int splits = SP > 0 ? SP : a.splits;
+    const int d4 = (tid & 31) * 4;
+    for (int g = tid >> 5; g < G; g += 8) {
+        const int head = kvh * G + g;
+        const float* pm = a.part_ml + ((size_t)qi * a.H + head) * splits * 2;
+        const float* po = a.part_o + ((size_t)qi * a.H + head) * splits * HD + d4;
+        float L = 0.f;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (SP > 0) {
+            float2 ml[SP > 0 ? SP : 1];
+            float4 ov[SP > 0 ? SP : 1];
+#pragma unroll
+            for (int s = 0; s < SP; ++s) {
+                ml[s].x = cld(pm + 2 * s);
+                ml[s].y = cld(pm + 2 * s + 1);
+                const float* pp = po + (size_t)s * HD;
+                ov[s] = make_float4(cld(pp), cld(pp + 1), cld(pp + 2), cld(pp + 3));
+            }
+            float mm = -INFINITY;
+#pragma unroll
+            for (int s = 0; s < SP; ++s) mm = fmaxf(mm, ml[s].x);
+#pragma unroll
+            for (int s = 0; s < SP; ++s) {
+                const float sc = (ml[s].x == -INFINITY) ? 0.f : __expf(ml[s].x - mm);
+                L += sc * ml[s].y;
+                acc[0] += sc * ov[s].x; acc[1] += sc * ov[s].y; acc[2] += sc * ov[s].z; acc[3] += sc * ov[s].w;
+            }
+        } else {
+            float mm = -INFINITY;
+            for (int s = 0; s < splits; ++s) mm = fmaxf(mm, cld(pm + 2 * s));
+            for (int s = 0; s < splits; ++s) {
+                const float ms = cld(pm + 2 * s);
+                const float sc = (ms == -INFINITY) ? 0.f : __expf(ms - mm);
+                L += sc * cld(pm + 2 * s + 1);
+                const float* pp = po + (size_t)s * HD;
+                const float4 ov = make_float4(cld(pp), cld(pp + 1), cld(pp + 2), cld(pp + 3));
+                acc[0] += sc * ov.x; acc[1] += sc * ov.y; acc[2] += sc * ov.z; acc[3] += sc * ov.w;
+            }
+        }
+        uint16_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = f2bf(L > 0.f ? acc[j] / L : 0.f);
+        uint2 pk;
+        pk.x = (uint32_t)r[0] | ((uint32_t)r[1] << 16);
+        pk.y = (uint32_t)r[2] | ((uint32_t)r[3] << 16);
+        *reinterpret_cast<uint2*>(a.out + ((size_t)qi * a.H + head) * HD + d4) = pk;
+    }
+}
+
 // hd == 128 only (4 MFMA k-steps; lane owns 2 value columns).  GP = GQA group size padded to a power of two.
 // With a.qkv_raw set (decode, nq == 1) the kernel also applies mRoPE and appends the new K/V to the cache.
 template <int GP>
@@ -342,12 +400,44 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
         }
         const int head = kvh * G + g;
         float* po = a.part_o + (((size_t)qi * a.H + head) * a.splits + split) * HD + cg * 8;
+        float* pm = a.part_ml + (((size_t)qi * a.H + head) * a.splits + split) * 2;
+        if (a.sync) {   // agent-coherent (write-through, sc1) stores: read by a workgroup on another XCD in this same launch
 #pragma unroll
-        for (int j = 0; j < 8; ++j) po[j] = acc[j];
-        if (cg == 0) {
-            float* pm = a.part_ml + (((size_t)qi * a.H + head) * a.splits + split) * 2;
-            pm[0] = mm;
-            pm[1] = L;
+            for (int j = 0; j < 8; ++j) __hip_atomic_store(po + j, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cg == 0) {
+                __hip_atomic_store(pm, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pm + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) po[j] = acc[j];
+            if (cg == 0) {
+                pm[0] = mm;
+                pm[1] = L;
+            }
+        }
+    }
+    if (a.sync) {
+        // one launch instead of two: every split writes its partials through to the coherence point and takes a ticket; the
+        // workgroup that draws the last ticket of its (query, kv head) merges.  One writer per output element and a fixed
+        // summation order (split 0..SP-1), whichever workgroup happens to be last -> results do not depend on the schedule.
+        // No agent-scope fence: `buffer_wbl2` / `buffer_inv` per wave walk the whole L2 (measured: +37 us per layer); the
+        // partials travel as relaxed agent-scope atomics (sc1 stores / loads) instead, and __syncthreads() (a workgroup
+        // release: vscnt(0)) orders them before the ticket.
+        __shared__ int last_flag;
+        __syncthreads();
+        if (tid == 0) {
+            int* ctr = a.sync + (size_t)qi * a.KVH + kvh;
+            const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == a.splits - 1;
+            if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            last_flag = last;
+        }
+        __syncthreads();
+        if (last_flag) {
+            if (a.splits == 8) merge_splits_tail<8>(a, qi, kvh, G, tid);
+            else if (a.splits == 4) merge_splits_tail<4>(a, qi, kvh, G, tid);
+            else merge_splits_tail<0>(a, qi, kvh, G, tid);
         }
     }
     TL_EXIT(7);
@@ -433,9 +523,12 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     if (nqi <= 65535u) {
         launch_attn(a, dim3((unsigned)a->splits, (unsigned)a->KVH, nqi), s);
         UMOE_LAUNCH_CHECK();
-        launch_attn_combine(a, dim3((unsigned)a->H, nqi), s);
-        UMOE_LAUNCH_CHECK();
+        if (!a->sync) {
+            launch_attn_combine(a, dim3((unsigned)a->H, nqi), s);
+            UMOE_LAUNCH_CHECK();
+        }
     } else {
+        UMOE_REQUIRE(!a->sync, "umoe_attn_decode: the single-launch merge (sync) covers <= 65535 query tokens");
         // process row by row (prefill with very long prompts)
         for (int r = 0; r < a->rows; ++r) {
             umoe_attn_args b = *a;

@@ -58,7 +58,7 @@ struct umoe_engine {
              *hbuf = nullptr, *ybuf = nullptr;
     float *part_o = nullptr, *part_ml = nullptr, *logits = nullptr, *ypart = nullptr;
     int32_t *pos3 = nullptr, *kv_pos = nullptr, *q_pos0 = nullptr, *kv_start = nullptr, *tok_in = nullptr,
-            *valid_count = nullptr, *eng_state = nullptr;
+            *valid_count = nullptr, *eng_state = nullptr, *attn_sync = nullptr;
     void* r_logits = nullptr;
     int64_t *r_topk = nullptr, *pred = nullptr;
     int32_t *r_sel = nullptr, *r_mask = nullptr, *counts = nullptr, *offsets = nullptr, *slot_token = nullptr,
@@ -76,6 +76,8 @@ struct umoe_engine {
     // decode with >= 6 rows: every routed expert is hit with probability ~1, so each expert computes ALL rows (no gather
     // lists, no dispatch kernel, no device-produced row counts in the GEMM prologues) and the combine selects by mask
     bool dense_experts = true;
+    bool attn_single = false;    // UMOE_ATTN_SINGLE: decode attention merges its key splits in the same launch (umoe_attn_args.sync);
+                                 // measured 3.644 vs 3.585 ms/step: ticket + coherent re-read cost more than the combine launch
     int flat_wgs = 0;            // UMOE_FLAT_WGS: workgroups of the flat gate/up launch; measured 42.4 us (256 slices of 6-7
                                  // pairs, the 7th slot of a 6-pair slice re-reads) vs 37.3 us for the per-group grid -> off
     bool tiled_prefill = true;   // UMOE_TILED_PREFILL=0: weight-streaming kernels for every row count (A/B, tests)
@@ -115,6 +117,7 @@ static size_t carve(umoe_engine* e, int n_tok, char* base) {
     e->kv_start = k.take<int32_t>(c.rows);
     e->valid_count = k.take<int32_t>(c.rows);
     e->eng_state = k.take<int32_t>(8);
+    e->attn_sync = k.take<int32_t>((size_t)n_tok * c.kv_heads);   // zero at allocation; the attention kernel leaves it zero
     e->tok_in = k.take<int32_t>((size_t)c.rows * c.codec_channels);
     e->r_logits = k.take<float>((size_t)n_tok * E);
     e->r_topk = k.take<int64_t>(n_tok);
@@ -240,6 +243,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (const char* v = getenv("UMOE_DENSE_EXPERTS")) e->dense_experts = atoi(v) != 0;
     if (const char* v = getenv("UMOE_TILED_PREFILL")) e->tiled_prefill = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FLAT_WGS")) e->flat_wgs = atoi(v);
+    if (const char* v = getenv("UMOE_ATTN_SINGLE")) e->attn_single = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -365,6 +369,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     t.q = e->q_r; t.k_cache = r.k_cache; t.v_cache = r.v_cache; t.kv_start = e->kv_start; t.q_pos0 = e->q_pos0;
     t.rows = c.rows; t.nq = T; t.H = c.heads; t.KVH = c.kv_heads; t.hd = c.head_dim; t.Lmax = c.Lmax; t.splits = splits;
     t.scale = 1.0f / sqrtf((float)c.head_dim); t.part_o = e->part_o; t.part_ml = e->part_ml; t.out = e->attn_out;
+    if (T == 1 && e->attn_single) t.sync = e->attn_sync;   // decode: the last key split merges, no combine launch
     if (fuse_rope) {
         t.qkv_raw = e->qkv; t.cos_tab = e->cos_tab; t.sin_tab = e->sin_tab; t.pos3 = e->pos3;
         t.sec0 = c.mrope0; t.sec1 = c.mrope1; t.sec2 = c.mrope2;

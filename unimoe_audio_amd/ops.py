@@ -266,18 +266,24 @@ def qkv_mrope_kvappend(qkv, cos_tab, sin_tab, pos3, kv_pos, T, H, KVH, hd, secti
 
 
 def attention(q, k_cache, v_cache, kv_start, q_pos0, nq, H, splits=1, qkv_raw=None, cos_tab=None, sin_tab=None, pos3=None,
-              sections=(16, 24, 24), lse_out=None):
-    """q: rotated queries [rows*nq, H*hd]; or pass qkv_raw (decode, nq == 1) to fuse mRoPE + KV append into the kernel."""
+              sections=(16, 24, 24), lse_out=None, single_launch=False):
+    """q: rotated queries [rows*nq, H*hd]; or pass qkv_raw (decode, nq == 1) to fuse mRoPE + KV append into the kernel.
+    single_launch: the last key split to finish merges the partials (umoe_attn_args.sync) -- no combine launch."""
     rows, KVH, Lmax, hd = k_cache.shape
     n = (q if q is not None else qkv_raw).shape[0]
     dev0 = (q if q is not None else qkv_raw).device
     po = torch.empty((n, H, splits, hd), dtype=torch.float32, device=dev0)
     pm = torch.empty((n, H, splits, 2), dtype=torch.float32, device=dev0)
     out = torch.empty((n, H * hd), dtype=torch.bfloat16, device=dev0)
+    sync = None
+    if isinstance(single_launch, torch.Tensor):      # caller-owned counters [n, KVH] int32, zero before the first call
+        sync = single_launch
+    elif single_launch:
+        sync = torch.zeros((n, KVH), dtype=torch.int32, device=dev0)
     a = L.AttnArgs(q=_p(q), k_cache=_p(k_cache), v_cache=_p(v_cache), kv_start=_p(kv_start), q_pos0=_p(q_pos0), rows=rows,
                    nq=nq, H=H, KVH=KVH, hd=hd, Lmax=Lmax, splits=splits, scale=float(hd) ** -0.5, part_o=_p(po),
                    part_ml=_p(pm), out=_p(out), qkv_raw=_p(qkv_raw), cos_tab=_p(cos_tab), sin_tab=_p(sin_tab), pos3=_p(pos3),
-                   sec0=sections[0], sec1=sections[1], sec2=sections[2], lse_out=_p(lse_out))
+                   sec0=sections[0], sec1=sections[1], sec2=sections[2], lse_out=_p(lse_out), sync=_p(sync))
     if nq >= 16 and qkv_raw is None:       # many queries per row: MFMA flash-attention kernel (umoe_attn_prefill_fwd)
         L.check(L.lib().umoe_attn_prefill_fwd(C.byref(a), _stream()), "umoe_attn_prefill_fwd")
     else:
