@@ -26,10 +26,92 @@ struct tg_pack { umoe_tgroup_t g[TG_MAXG]; };
 // 16-byte chunk c of tile row r, rows of BKC chunks.  An operand read takes ONE chunk column of 16 consecutive rows; rows
 // are BKC*16 B = BKC*4 banks, so 16/BKC consecutive rows span the 64 banks and the rows that share banks (every 16/BKC-th)
 // must land on different chunk slots -> swizzle by (r / (16/BKC)) % BKC: conflict-free (SQ_LDS_BANK_CONFLICT = 0).
+// BKC = 4 (64-byte rows, four rows per 256-byte bank line): ds_read_b128 serves a wave in four groups of 16 lanes that MIX two
+// chunk columns -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS) -- i.e. rows 0-3 and 12-15 with
+// chunk h next to rows 4-11 with chunk h + 1.  Rows r, r+4, r+8, r+12 share their four banks' quad, so the slots
+// {g(0), g(12), 1^g(4), 1^g(8)} and {g(4), g(8), 1^g(0), 1^g(12)} must each be distinct: g(r) = (-(r >> 2)) & 3 (0, 3, 2, 1).
+// (The obvious g = (r >> 2) & 3 is 2-way on every read: SQ_LDS_BANK_CONFLICT = 4 cycles per ds_read_b128, measured.)
+template <int BKC>
+__device__ __forceinline__ int tg_swz(int row) {
+    return BKC == 8 ? ((row >> 1) & 7) : ((0 - (row >> 2)) & 3);
+}
 template <int BKC>
 __device__ __forceinline__ int tg_off(int row, int chunk) {
-    constexpr int SH = BKC == 8 ? 1 : 2;
-    return row * (BKC * 16) + ((chunk ^ ((row >> SH) & (BKC - 1))) << 4);
+    return row * (BKC * 16) + ((chunk ^ tg_swz<BKC>(row)) << 4);
+}
+
+// Epilogue shared by the tile variants.  acc[j][i]: lane (h = lane >> 4, c16 = lane & 15) holds features fbase[j] + 4 h .. + 3 of
+// token row rbase + 16 i + c16 (SwiGLU: acc[j] = gate, acc[j + 2] = up of the same features, j < 2).
+template <int EPI, int MI>
+__device__ __forceinline__ void tg_epilogue(const umoe_tgemm_args& p, const umoe_tgroup_t& g, const f32x4_t (&acc)[4][MI], const int count,
+                                            const int roff, const int rbase, const int (&fbase)[4], const int lane) {
+    constexpr bool SW = EPI == UMOE_EPI_SWIGLU;
+    const int h = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int r = rbase + 16 * i + c16;
+        if (r >= count) continue;
+        const long orow = (long)g.out_row_base + roff + r;
+        const int oc = g.out_col_off;
+        if (SW) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = fbase[j] + 4 * h;
+                if (col >= g.n) continue;
+                uint16_t y[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float gt = rbf(acc[j][i][q]);
+                    const float up = rbf(acc[j + 2][i][q]);
+                    const float si = rbf(gt / (1.0f + expf(-gt)));
+                    y[q] = f2bf(si * up);
+                    if (p.aux_out && col + q < g.n) {
+                        p.aux_out[orow * p.ld_aux + col + q] = f2bf(gt);
+                        p.aux_out[orow * p.ld_aux + g.n + col + q] = f2bf(up);
+                    }
+                }
+                uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + oc + col;
+                if (col + 3 < g.n && ((p.ldo | oc) & 3) == 0) {
+                    *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (col + q < g.n) o[q] = y[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = fbase[j] + 4 * h;
+                if (col >= g.n) continue;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = acc[j][i][q] + ((g.bias && col + q < g.n) ? g.bias[col + q] : 0.f);
+                if (EPI == UMOE_EPI_F32 || EPI == UMOE_EPI_F32_RAW) {
+                    float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + oc + col;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (col + q < g.n) o[q] = (EPI == UMOE_EPI_F32) ? rbf(v[q]) : v[q];
+                } else {
+                    uint16_t y[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float x = rbf(v[q]);
+                        if (EPI == UMOE_EPI_BF16_RESID && col + q < g.n) x = bf2f(p.resid[orow * p.ldo + oc + col + q]) + x;
+                        y[q] = f2bf(x);
+                    }
+                    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + oc + col;
+                    if (col + 3 < g.n && ((p.ldo | oc) & 3) == 0) {
+                        *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (col + q < g.n) o[q] = y[q];
+                    }
+                }
+            }
+        }
+    }
 }
 
 // MI = 16-token sub-tiles per wave: 4 -> 128-token tiles, K steps of 64 (BKC 8), 64 x 64 wave tiles;
@@ -129,8 +211,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
 #pragma unroll
         for (int j = 0; j < AGW; ++j) {
             const int tr = (wave + 4 * j) * RPG + rl;     // tile row
-            constexpr int SH = BKC == 8 ? 1 : 2;
-            const int c = slot ^ ((tr >> SH) & (BKC - 1));
+            const int c = slot ^ tg_swz<BKC>(tr);
             gch = c;                                      // RPG * 4 is a multiple of the swizzle period: c does not depend on j
             const int r = row0 + tr;
             gap[j] = nullptr;
@@ -142,8 +223,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
 #pragma unroll
         for (int j = 0; j < WGW; ++j) {
             const int tr = (wave + 4 * j) * RPG + rl;
-            constexpr int SH = BKC == 8 ? 1 : 2;
-            const int c = slot ^ ((tr >> SH) & (BKC - 1));
+            const int c = slot ^ tg_swz<BKC>(tr);
             int n;
             const uint16_t* wb = g.w;
             if (SW) {
@@ -232,71 +312,206 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
     }
 
     // ---- epilogue: acc[j][i] lane (h, c16): token row 16 MI wm + 16 i + c16, features (weight rows) wrow[j] + 4 h .. +3 ----
+    int fbase[4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int r = row0 + 16 * MI * wm + 16 * i + c16;
-        if (r >= count) continue;
-        const long orow = (long)g.out_row_base + roff + r;
-        const int oc = g.out_col_off;
-        if (SW) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + 32 * wn + 16 * j + 4 * h;
-                if (col >= g.n) continue;
-                uint16_t y[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float gt = rbf(acc[j][i][q]);
-                    const float up = rbf(acc[j + 2][i][q]);
-                    const float si = rbf(gt / (1.0f + expf(-gt)));
-                    y[q] = f2bf(si * up);
-                    if (p.aux_out && col + q < g.n) {
-                        p.aux_out[orow * p.ld_aux + col + q] = f2bf(gt);
-                        p.aux_out[orow * p.ld_aux + g.n + col + q] = f2bf(up);
-                    }
-                }
-                uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + oc + col;
-                if (col + 3 < g.n && ((p.ldo | oc) & 3) == 0) {
-                    *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col + q < g.n) o[q] = y[q];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = n0 + wrow[j] + 4 * h;
-                if (col >= g.n) continue;
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = acc[j][i][q] + ((g.bias && col + q < g.n) ? g.bias[col + q] : 0.f);
-                if (EPI == UMOE_EPI_F32 || EPI == UMOE_EPI_F32_RAW) {
-                    float* o = reinterpret_cast<float*>(p.out) + orow * p.ldo + oc + col;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (col + q < g.n) o[q] = (EPI == UMOE_EPI_F32) ? rbf(v[q]) : v[q];
-                } else {
-                    uint16_t y[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float x = rbf(v[q]);
-                        if (EPI == UMOE_EPI_BF16_RESID && col + q < g.n) x = bf2f(p.resid[orow * p.ldo + oc + col + q]) + x;
-                        y[q] = f2bf(x);
-                    }
-                    uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + oc + col;
-                    if (col + 3 < g.n && ((p.ldo | oc) & 3) == 0) {
-                        *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (col + q < g.n) o[q] = y[q];
-                    }
-                }
-            }
-        }
+    for (int j = 0; j < 4; ++j) fbase[j] = n0 + (SW ? 32 * wn + 16 * (j & 1) : wrow[j]);
+    tg_epilogue<EPI, MI>(p, g, acc, count, roff, row0 + 16 * MI * wm, fbase, lane);
+}
+
+// ------------------------------------------------------------------------------------ 256 x 256 tiles, two wave groups in ping-pong
+// 512 threads = 8 waves as 2 (token halves, wr) x 4 (feature quarters, wc); a wave owns 128 tokens x 64 features = 4 x 8
+// accumulators (128 registers).  Each SIMD carries one wave of each group; the groups run ONE BARRIER APART, so while group 0
+// issues its 16 MFMAs group 1 reads its operands / issues the next LDS-DMA, and vice versa -- the matrix pipe of every SIMD
+// always has a wave in its MFMA segment (MI355X_MICROARCH.md, LDS section: one wave per SIMD cannot hide its own ds_reads).
+//   K runs in tiles of 32 (one MFMA k-step); LDS = ring of 4 tiles x [W unit 256 rows x 64 B | token unit 256 rows x 64 B] =
+//   128 KiB; a unit is staged by all 8 waves (2 global_load_lds_dwordx4 each) and the DMA runs THREE tiles ahead.
+//   phase 2v   : L: read W(v) (4 fragments) + tokens(v) first half (4); stage W(v+3)         | barrier | M: 16 MFMA | barrier
+//   phase 2v+1 : L: read tokens(v) second half (4); stage tokens(v+3); s_waitcnt vmcnt(8)    | barrier | M: 16 MFMA | barrier
+//   RAW: a wave's vmcnt(8) in phase 2v+1 retires ITS pieces of tile v+1 (the 8 newer DMAs are W/tokens of v+2, v+3); the reads
+//        of tile v+1 start in phase 2v+2, behind a barrier that both groups have passed after their waits.
+//   WAR: W(v+3) overwrites W(v-1), last read in phase 2v-2; tokens(v+3) overwrite tokens(v-1), last read in phase 2v-1: two
+//        phases earlier, i.e. also the lagging group has retired those reads (lgkmcnt) before any wave issues the DMA.
+//   Tiles beyond K are staged from the zero block, so the vmcnt arithmetic is the same in every iteration.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args p, const tg_pack gp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int UNIT = 256 * 64, SLOT = 2 * UNIT;
+    constexpr bool SW = EPI == UMOE_EPI_SWIGLU;
+    constexpr int NTILE = SW ? 128 : 256;
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id, so the workgroups that share an XCD
+    // (and its L2) take a CONTIGUOUS range of tiles -- column tiles of the same token rows next to each other -- instead
+    // of every 8th tile: an XCD then pulls ~1/8 of the token rows (and all of the weights) through its L2, not all of both.
+    // Bijective for any grid size (q + 1 tiles for the first nwg % 8 XCDs, q for the rest).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    {
+        const unsigned nx = gridDim.x, ny = gridDim.y, nwg = nx * ny * gridDim.z;
+        const unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
+        const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+        bx = (int)(id % nx);
+        by = (int)((id / nx) % ny);
+        bz = (int)(id / (nx * ny));
     }
+    const umoe_tgroup_t g = gp.g[bz];
+    const int count = g.count ? *g.count : g.static_count;
+    const int roff = g.row_off ? *g.row_off : 0;
+    const int row0 = by * 256;
+    if (row0 >= count) return;
+    const int n0 = bx * NTILE;
+    if (n0 >= g.n) return;
+    const int koff = g.k_off ? *g.k_off : 0;
+    const int K = g.k_count ? ((*g.k_count + 7) & ~7) : g.k;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- LDS-DMA sources: this wave stages row groups `wave` and `wave + 8` (16 rows each) of every unit ----
+    const int rl = lane >> 2, slot = lane & 3;
+    const int gch = slot ^ tg_swz<4>(rl);           // source chunk: the swizzle sits on the global address (row groups of 16: same for both)
+    // Source address = zero block + byte delta, delta = 0 for rows outside the tile: the choice between a tile chunk and the
+    // zero block is ARITHMETIC on an integer.  (A select between two pointers in front of the intrinsic is turned into two
+    // exec-masked DMA instructions by hipcc -- the number of VMEM operations per stage would then depend on the data and the
+    // counted vmcnt waits below would retire the wrong tile.)
+    const char* zero = reinterpret_cast<const char*>(&tg_zero16);
+    long tdel[2], wdel[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int tr = (wave + 8 * q) * 16 + rl;    // tile row 0..255
+        const int r = row0 + tr;
+        tdel[q] = 0;
+        if (r < count) {
+            const long arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
+            tdel[q] = reinterpret_cast<const char*>(p.a + arow * (long)p.lda + g.a_col_off + koff + gch * 8) - zero;
+        }
+        int n;
+        const uint16_t* wb = g.w;
+        if (SW) {
+            n = n0 + (tr & 127);
+            if (tr >= 128) wb = g.w2;
+        } else {
+            n = n0 + tr;
+        }
+        wdel[q] = n < g.n ? reinterpret_cast<const char*>(wb + (long)n * g.ldw + koff + gch * 8) - zero : 0;
+    }
+    auto stage = [&](const long (&del)[2], const int unit_off, const int tile) {
+        const int k0 = tile * 32;
+        const long live = (k0 + gch * 8 < K) ? -1L : 0L;      // K tail and the tiles staged past the end read zeros
+        char* base = smem + (tile & 3) * SLOT + unit_off;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const long d = del[q] == 0 ? 0 : ((del[q] + 2L * k0) & live);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(zero + d),
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * q) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int h = lane >> 4, c16 = lane & 15;
+    int wrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wrow[j] = SW ? ((j < 2 ? 0 : 128) + 32 * wc + 16 * (j & 1)) : (64 * wc + 16 * j);
+    // operand read offsets inside a unit (the swizzle term only depends on c16: rows step by 16)
+    int woff[4], toff[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = tg_off<4>(wrow[j] + c16, h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) toff[i] = UNIT + tg_off<4>(128 * wr + 16 * i + c16, h);
+
+    const int KT = (K + 31) >> 5;
+    // prologue: tiles 0..2 in flight, tile 0 landed and visible
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        stage(wdel, 0, u);
+        stage(tdel, UNIT, u);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind group 0 from here on
+#ifdef UMOE_PP_STAMPS
+    unsigned long long st[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) st[k] = 0;
+#define PP_ST(k) if (v == (KT >> 1)) st[k] = clock64()
+#else
+#define PP_ST(k)
+#endif
+    for (int v = 0; v < KT; ++v) {
+        const char* T = smem + (v & 3) * SLOT;
+        bf16x8_t wf[4], af[4];
+        // ---- phase 2v
+        PP_ST(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(T + woff[j]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(T + toff[i]));
+        stage(wdel, 0, v + 3);
+        PP_ST(1);
+        __builtin_amdgcn_s_barrier();
+        PP_ST(2);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_ST(3);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2v + 1
+        PP_ST(4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(T + toff[4 + i]));
+        stage(tdel, UNIT, v + 3);
+        PP_ST(5);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        PP_ST(6);
+        __builtin_amdgcn_s_barrier();
+        PP_ST(7);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_ST(8);
+        __builtin_amdgcn_s_barrier();
+        PP_ST(9);
+    }
+#ifdef UMOE_PP_STAMPS
+    if (p.aux_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.aux_out) + wave * 10;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) o[k] = st[k];
+    }
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-tile DMAs of the last iterations must not outlive the workgroup
+    if (wr == 0) __builtin_amdgcn_s_barrier();      // every wave has now executed the same number of barriers
+
+    int fbase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fbase[j] = n0 + (SW ? 32 * wc + 16 * (j & 1) : wrow[j]);
+    tg_epilogue<EPI, 8>(p, g, acc, count, roff, row0 + 128 * wr, fbase, lane);
+}
+
+template <int EPI>
+static int launch_tgemm_pp(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
+    tg_pack gp;
+    memset(&gp, 0, sizeof(gp));
+    memcpy(gp.g, a->groups, sizeof(umoe_tgroup_t) * a->num_groups);
+    constexpr int lds = 4 * 2 * 256 * 64;
+    static bool configured = false;
+    if (!configured) {
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    const int ntile = EPI == UMOE_EPI_SWIGLU ? 128 : 256;
+    dim3 grid((unsigned)ceil_div(max_n, ntile), (unsigned)ceil_div(a->max_rows, 256), (unsigned)a->num_groups);
+    tgemm_pp_kernel<EPI><<<grid, 512, lds, s>>>(*a, gp);
+    UMOE_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int EPI, int MI, int BKC, int NST>
@@ -337,6 +552,18 @@ static int tgemm_tm(const umoe_tgemm_args* a) {
     return wgs >= minwg ? 256 : 128;     // big tiles only when they still fill the chip (2 workgroups per CU)
 }
 
+// 256 x 256 ping-pong tiles once they fill the chip (one workgroup per CU)
+static bool tgemm_pp_pays(const umoe_tgemm_args* a, int max_n) {
+    static int minwg = -1;
+    if (minwg < 0) {
+        const char* v = getenv("UMOE_TGEMM_PP_MINWG");
+        minwg = v ? atoi(v) : 192;
+    }
+    if (a->max_rows < 1024) return false;
+    const long wgs = (long)ceil_div(a->max_rows, 256) * ceil_div(max_n, a->epilogue == UMOE_EPI_SWIGLU ? 128 : 256) * a->num_groups;
+    return wgs >= minwg;
+}
+
 template <int EPI>
 static int launch_tgemm(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
     // staging variant (UMOE_TGEMM_GLDS, experiments): default = LDS-DMA; 256-token tiles with three LDS stages (the DMA of
@@ -348,6 +575,12 @@ static int launch_tgemm(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
         const char* v = getenv("UMOE_TGEMM_GLDS");
         glds = v ? atoi(v) : 1;
     }
+    static int pp = -1;
+    if (pp < 0) {
+        const char* v = getenv("UMOE_TGEMM_PP");
+        pp = v ? atoi(v) : 2;
+    }
+    if (pp == 1 || (pp == 2 && tgemm_pp_pays(a, max_n))) return launch_tgemm_pp<EPI>(a, max_n, s);
     if (glds == 43) return launch_tgemm_v<EPI, 4, 4, 3>(a, max_n, s);
     if (tgemm_tm(a) == 256) {
         if (glds == 0) return launch_tgemm_v<EPI, 8, 4, 0>(a, max_n, s);
