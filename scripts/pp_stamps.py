@@ -22,14 +22,14 @@ M, N, K = 6240, 2560, 2048
 x = (torch.randn(M, K, device=dev)).to(torch.bfloat16)
 w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
 out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-aux = torch.zeros(8 * 10 * 4, dtype=torch.bfloat16, device=dev)           # 8 waves x 10 stamps x 8 bytes
+aux = torch.zeros(8 * 16 * 4, dtype=torch.bfloat16, device=dev)           # 8 waves x 10 stamps x 8 bytes
 for _ in range(3):
     ops.tiled_gemm([dict(w=w, static_count=M)], x, out, max_rows=M, epilogue=ops.EPI_BF16, aux_out=aux)
 torch.cuda.synchronize()
-st = aux.view(torch.int64).cpu().reshape(8, 10)
+st = aux.view(torch.int64).cpu().reshape(8, 16)
 t0 = int(st[:, 0].min())
 names = ["L0 start", "L0 issued", "after bar1", "M0 issued", "after bar2/L1 start", "L1 issued", "vmcnt(8) done", "after bar3", "M1 issued", "after bar4"]
 print("cycles relative to the earliest wave's phase start (shader clock); one row per wave (0-3 group 0, 4-7 group 1)")
 print(" " * 8 + " ".join(f"{n[:12]:>13s}" for n in names))
 for wv in range(8):
-    print(f"wave {wv}: " + " ".join(f"{int(st[wv, k]) - t0:13d}" for k in range(10)))
+    print(f"wave {wv}: " + " ".join(f"{int(st[wv, k]) - t0:13d}" for k in range(10)) + f"   entry->loop {int(st[wv,10]-st[wv,12])} loop {int(st[wv,11]-st[wv,10])} loop->exit {int(st[wv,13]-st[wv,11])} | ticks/us {int(st[wv,13]-st[wv,12]) / max((int(st[wv,15]-st[wv,14])) / 100.0, 1e-9):.0f}")

@@ -18,6 +18,7 @@
 // Roofline: MFMA (2.5 PFLOP/s dense bf16).  Intensity of a 128x128 tile: 64 flop per byte moved from L2.
 #include "umoe_common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 #define TG_MAXG 12
@@ -318,6 +319,78 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
     tg_epilogue<EPI, MI>(p, g, acc, count, roff, row0 + 16 * MI * wm, fbase, lane);
 }
 
+// Epilogue through LDS for the 256 x 256 variant (bf16 outputs): a lane's accumulators are 4 features of one token, so direct
+// stores put 32 contiguous bytes per token row (a quarter of a 128-byte line per instruction).  Each wave parks its 128-token x
+// 64-feature tile (bias added, rounded to bf16; SwiGLU applied: 32 features) in a private 16 KiB piece of the now idle
+// staging ring, token-major, and reads it back 16 bytes per lane: whole rows of 128 (64) contiguous bytes per store, the
+// residual read the same way.  Wave-private, and a wave's LDS operations execute in order: no barrier.
+template <int EPI>
+__device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const umoe_tgroup_t& g, const f32x4_t (&acc)[4][8], const int count,
+                                                const int roff, const int rbase, const int cbase, const int lane, char* my) {
+    constexpr bool SW = EPI == UMOE_EPI_SWIGLU;
+    constexpr int NJ = SW ? 2 : 4;      // 16-feature groups per staged row
+    constexpr int RB = NJ * 32;         // bytes per staged row
+    constexpr int CPR = RB / 16;        // 16-byte chunks per row
+    const int h = lane >> 4, c16 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 16 * i + c16;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = cbase + 16 * j + 4 * h;
+            uint16_t y[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (SW) {
+                    const float gt = rbf(acc[j][i][q]);
+                    const float up = rbf(acc[j + 2][i][q]);
+                    const float si = rbf(gt / (1.0f + expf(-gt)));
+                    y[q] = f2bf(si * up);
+                } else {
+                    y[q] = f2bf(acc[j][i][q] + ((g.bias && col + q < g.n) ? g.bias[col + q] : 0.f));
+                }
+            }
+            const int chunk = 2 * j + (h >> 1);
+            *reinterpret_cast<uint2*>(my + row * RB + ((chunk ^ (row & (CPR - 1))) << 4) + (h & 1) * 8) =
+                make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int RPI = 64 / CPR;       // rows per wave-instruction
+    const int rl = lane / CPR, c = lane % CPR;
+    const int col = cbase + c * 8;
+    const int oc = g.out_col_off;
+#pragma unroll 4
+    for (int it = 0; it < 128 / RPI; ++it) {
+        const int row = it * RPI + rl;
+        const uint4 d = *reinterpret_cast<const uint4*>(my + row * RB + ((c ^ (row & (CPR - 1))) << 4));
+        const int r = rbase + row;
+        if (r >= count || col >= g.n) continue;
+        const long orow = (long)g.out_row_base + roff + r;
+        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + oc + col;
+        if (col + 8 <= g.n) {
+            uint4 v = d;
+            if (EPI == UMOE_EPI_BF16_RESID) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(p.resid + orow * p.ldo + oc + col);
+                float a[8], b[8];
+                unpack8(d, a);
+                unpack8(rv, b);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a[q] = b[q] + a[q];
+                v = pack8(a);
+            }
+            *reinterpret_cast<uint4*>(o) = v;
+        } else {
+            const uint16_t* dv = reinterpret_cast<const uint16_t*>(&d);
+            for (int q = 0; q < 8 && col + q < g.n; ++q) {
+                float x = bf2f(dv[q]);
+                if (EPI == UMOE_EPI_BF16_RESID) x = bf2f(p.resid[orow * p.ldo + oc + col + q]) + x;
+                o[q] = f2bf(x);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ 256 x 256 tiles, two wave groups in ping-pong
 // 512 threads = 8 waves as 2 (token halves, wr) x 4 (feature quarters, wc); a wave owns 128 tokens x 64 features = 4 x 8
 // accumulators (128 registers).  Each SIMD carries one wave of each group; the groups run ONE BARRIER APART, so while group 0
@@ -335,6 +408,9 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args p, const tg_pack gp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef UMOE_PP_STAMPS
+    const unsigned long long t_entry = clock64(), w_entry = wall_clock64();
+#endif
     constexpr int UNIT = 256 * 64, SLOT = 2 * UNIT;
     constexpr bool SW = EPI == UMOE_EPI_SWIGLU;
     constexpr int NTILE = SW ? 128 : 256;
@@ -405,6 +481,29 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
         }
     };
 
+    // Steady state (tiles that lie entirely inside K): running source pointers, one 64-bit add per DMA.  Every VALU
+    // instruction of a wave in its load segment takes issue cycles from the MFMAs of the other group's wave on the same SIMD
+    // (measured with the address arithmetic above in the loop: 16 MFMAs took 360 cycles instead of 256).
+    const char* tptr[2];
+    const char* wptr[2];
+    long tinc[2], winc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        tinc[q] = tdel[q] ? 64 : 0;
+        winc[q] = wdel[q] ? 64 : 0;
+        tptr[q] = zero + tdel[q] + 3 * tinc[q];      // the prologue stages tiles 0..2
+        wptr[q] = zero + wdel[q] + 3 * winc[q];
+    }
+    auto stage_run = [&](const char* (&ptr)[2], const long (&inc)[2], const int unit_off, const int slot_off) {
+        char* base = smem + slot_off + unit_off;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr[q],
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * q) * 1024), 16, 0, 0);
+            ptr[q] += inc[q];
+        }
+    };
+
     f32x4_t acc[4][8];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -414,12 +513,11 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     int wrow[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wrow[j] = SW ? ((j < 2 ? 0 : 128) + 32 * wc + 16 * (j & 1)) : (64 * wc + 16 * j);
-    // operand read offsets inside a unit (the swizzle term only depends on c16: rows step by 16)
-    int woff[4], toff[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) woff[j] = tg_off<4>(wrow[j] + c16, h);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) toff[i] = UNIT + tg_off<4>(128 * wr + 16 * i + c16, h);
+    // operand reads: ONE base register per unit, the fragments at compile-time offsets (rows step by 16: the swizzle term
+    // only depends on c16) -> ds_read_b128 with immediate offsets
+    const int wbase = tg_off<4>(wrow[0] + c16, h);
+    const int tbase = UNIT + tg_off<4>(128 * wr + c16, h);
+    auto wfo = [](int j) { return SW ? ((j & 1) * 1024 + (j >> 1) * 8192) : j * 1024; };
 
     const int KT = (K + 31) >> 5;
     // prologue: tiles 0..2 in flight, tile 0 landed and visible
@@ -432,23 +530,29 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind group 0 from here on
 #ifdef UMOE_PP_STAMPS
-    unsigned long long st[10];
+    unsigned long long st[12];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) st[k] = 0;
-#define PP_ST(k) if (v == (KT >> 1)) st[k] = clock64()
+    for (int k = 0; k < 12; ++k) st[k] = 0;
+    st[10] = clock64();          // loop start
+#define PP_ST(k) if (v == 8) st[k] = clock64()
 #else
 #define PP_ST(k)
 #endif
-    for (int v = 0; v < KT; ++v) {
-        const char* T = smem + (v & 3) * SLOT;
+    auto tile_step = [&](const int v, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int so = (v & 3) * SLOT;               // ring slot of tile v (read); tile v + 3 goes to slot (v + 3) & 3
+        const int sn = ((v + 3) & 3) * SLOT;
+        const char* Wb = smem + so + wbase;
+        const char* Tb = smem + so + tbase;
         bf16x8_t wf[4], af[4];
         // ---- phase 2v
         PP_ST(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(T + woff[j]));
+        for (int j = 0; j < 4; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Wb + wfo(j)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(T + toff[i]));
-        stage(wdel, 0, v + 3);
+        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + i * 1024));
+        if (STEADY) stage_run(wptr, winc, 0, sn);
+        else stage(wdel, 0, v + 3);
         PP_ST(1);
         __builtin_amdgcn_s_barrier();
         PP_ST(2);
@@ -463,8 +567,9 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
         // ---- phase 2v + 1
         PP_ST(4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(T + toff[4 + i]));
-        stage(tdel, UNIT, v + 3);
+        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + (4 + i) * 1024));
+        if (STEADY) stage_run(tptr, tinc, UNIT, sn);
+        else stage(tdel, UNIT, v + 3);
         PP_ST(5);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         PP_ST(6);
@@ -479,17 +584,37 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
         PP_ST(8);
         __builtin_amdgcn_s_barrier();
         PP_ST(9);
-    }
+    };
+    // tiles v + 3 <= KT - 2 lie entirely inside K (only the last tile can hold the K tail): running pointers; the last four
+    // iterations stage the tail tile and the zero tiles with the arithmetic addresses
+    const int v_steady = KT - 4 > 0 ? KT - 4 : 0;
+    int v = 0;
+    for (; v < v_steady; ++v) tile_step(v, std::true_type{});
+    for (; v < KT; ++v) tile_step(v, std::false_type{});
 #ifdef UMOE_PP_STAMPS
-    if (p.aux_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.aux_out) + wave * 10;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) o[k] = st[k];
-    }
+    st[11] = clock64();          // loop end
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-tile DMAs of the last iterations must not outlive the workgroup
     if (wr == 0) __builtin_amdgcn_s_barrier();      // every wave has now executed the same number of barriers
+    __builtin_amdgcn_s_barrier();                   // ... and no DMA of any wave is still on its way into the ring
 
+    if constexpr (EPI == UMOE_EPI_BF16 || EPI == UMOE_EPI_BF16_RESID || EPI == UMOE_EPI_SWIGLU) {
+        const bool al16 = ((p.ldo | g.out_col_off) & 7) == 0 && (reinterpret_cast<size_t>(p.out) & 15) == 0 &&
+                          (EPI != UMOE_EPI_BF16_RESID || (reinterpret_cast<size_t>(p.resid) & 15) == 0);
+        if (al16 && !(SW && p.aux_out)) {     // 16-byte aligned rows; the aux stores keep the direct path
+            tg_epilogue_lds<EPI>(p, g, acc, count, roff, row0 + 128 * wr, n0 + (SW ? 32 : 64) * wc, lane, smem + wave * 16384);
+#ifdef UMOE_PP_STAMPS
+            if (p.aux_out && !SW && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(p.aux_out) + wave * 16;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) o[k] = st[k];
+                o[12] = t_entry; o[13] = clock64(); o[14] = w_entry; o[15] = wall_clock64();
+            }
+#endif
+            return;
+        }
+    }
     int fbase[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) fbase[j] = n0 + (SW ? 32 * wc + 16 * (j & 1) : wrow[j]);
