@@ -135,6 +135,9 @@ if "tiled" in which:
             xin = rnd(M, K)
             t = timeit(lambda i: ops.tlinear(xin, w), iters=20)
             print(f"tiled {name} M={M} N={N} K={K}: {t:.1f} us  {2*M*N*K/t/1e6:.0f} TFLOP/s", flush=True)
+        wo_, xo_, ro_ = rnd(D, D), rnd(M, D), rnd(M, D)
+        t = timeit(lambda i: ops.tlinear(xo_, wo_, resid=ro_), iters=20)
+        print(f"tiled o_proj+resid M={M}: {t:.1f} us  {2*M*D*D/t/1e6:.0f} TFLOP/s", flush=True)
         wg, wu, wd = rnd(Id, D), rnd(Id, D), rnd(D, Id)
         hb = torch.empty(M, Id, device=dev, dtype=torch.bfloat16)
         yb = torch.empty(M, D, device=dev, dtype=torch.bfloat16)

@@ -324,11 +324,10 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
 // 64-feature tile (bias added, rounded to bf16; SwiGLU applied: 32 features) in a private 16 KiB piece of the now idle
 // staging ring, token-major, and reads it back 16 bytes per lane: whole rows of 128 (64) contiguous bytes per store, the
 // residual read the same way.  Wave-private, and a wave's LDS operations execute in order: no barrier.
-template <int EPI>
-__device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const umoe_tgroup_t& g, const f32x4_t (&acc)[4][8], const int count,
-                                                const int roff, const int rbase, const int cbase, const int lane, char* my) {
-    constexpr bool SW = EPI == UMOE_EPI_SWIGLU;
-    constexpr int NJ = SW ? 2 : 4;      // 16-feature groups per staged row
+//   tile_store_lds: NJ 16-feature groups per row; val(i, j, q) = bf16 bits of feature 16 j + 4 h + q of token 16 i + c16.
+template <int NJ, bool RESID, class F>
+__device__ __forceinline__ void tile_store_lds(F val, uint16_t* dst, const uint16_t* resid, const long ld, const int ncols, const long orow0,
+                                               const int count, const int rbase, const int cbase, const int lane, char* my) {
     constexpr int RB = NJ * 32;         // bytes per staged row
     constexpr int CPR = RB / 16;        // 16-byte chunks per row
     const int h = lane >> 4, c16 = lane & 15;
@@ -337,41 +336,26 @@ __device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const 
         const int row = 16 * i + c16;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int col = cbase + 16 * j + 4 * h;
-            uint16_t y[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (SW) {
-                    const float gt = rbf(acc[j][i][q]);
-                    const float up = rbf(acc[j + 2][i][q]);
-                    const float si = rbf(gt / (1.0f + expf(-gt)));
-                    y[q] = f2bf(si * up);
-                } else {
-                    y[q] = f2bf(acc[j][i][q] + ((g.bias && col + q < g.n) ? g.bias[col + q] : 0.f));
-                }
-            }
+            const uint32_t y0 = val(i, j, 0), y1 = val(i, j, 1), y2 = val(i, j, 2), y3 = val(i, j, 3);
             const int chunk = 2 * j + (h >> 1);
-            *reinterpret_cast<uint2*>(my + row * RB + ((chunk ^ (row & (CPR - 1))) << 4) + (h & 1) * 8) =
-                make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
+            *reinterpret_cast<uint2*>(my + row * RB + ((chunk ^ (row & (CPR - 1))) << 4) + (h & 1) * 8) = make_uint2(y0 | (y1 << 16), y2 | (y3 << 16));
         }
     }
     __builtin_amdgcn_wave_barrier();
     constexpr int RPI = 64 / CPR;       // rows per wave-instruction
     const int rl = lane / CPR, c = lane % CPR;
     const int col = cbase + c * 8;
-    const int oc = g.out_col_off;
 #pragma unroll 4
     for (int it = 0; it < 128 / RPI; ++it) {
         const int row = it * RPI + rl;
         const uint4 d = *reinterpret_cast<const uint4*>(my + row * RB + ((c ^ (row & (CPR - 1))) << 4));
         const int r = rbase + row;
-        if (r >= count || col >= g.n) continue;
-        const long orow = (long)g.out_row_base + roff + r;
-        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow * p.ldo + oc + col;
-        if (col + 8 <= g.n) {
+        if (r >= count || col >= ncols) continue;
+        uint16_t* o = dst + (orow0 + r) * ld + col;
+        if (col + 8 <= ncols) {
             uint4 v = d;
-            if (EPI == UMOE_EPI_BF16_RESID) {
-                const uint4 rv = *reinterpret_cast<const uint4*>(p.resid + orow * p.ldo + oc + col);
+            if (RESID) {
+                const uint4 rv = *reinterpret_cast<const uint4*>(resid + (orow0 + r) * ld + col);
                 float a[8], b[8];
                 unpack8(d, a);
                 unpack8(rv, b);
@@ -382,12 +366,43 @@ __device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const 
             *reinterpret_cast<uint4*>(o) = v;
         } else {
             const uint16_t* dv = reinterpret_cast<const uint16_t*>(&d);
-            for (int q = 0; q < 8 && col + q < g.n; ++q) {
+            for (int q = 0; q < 8 && col + q < ncols; ++q) {
                 float x = bf2f(dv[q]);
-                if (EPI == UMOE_EPI_BF16_RESID) x = bf2f(p.resid[orow * p.ldo + oc + col + q]) + x;
+                if (RESID) x = bf2f(resid[(orow0 + r) * ld + col + q]) + x;
                 o[q] = f2bf(x);
             }
         }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int EPI>
+__device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const umoe_tgroup_t& g, const f32x4_t (&acc)[4][8], const int count,
+                                                const int roff, const int rbase, const int cbase, const int lane, char* my) {
+    constexpr bool SW = EPI == UMOE_EPI_SWIGLU;
+    const int h = lane >> 4;
+    const long orow0 = (long)g.out_row_base + roff;
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + g.out_col_off;
+    if constexpr (SW) {
+        auto act = [&](int i, int j, int q) -> uint32_t {
+            const float gt = rbf(acc[j][i][q]);
+            const float up = rbf(acc[j + 2][i][q]);
+            const float si = rbf(gt / (1.0f + expf(-gt)));
+            return f2bf(si * up);
+        };
+        tile_store_lds<2, false>(act, out, nullptr, p.ldo, g.n, orow0, count, rbase, cbase, lane, my);
+        if (p.aux_out) {   // pre-activations for the backward pass: gate at [row][col], up at [row][n + col]
+            tile_store_lds<2, false>([&](int i, int j, int q) -> uint32_t { return f2bf(acc[j][i][q]); }, p.aux_out, nullptr, p.ld_aux, g.n,
+                                     orow0, count, rbase, cbase, lane, my);
+            tile_store_lds<2, false>([&](int i, int j, int q) -> uint32_t { return f2bf(acc[j + 2][i][q]); }, p.aux_out + g.n, nullptr, p.ld_aux,
+                                     g.n, orow0, count, rbase, cbase, lane, my);
+        }
+    } else {
+        auto lin = [&](int i, int j, int q) -> uint32_t {
+            const int col = cbase + 16 * j + 4 * h + q;
+            return f2bf(acc[j][i][q] + ((g.bias && col < g.n) ? g.bias[col] : 0.f));
+        };
+        tile_store_lds<4, EPI == UMOE_EPI_BF16_RESID>(lin, out, p.resid + g.out_col_off, p.ldo, g.n, orow0, count, rbase, cbase, lane, my);
     }
 }
 
@@ -405,8 +420,8 @@ __device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const 
 //   WAR: W(v+3) overwrites W(v-1), last read in phase 2v-2; tokens(v+3) overwrite tokens(v-1), last read in phase 2v-1: two
 //        phases earlier, i.e. also the lagging group has retired those reads (lgkmcnt) before any wave issues the DMA.
 //   Tiles beyond K are staged from the zero block, so the vmcnt arithmetic is the same in every iteration.
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args p, const tg_pack gp) {
+template <int EPI, int PRIO>
+__global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args p, const tg_pack gp, const int epi_lds_mask, const int nx, const int ny, const int nz, const int ragged_order) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef UMOE_PP_STAMPS
     const unsigned long long t_entry = clock64(), w_entry = wall_clock64();
@@ -414,19 +429,33 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     constexpr int UNIT = 256 * 64, SLOT = 2 * UNIT;
     constexpr bool SW = EPI == UMOE_EPI_SWIGLU;
     constexpr int NTILE = SW ? 128 : 256;
-    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by linear id, so the workgroups that share an XCD
-    // (and its L2) take a CONTIGUOUS range of tiles -- column tiles of the same token rows next to each other -- instead
-    // of every 8th tile: an XCD then pulls ~1/8 of the token rows (and all of the weights) through its L2, not all of both.
-    // Bijective for any grid size (q + 1 tiles for the first nwg % 8 XCDs, q for the rest).
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by linear id (1-D launch), so the workgroups with
+    // lin % 8 == x share an L2.  Two bijective maps from (x, lin / 8) to tiles:
+    //  * static groups (every tile is live; dense layers, shared experts, the codec head): XCD x takes a CONTIGUOUS range of the
+    //    row-major tile order (q + 1 tiles for the first nwg % 8 XCDs, q for the rest) -- balanced to one tile, which decides a
+    //    launch of ~one workgroup per CU, and an XCD pulls ~1/8 of the token rows through its L2;
+    //  * ragged groups (live row tiles known only on the device): XCD x takes the row tiles RR = x, x + 8, ... (RR runs over
+    //    groups and token tiles; the grid is padded to a multiple of 8 row tiles), sweeping the nx column tiles of a row tile
+    //    before the next -- every XCD gets row tiles of EVERY expert (contiguous ranges would put one expert on one XCD
+    //    and let the largest expert set the time; measured in the training step: 228 -> 201 us per launch).
+    int bx, by, bz;
     {
-        const unsigned nx = gridDim.x, ny = gridDim.y, nwg = nx * ny * gridDim.z;
-        const unsigned lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
-        const unsigned q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
-        const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-        bx = (int)(id % nx);
-        by = (int)((id / nx) % ny);
-        bz = (int)(id / (nx * ny));
+        const unsigned lin = blockIdx.x, xcd = lin & 7, seq = lin >> 3;
+        if (ragged_order) {
+            const unsigned rr = seq / (unsigned)nx;
+            bx = (int)(seq - rr * (unsigned)nx);
+            const unsigned RR = rr * 8 + xcd;
+            if (RR >= (unsigned)(ny * nz)) return;       // padding row tiles
+            bz = (int)(RR / (unsigned)ny);
+            by = (int)(RR - (unsigned)bz * (unsigned)ny);
+        } else {
+            const unsigned nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+            const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
+            bx = (int)(id % (unsigned)nx);
+            const unsigned RR = id / (unsigned)nx;
+            bz = (int)(RR / (unsigned)ny);
+            by = (int)(RR - (unsigned)bz * (unsigned)ny);
+        }
     }
     const umoe_tgroup_t g = gp.g[bz];
     const int count = g.count ? *g.count : g.static_count;
@@ -529,6 +558,7 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind group 0 from here on
+    if (PRIO == 2 && wr == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (it loses every arbitration by age)
 #ifdef UMOE_PP_STAMPS
     unsigned long long st[12];
 #pragma unroll
@@ -556,12 +586,12 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
         PP_ST(1);
         __builtin_amdgcn_s_barrier();
         PP_ST(2);
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         PP_ST(3);
         __builtin_amdgcn_s_barrier();
         // ---- phase 2v + 1
@@ -575,12 +605,12 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
         PP_ST(6);
         __builtin_amdgcn_s_barrier();
         PP_ST(7);
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][4 + i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         PP_ST(8);
         __builtin_amdgcn_s_barrier();
         PP_ST(9);
@@ -601,10 +631,11 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     if constexpr (EPI == UMOE_EPI_BF16 || EPI == UMOE_EPI_BF16_RESID || EPI == UMOE_EPI_SWIGLU) {
         const bool al16 = ((p.ldo | g.out_col_off) & 7) == 0 && (reinterpret_cast<size_t>(p.out) & 15) == 0 &&
                           (EPI != UMOE_EPI_BF16_RESID || (reinterpret_cast<size_t>(p.resid) & 15) == 0);
-        if (al16 && !(SW && p.aux_out)) {     // 16-byte aligned rows; the aux stores keep the direct path
+        const bool aux16 = !SW || !p.aux_out || (((p.ld_aux | g.n) & 7) == 0 && (reinterpret_cast<size_t>(p.aux_out) & 15) == 0);
+        if (al16 && aux16 && ((epi_lds_mask >> (SW ? 2 : (EPI == UMOE_EPI_BF16_RESID ? 1 : 0))) & 1)) {     // 16-byte aligned rows; the aux stores keep the direct path
             tg_epilogue_lds<EPI>(p, g, acc, count, roff, row0 + 128 * wr, n0 + (SW ? 32 : 64) * wc, lane, smem + wave * 16384);
 #ifdef UMOE_PP_STAMPS
-            if (p.aux_out && !SW && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) {
+            if (p.aux_out && !SW && blockIdx.x == 0 && lane == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 unsigned long long* o = reinterpret_cast<unsigned long long*>(p.aux_out) + wave * 16;
 #pragma unroll
@@ -621,20 +652,32 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     tg_epilogue<EPI, 8>(p, g, acc, count, roff, row0 + 128 * wr, fbase, lane);
 }
 
-template <int EPI>
-static int launch_tgemm_pp(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
+template <int EPI, int PRIO>
+static int launch_tgemm_pp_v(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
     tg_pack gp;
     memset(&gp, 0, sizeof(gp));
     memcpy(gp.g, a->groups, sizeof(umoe_tgroup_t) * a->num_groups);
     constexpr int lds = 4 * 2 * 256 * 64;
     static bool configured = false;
     if (!configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_pp_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_pp_kernel<EPI, PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
     const int ntile = EPI == UMOE_EPI_SWIGLU ? 128 : 256;
-    dim3 grid((unsigned)ceil_div(max_n, ntile), (unsigned)ceil_div(a->max_rows, 256), (unsigned)a->num_groups);
-    tgemm_pp_kernel<EPI><<<grid, 512, lds, s>>>(*a, gp);
+    const int nx = ceil_div(max_n, ntile), ny = ceil_div(a->max_rows, 256), nz = a->num_groups;
+    int ragged = 0;
+    for (int i = 0; i < a->num_groups; ++i) ragged |= a->groups[i].count != nullptr;
+    const long nwg = ragged ? (long)nx * (((long)ny * nz + 7) & ~7L) : (long)nx * ny * nz;
+    UMOE_REQUIRE(nwg < (1L << 31), "umoe_tiled_gemm: too many tiles (%ld)", nwg);
+    dim3 grid((unsigned)nwg);
+    // which bf16 epilogues go through LDS (bit 0 plain, 1 residual, 2 SwiGLU).  Measured at 6240 rows (scripts/kbench.py tiled):
+    // residual 621 -> 833 TFLOP/s (the residual is read in whole rows too), SwiGLU +2 %, plain -5 % (stays direct)
+    static int mask = -1;
+    if (mask < 0) {
+        const char* v = getenv("UMOE_TGEMM_EPI_LDS");
+        mask = v ? atoi(v) : 6;
+    }
+    tgemm_pp_kernel<EPI, PRIO><<<grid, 512, lds, s>>>(*a, gp, mask, nx, ny, nz, ragged);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -677,12 +720,24 @@ static int tgemm_tm(const umoe_tgemm_args* a) {
     return wgs >= minwg ? 256 : 128;     // big tiles only when they still fill the chip (2 workgroups per CU)
 }
 
+template <int EPI>
+static int launch_tgemm_pp(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
+    static int prio = -1;
+    if (prio < 0) {
+        const char* v = getenv("UMOE_TGEMM_PRIO");
+        prio = v ? atoi(v) : 1;
+    }
+    if (prio == 0) return launch_tgemm_pp_v<EPI, 0>(a, max_n, s);
+    if (prio == 2) return launch_tgemm_pp_v<EPI, 2>(a, max_n, s);
+    return launch_tgemm_pp_v<EPI, 1>(a, max_n, s);
+}
+
 // 256 x 256 ping-pong tiles once they fill the chip (one workgroup per CU)
 static bool tgemm_pp_pays(const umoe_tgemm_args* a, int max_n) {
     static int minwg = -1;
     if (minwg < 0) {
         const char* v = getenv("UMOE_TGEMM_PP_MINWG");
-        minwg = v ? atoi(v) : 192;
+        minwg = v ? atoi(v) : 128;
     }
     if (a->max_rows < 1024) return false;
     const long wgs = (long)ceil_div(a->max_rows, 256) * ceil_div(max_n, a->epilogue == UMOE_EPI_SWIGLU ? 128 : 256) * a->num_groups;
