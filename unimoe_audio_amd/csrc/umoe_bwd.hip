@@ -785,26 +785,45 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
         for (int g = 0; g < G; ++g)
             if ((rc = umoe_transpose_slots(a->x, a->ldx, D, nullptr, nullptr, nullptr, 1, S, xeT + (size_t)g * Sp, ldT, stream))) return rc;
     }
-    // dWd_g [D][I] = dyT[:, cols_g] * hT[:, cols_g]^T ; dWg_g [I][D] = dgT * xeT^T ; dWu_g = duT * xeT^T  (one launch per output)
-    for (int g = 0; g < G; ++g) {
-        umoe_tgroup_t t1{};
+    // dWd_g [D][I] = dyT[:, cols_g] * hT[:, cols_g]^T ; dWg_g [I][D] = dgT * xeT^T ; dWu_g = duT * xeT^T.
+    // When the caller's gradient buffers of a kind are one stacked allocation ([G][rows][cols], as ops.experts_swiglu_bwd makes
+    // them) the G products of that kind are ONE grouped launch (per-group contraction window and output row base): 8 x 88
+    // tiles fill the chip with the 256 x 256 variant, one expert's 88 tiles alone run on the small tiles at ~400 TFLOP/s.
+    auto window = [&](umoe_tgroup_t& t, int g) {
+        if (ragged) { t.k_off = a->offsets + g; t.k_count = a->counts + g; t.k = 8; }
+        else { t.k = Sp; t.a_col_off = g * Sp; }       // zero-padded private column range
+    };
+    auto stacked = [&](uint16_t* const* ptrs, size_t elems) {
+        for (int g = 1; g < G; ++g)
+            if (ptrs[g] != ptrs[0] + (size_t)g * elems) return false;
+        return true;
+    };
+    auto products = [&](const uint16_t* wT, int n, int rows, const uint16_t* aT, int a_row_base, uint16_t* const* outs) -> int {
+        // out_g [rows][n] = aT[a_row_base + r][cols_g] . wT[c][cols_g]
         umoe_tgemm_args b{};
-        const int cbase = ragged ? 0 : g * Sp;
-        auto window = [&](umoe_tgroup_t& t) {
-            if (ragged) { t.k_off = a->offsets + g; t.k_count = a->counts + g; t.k = 8; }
-            else { t.k = Sp; }       // zero-padded columns
-        };
-        t1.w = hT + cbase; t1.n = I; t1.ldw = ldT; t1.static_count = D; window(t1);
-        b.groups = &t1; b.num_groups = 1; b.max_rows = D; b.a = dyT + cbase; b.lda = ldT; b.out = a->dw_down[g]; b.ldo = I; b.epilogue = UMOE_EPI_BF16;
-        if ((rc = umoe_tiled_gemm(&b, stream))) return rc;
-        t1 = umoe_tgroup_t{};
-        t1.w = xeT + cbase; t1.n = D; t1.ldw = ldT; t1.static_count = I; window(t1);
-        b.max_rows = I; b.a = dguT + cbase; b.out = a->dw_gate[g]; b.ldo = D;
-        if ((rc = umoe_tiled_gemm(&b, stream))) return rc;
-        t1.a_row_base = I;
-        b.out = a->dw_up[g];
-        if ((rc = umoe_tiled_gemm(&b, stream))) return rc;
-    }
+        b.max_rows = rows; b.a = aT; b.lda = ldT; b.ldo = n; b.epilogue = UMOE_EPI_BF16;
+        if (stacked(outs, (size_t)rows * n)) {
+            memset(tg, 0, sizeof(tg));
+            for (int g = 0; g < G; ++g) {
+                tg[g].w = wT + (ragged ? 0 : g * Sp); tg[g].n = n; tg[g].ldw = ldT; tg[g].static_count = rows; tg[g].a_row_base = a_row_base;
+                tg[g].out_row_base = g * rows;
+                window(tg[g], g);
+            }
+            b.groups = tg; b.num_groups = G; b.out = outs[0];
+            return umoe_tiled_gemm(&b, stream);
+        }
+        for (int g = 0; g < G; ++g) {
+            umoe_tgroup_t t1{};
+            t1.w = wT + (ragged ? 0 : g * Sp); t1.n = n; t1.ldw = ldT; t1.static_count = rows; t1.a_row_base = a_row_base;
+            window(t1, g);
+            b.groups = &t1; b.num_groups = 1; b.out = outs[g];
+            if (int rc2 = umoe_tiled_gemm(&b, stream)) return rc2;
+        }
+        return 0;
+    };
+    if ((rc = products(hT, I, D, dyT, 0, a->dw_down))) return rc;
+    if ((rc = products(xeT, D, I, dguT, 0, a->dw_gate))) return rc;
+    if ((rc = products(xeT, D, I, dguT, I, a->dw_up))) return rc;
     return 0;
 }
 

@@ -487,9 +487,10 @@ def experts_swiglu_bwd(ws_list, *, x, h, gu, dy, dx_slots, D: int, I: int, max_r
     G = len(ws_list)
     dev = x.device
     arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])
-    dwg = [torch.empty_like(w[0]) for w in ws_list]
-    dwu = [torch.empty_like(w[1]) for w in ws_list]
-    dwd = [torch.empty_like(w[2]) for w in ws_list]
+    # one stacked allocation per kind: the composite then runs each kind's G weight-gradient products as ONE grouped launch
+    dwg = list(torch.empty((G,) + tuple(ws_list[0][0].shape), dtype=torch.bfloat16, device=dev).unbind(0))
+    dwu = list(torch.empty((G,) + tuple(ws_list[0][1].shape), dtype=torch.bfloat16, device=dev).unbind(0))
+    dwd = list(torch.empty((G,) + tuple(ws_list[0][2].shape), dtype=torch.bfloat16, device=dev).unbind(0))
     keep = (arr([w[0] for w in ws_list]), arr([w[1] for w in ws_list]), arr([w[2] for w in ws_list]), arr(dwg), arr(dwu), arr(dwd))
     a = L.SwigluBwdArgs(num_groups=G, w_gate=keep[0], w_up=keep[1], w_down=keep[2], D=D, I=I, counts=_p(counts), offsets=_p(offsets),
                         slot_token=_p(slot_token), max_rows=max_rows, slot_rows=h.shape[0], row_base=row_base,
