@@ -37,7 +37,9 @@ def _ref_linear(x, w, bias=None):
 
 # ----------------------------------------------------------------------------- GEMM family
 @pytest.mark.parametrize("S,K,N", [(300, 2048, 2560), (129, 2752, 2048), (128, 1376, 2048), (1, 64, 8), (257, 72, 130),
-                                   (640, 2048, 12324)])
+                                   (640, 2048, 12324),
+                                   # >= 1024 rows and >= 128 tiles of 256 x 256: the ping-pong variant (K tail, ragged last tiles)
+                                   (2048, 520, 4000), (2300, 256, 3600)])
 def test_tiled_gemm_plain_bias_resid_f32(dev, S, K, N):
     """umoe_tiled_gemm (row-major weights, 128x128x64 MFMA tiles) against an fp32 torch reference with the reference's
     rounding points: Linear output rounded to bf16, then bias-free residual add rounded again."""
@@ -65,15 +67,16 @@ def test_tiled_gemm_plain_bias_resid_f32(dev, S, K, N):
         assert (y4.float() - y.float()).abs().max() <= 2 ** -6 * ref.abs().max()
 
 
-def test_tiled_gemm_ragged_swiglu_groups(dev):
+@pytest.mark.parametrize("S,D,I,E,p_sel", [(700, 256, 352, 4, 0.4),
+                                           (2600, 512, 1024, 8, 0.25)])   # 704 / 176 tiles of 256 x 256: ping-pong variant, ragged order
+def test_tiled_gemm_ragged_swiglu_groups(dev, S, D, I, E, p_sel):
     """Routed experts at training-like sizes: ragged row lists (device-side counts / offsets / gather list), SwiGLU
     epilogue from separate gate/up matrices, then the down projection over the slot rows; oracle = oracle.dcmoe.swiglu_mlp."""
     from unimoe_audio_amd import ops
     from oracle import dcmoe as OD
     g = torch.Generator().manual_seed(5)
-    S, D, I, E = 700, 256, 352, 4
     x = torch.randn(S, D, generator=g).to(torch.bfloat16)
-    mask = (torch.rand(S, E + 3, generator=g) < 0.4).to(torch.int32)
+    mask = (torch.rand(S, E + 3, generator=g) < p_sel).to(torch.int32)
     mask[:, 2] = 0                                   # an expert nobody chose
     wg = [(torch.randn(I, D, generator=g) * 0.06).to(torch.bfloat16) for _ in range(E)]
     wu = [(torch.randn(I, D, generator=g) * 0.06).to(torch.bfloat16) for _ in range(E)]
@@ -505,6 +508,21 @@ def test_attention_decode_single_launch_merge(dev, rows, H, KVH, L, splits):
         got = ops.attention(q, kc, vc, kv_start, q0, 1, H, splits=splits, single_launch=sync)
         assert torch.equal(got, ref)
         assert int(sync.abs().sum()) == 0          # the counters are zero again after every call
+
+
+def test_gemm256_forced_in_child_process():
+    """The 256 x 256 ping-pong GEMM is chosen by size; UMOE_TGEMM_PP=1 forces it for EVERY tiled GEMM.  Re-run the GEMM,
+    ragged / SwiGLU, block-backward and backward-kernel tests with it forced (small and odd shapes: partial tiles, K tails,
+    gather lists, contraction windows, pre-activation outputs, fp32 outputs), in a child process because the library reads
+    the switch once."""
+    import subprocess, sys
+    env = dict(os.environ, UMOE_TGEMM_PP="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_ops.py"), os.path.join(here, "test_gpu_bwd.py"), "-x", "-q",
+                        "-m", "gpu", "-k", "tiled or ragged or backward or multitile or bwd", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
 
 
 # ----------------------------------------------------------------------------- codec side

@@ -226,8 +226,8 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
         umoe_engine_destroy(e);
         return -2;
     }
-    hipMemset(e->k_cache, 0, kv * 2);
-    hipMemset(e->v_cache, 0, kv * 2);
+    UMOE_HIP(hipMemset(e->k_cache, 0, kv * 2));
+    UMOE_HIP(hipMemset(e->v_cache, 0, kv * 2));
     if (ensure_workspace(e, cfg->rows)) {
         umoe_engine_destroy(e);
         return -2;
@@ -250,17 +250,17 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
 
 extern "C" void umoe_engine_destroy(umoe_engine* e) {
     if (!e) return;
-    if (e->exec) hipGraphExecDestroy(e->exec);
-    if (e->graph) hipGraphDestroy(e->graph);
-    for (hipEvent_t x : e->ev) hipEventDestroy(x);
-    if (e->ev_fork) hipEventDestroy(e->ev_fork);
-    if (e->ev_join) hipEventDestroy(e->ev_join);
-    if (e->s2) hipStreamDestroy(e->s2);
-    if (e->ws) hipFree(e->ws);
-    if (e->k_cache) hipFree(e->k_cache);
-    if (e->v_cache) hipFree(e->v_cache);
-    if (e->d_delay) hipFree(e->d_delay);
-    if (e->d_groups) hipFree(e->d_groups);
+    if (e->exec) (void)hipGraphExecDestroy(e->exec);
+    if (e->graph) (void)hipGraphDestroy(e->graph);
+    for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->s2) (void)hipStreamDestroy(e->s2);
+    if (e->ws) (void)hipFree(e->ws);
+    if (e->k_cache) (void)hipFree(e->k_cache);
+    if (e->v_cache) (void)hipFree(e->v_cache);
+    if (e->d_delay) (void)hipFree(e->d_delay);
+    if (e->d_groups) (void)hipFree(e->d_groups);
     delete e;
 }
 
@@ -638,8 +638,8 @@ extern "C" int umoe_engine_capture(umoe_engine* e, const umoe_decode_io* io, umo
     UMOE_REQUIRE(e && io && io->tokens && io->state, "umoe_engine_capture: null argument");
     UMOE_REQUIRE(e->T_prompt > 0, "umoe_engine_capture: prefill first");
     hipStream_t s = (hipStream_t)stream;
-    if (e->exec) { hipGraphExecDestroy(e->exec); e->exec = nullptr; }
-    if (e->graph) { hipGraphDestroy(e->graph); e->graph = nullptr; }
+    if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
+    if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
     UMOE_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue_step(e, io, s);
     hipGraph_t g = nullptr;

@@ -204,9 +204,13 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
     //      as with register staging).  No data registers, no ds_write pass; chunks outside the tile read a block of zeros.
     constexpr int RPG = 64 / BKC;                         // tile rows per wave-instruction
     constexpr int AGW = TM / RPG / 4, WGW = 128 / RPG / 4;   // groups per wave
-    const uint16_t* gap[GLDS ? AGW : 1];
-    const uint16_t* gwp[GLDS ? WGW : 1];
+    // source = zero block + integer byte delta (0 for chunks outside the tile): the choice is arithmetic, so every stage issues the
+    // same number of DMA instructions whatever the data (a pointer select in front of the intrinsic compiles to two exec-masked
+    // DMAs; the counted vmcnt waits stay safe with them -- extra instructions only over-wait -- but they cost issue slots)
+    long gad[GLDS ? AGW : 1];
+    long gwd[GLDS ? WGW : 1];
     int gch = 0;                                          // this lane's chunk (same for every group: row & swizzle mask repeats)
+    const char* zero_b = reinterpret_cast<const char*>(&tg_zero16);
     if (GLDS) {
         const int rl = lane / BKC, slot = lane % BKC;
 #pragma unroll
@@ -215,10 +219,10 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
             const int c = slot ^ tg_swz<BKC>(tr);
             gch = c;                                      // RPG * 4 is a multiple of the swizzle period: c does not depend on j
             const int r = row0 + tr;
-            gap[j] = nullptr;
+            gad[j] = 0;
             if (r < count) {
                 const long arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
-                gap[j] = p.a + arow * (long)p.lda + g.a_col_off + koff + c * 8;
+                gad[j] = reinterpret_cast<const char*>(p.a + arow * (long)p.lda + g.a_col_off + koff + c * 8) - zero_b;
             }
         }
 #pragma unroll
@@ -233,24 +237,23 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
             } else {
                 n = n0 + tr;
             }
-            gwp[j] = n < g.n ? wb + (long)n * g.ldw + koff + c * 8 : nullptr;
+            gwd[j] = n < g.n ? reinterpret_cast<const char*>(wb + (long)n * g.ldw + koff + c * 8) - zero_b : 0;
         }
     }
     auto stage = [&](int buf, int k0) {
-        const bool kok = k0 + gch * 8 < K;
-        const uint16_t* zero = reinterpret_cast<const uint16_t*>(&tg_zero16);
+        const long live = (k0 + gch * 8 < K) ? -1L : 0L;
         char* A = smem + buf * BUF;
         char* W = A + ABYTES;
 #pragma unroll
         for (int j = 0; j < AGW; ++j) {
-            const uint16_t* src = (kok && gap[j]) ? gap[j] + k0 : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            const long d = gad[j] == 0 ? 0 : ((gad[j] + 2L * k0) & live);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(zero_b + d),
                                              (__attribute__((address_space(3))) void*)(A + (wave + 4 * j) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < WGW; ++j) {
-            const uint16_t* src = (kok && gwp[j]) ? gwp[j] + k0 : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            const long d = gwd[j] == 0 ? 0 : ((gwd[j] + 2L * k0) & live);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(zero_b + d),
                                              (__attribute__((address_space(3))) void*)(W + (wave + 4 * j) * 1024), 16, 0, 0);
         }
     };
