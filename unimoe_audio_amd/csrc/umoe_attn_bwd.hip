@@ -166,15 +166,24 @@ __global__ __launch_bounds__(64 * GP) void attn_bwd_dq_kernel(const umoe_attn_bw
 }
 
 // ------------------------------------------------------------------------------------ dK, dV
-// grid = (64-key tiles, kv heads, rows), 4 waves: wave w owns keys K0 + 16 w .. +15 (stationary K / V fragments and the
-// dK^T / dV^T accumulators in registers), the workgroup streams the Q / dO tiles (64 queries) of every query head of the group.
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const umoe_attn_bwd_args a, const int32_t* __restrict__ kv_start,
-                                                           const float* __restrict__ Dv) {
+// grid = (64-key tiles, kv heads x P, rows), 4 waves: wave w owns keys K0 + 16 w .. +15 (stationary K / V fragments and the
+// dK^T / dV^T accumulators in registers), the workgroup streams the Q / dO tiles (64 queries) of G / P query heads of the group.
+// Causality makes the work of a key tile proportional to the queries behind it (the first tile: every query tile of every head,
+// the last: one per head), so the kernel lasts as long as its first key tile: splitting the group's heads over P workgroups
+// (P = 4 at G = 8) cuts that critical path by P and quadruples the waves in flight; the P partial sums go to fp32 slabs and
+// attn_bwd_dkv_sum_kernel adds them in fixed order (one rounding to bf16, as before).  P = 1: direct bf16 stores.
+// NW waves = 16 NW keys per workgroup: every key tile re-streams the Q / dO tiles of the queries behind it, so the L2 -> LDS
+// traffic (5.3 GB per layer at 4 x 1560 tokens with 64-key tiles: the kernel ran at L2 bandwidth) halves with 128-key tiles.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const umoe_attn_bwd_args a, const int32_t* __restrict__ kv_start,
+                                                               const float* __restrict__ Dv, const int P, float* __restrict__ slab_k,
+                                                               float* __restrict__ slab_v) {
+    constexpr int NT = NW * 64, NLD = 2048 / NT;               // threads, 16-byte chunks per thread and stage
     constexpr int HD = 128;
     constexpr int STAGE = 2 * 16384 + 512;                     // Q tile | dO tile | lse[64] | D[64]
     extern __shared__ __attribute__((aligned(16))) char smem[];   // two stages
-    const int K0 = blockIdx.x * 64, kvh = blockIdx.y, row = blockIdx.z;
-    const int G = a.H / a.KVH;
+    const int K0 = blockIdx.x * (NW * 16), kvh = blockIdx.y / P, part = blockIdx.y - kvh * P, row = blockIdx.z;
+    const int G = a.H / a.KVH, GW = G / P;                      // query heads of this workgroup: kvh G + part GW .. + GW
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 4, c16 = lane & 15;
     const int kv0 = kv_start[row];
@@ -200,14 +209,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const umoe_attn_bwd_a
     // steps: every query head of the group x every 64-query tile that can see a key of this workgroup
     const int q_first = (K0 > kv0 ? K0 : kv0) & ~63;
     const int nq_steps = q_first < a.T ? (a.T - q_first + 63) >> 6 : 0;
-    const int n_steps = G * nq_steps;
-    uint4 stg[8];
+    const int n_steps = GW * nq_steps;
+    uint4 stg[NLD];
     float stg_l = 0.f;
     auto gload = [&](int step) {
-        const int head = kvh * G + step / nq_steps, q0 = q_first + (step % nq_steps) * 64;
+        const int head = kvh * G + part * GW + step / nq_steps, q0 = q_first + (step % nq_steps) * 64;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int idx = tid + n * 256;
+        for (int n = 0; n < NLD; ++n) {
+            const int idx = tid + n * NT;
             const int tq = q0 + ((idx >> 4) & 63);
             stg[n] = make_uint4(0, 0, 0, 0);
             if (tq < a.T) stg[n] = ld16(((idx >> 10) ? a.d_out : a.q) + (((size_t)row * a.T + tq) * a.H + head) * HD + (idx & 15) * 8);
@@ -221,8 +230,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const umoe_attn_bwd_a
     auto lstore = [&](int buf) {
         char* base = smem + buf * STAGE;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int idx = tid + n * 256;
+        for (int n = 0; n < NLD; ++n) {
+            const int idx = tid + n * NT;
             st16(base + (idx >> 10) * 16384 + kvo((idx >> 4) & 63, idx & 15), stg[n]);
         }
         if (tid < 128) reinterpret_cast<float*>(base + 32768)[tid] = stg_l;
@@ -271,6 +280,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const umoe_attn_bwd_a
         if (step + 1 < n_steps) lstore(buf ^ 1);
         __syncthreads();
     }
+    if (P > 1) {
+        if (key < a.T) {
+            const size_t o = ((((size_t)part * a.rows + row) * a.KVH + kvh) * a.T + key) * HD + 4 * h;
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                *reinterpret_cast<float4*>(slab_k + o + db * 16) = make_float4(dkT[db][0], dkT[db][1], dkT[db][2], dkT[db][3]);
+                *reinterpret_cast<float4*>(slab_v + o + db * 16) = make_float4(dvT[db][0], dvT[db][1], dvT[db][2], dvT[db][3]);
+            }
+        }
+        return;
+    }
     if (key < a.T) {
         uint16_t* ok = a.dk_cache + (((size_t)row * a.KVH + kvh) * a.Lmax + key) * HD + 4 * h;
         uint16_t* ov = a.dv_cache + (((size_t)row * a.KVH + kvh) * a.Lmax + key) * HD + 4 * h;
@@ -281,6 +301,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const umoe_attn_bwd_a
             *reinterpret_cast<uint2*>(ov + db * 16) = make_uint2((uint32_t)f2bf(dvT[db][0]) | ((uint32_t)f2bf(dvT[db][1]) << 16),
                                                                  (uint32_t)f2bf(dvT[db][2]) | ((uint32_t)f2bf(dvT[db][3]) << 16));
         }
+    }
+}
+
+// dK / dV = sum of the P head-split slabs, parts in ascending order, one rounding to bf16; 8 elements per thread
+__global__ __launch_bounds__(256) void attn_bwd_dkv_sum_kernel(const umoe_attn_bwd_args a, const int P, const float* __restrict__ slab_k,
+                                                               const float* __restrict__ slab_v) {
+    constexpr int HD = 128;
+    const size_t per = (size_t)a.rows * a.KVH * a.T * HD;        // elements of one slab
+    const size_t i8 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i8 >= per) return;
+    const size_t rk = i8 / HD;                                   // (row * KVH + kvh) * T + key
+    const size_t rowkv = rk / a.T, key = rk - rowkv * a.T;
+    const size_t o = (rowkv * a.Lmax + key) * HD + (i8 & (HD - 1));
+    for (int which = 0; which < 2; ++which) {
+        const float* sl = which ? slab_v : slab_k;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float4 x = *reinterpret_cast<const float4*>(sl + (size_t)p * per + i8);
+            const float4 y = *reinterpret_cast<const float4*>(sl + (size_t)p * per + i8 + 4);
+            acc[0] += x.x; acc[1] += x.y; acc[2] += x.z; acc[3] += x.w;
+            acc[4] += y.x; acc[5] += y.y; acc[6] += y.z; acc[7] += y.w;
+        }
+        *reinterpret_cast<uint4*>((which ? a.dv_cache : a.dk_cache) + o) = pack8(acc);
     }
 }
 
@@ -319,12 +364,43 @@ int umoe_attn_bwd_fused(const umoe_attn_bwd_args* a, umoe_stream_t stream) {
     else if (G <= 4) rc = launch_dq<4>(a, kvs, D, s);
     else rc = launch_dq<8>(a, kvs, D, s);
     if (rc) return rc;
-    static bool dkv_configured = false;
-    if (!dkv_configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 16384 + 512)));
-        dkv_configured = true;
+    // head split of the dK / dV pass: as many parts as divide the group (up to 4) and fit the workspace behind D and kv_start
+    static int psplit = -1;
+    if (psplit < 0) {
+        const char* e = getenv("UMOE_ATTN_BWD_SPLIT");
+        psplit = e ? atoi(e) : 4;
     }
-    attn_bwd_dkv_kernel<<<dim3((unsigned)ceil_div(a->T, 64), (unsigned)a->KVH, (unsigned)a->rows), 256, 2 * (2 * 16384 + 512), s>>>(*a, kvs, D);
+    int P = 1;
+    const size_t base = ((nD * 4 + 255) & ~(size_t)255) + (((size_t)a->rows * 4 + 255) & ~(size_t)255);
+    const size_t per = (size_t)a->rows * a->KVH * a->T * 128;
+    for (int cand = 4; cand >= 2; cand >>= 1)
+        if (cand <= psplit && G % cand == 0 && a->ws_bytes >= base + 2 * (size_t)cand * per * 4 && (size_t)a->KVH * cand <= 65535) { P = cand; break; }
+    float* slab_k = reinterpret_cast<float*>(reinterpret_cast<char*>(a->ws) + base);
+    float* slab_v = slab_k + (size_t)P * per;
+    static int key_waves = -1;
+    if (key_waves < 0) {
+        const char* e = getenv("UMOE_ATTN_BWD_KEYWAVES");
+        key_waves = e ? atoi(e) : 8;
+    }
+    constexpr int LDS = 2 * (2 * 16384 + 512);
+    static bool cfg4 = false, cfg8 = false;
+    if (key_waves == 8 && a->T > 64) {     // 128-key tiles
+        if (!cfg8) {
+            UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            cfg8 = true;
+        }
+        attn_bwd_dkv_kernel<8><<<dim3((unsigned)ceil_div(a->T, 128), (unsigned)(a->KVH * P), (unsigned)a->rows), 512, LDS, s>>>(*a, kvs, D, P, slab_k, slab_v);
+    } else {
+        if (!cfg4) {
+            UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            cfg4 = true;
+        }
+        attn_bwd_dkv_kernel<4><<<dim3((unsigned)ceil_div(a->T, 64), (unsigned)(a->KVH * P), (unsigned)a->rows), 256, LDS, s>>>(*a, kvs, D, P, slab_k, slab_v);
+    }
     UMOE_LAUNCH_CHECK();
+    if (P > 1) {
+        attn_bwd_dkv_sum_kernel<<<dim3((unsigned)((per / 8 + 255) / 256)), 256, 0, s>>>(*a, P, slab_k, slab_v);
+        UMOE_LAUNCH_CHECK();
+    }
     return 0;
 }

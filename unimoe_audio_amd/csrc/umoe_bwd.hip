@@ -857,7 +857,12 @@ extern "C" size_t umoe_attn_prefill_bwd_workspace_bytes(const umoe_attn_bwd_args
     if (!a || a->KVH <= 0) return 0;
     float* f;
     uint16_t *p1, *p2, *p3, *p4, *p5, *p6, *p7, *p8;
-    return attn_bwd_carve(a, nullptr, 0, &f, &p1, &p2, &p3, &p4, &p5, &p6, &p7, &p8);
+    const size_t unfused = attn_bwd_carve(a, nullptr, 0, &f, &p1, &p2, &p3, &p4, &p5, &p6, &p7, &p8);
+    // fused path: D [rows*T*H] fp32, kv_start [rows], then up to 4 head-split slabs of dK and dV in fp32 (umoe_attn_bwd.hip)
+    const size_t nD = (size_t)a->rows * a->T * a->H;
+    const size_t fused = ((nD * 4 + 255) & ~(size_t)255) + (((size_t)a->rows * 4 + 255) & ~(size_t)255) +
+                         2 * 4 * (size_t)a->rows * a->KVH * a->T * 128 * 4 + 256;
+    return unfused > fused ? unfused : fused;
 }
 
 // Backward of causal GQA attention over full sequences (one query per key position, left padding via kv_start):
