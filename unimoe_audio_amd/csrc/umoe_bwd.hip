@@ -9,14 +9,10 @@
 // ------------------------------------------------------------------------------------ transposes
 // dst[c][off_g + r] = src[row(off_g + r)][c] for r < cnt_g, 0 for cnt_g <= r < roundup8(cnt_g); row(s) = rows ? rows[s] : s.
 // grid = (slot tiles of 64, column tiles of 64, groups).  counts == NULL: one group of `static_rows` rows at offset 0.
-__global__ __launch_bounds__(256) void transpose_slots_kernel(const uint16_t* __restrict__ src, int ld_src, int C,
-                                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ counts,
-                                                              const int32_t* __restrict__ offsets, int static_rows,
-                                                              uint16_t* __restrict__ dst, int ld_dst) {
+__device__ __forceinline__ void transpose_tile(const uint16_t* __restrict__ src, const int ld_src, const int C,
+                                               const int32_t* __restrict__ rows, const int cnt, const int off,
+                                               uint16_t* __restrict__ dst, const int ld_dst) {
     __shared__ uint16_t tile[64][72];   // [slot][col], 144-byte rows: 16-byte aligned chunks, bank spread
-    const int g = blockIdx.z;
-    const int cnt = counts ? counts[g] : static_rows;
-    const int off = offsets ? offsets[g] : 0;
     const int pad = (cnt + 7) & ~7;
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     if (r0 >= pad) return;
@@ -55,6 +51,30 @@ __global__ __launch_bounds__(256) void transpose_slots_kernel(const uint16_t* __
                                    (uint32_t)t[4] | ((uint32_t)t[5] << 16), (uint32_t)t[6] | ((uint32_t)t[7] << 16));
         st16(dst + (size_t)(c0 + c) * ld_dst + off + r0 + sc * 8, v);
     }
+}
+
+__global__ __launch_bounds__(256) void transpose_slots_kernel(const uint16_t* __restrict__ src, int ld_src, int C,
+                                                              const int32_t* __restrict__ rows, const int32_t* __restrict__ counts,
+                                                              const int32_t* __restrict__ offsets, int static_rows,
+                                                              uint16_t* __restrict__ dst, int ld_dst) {
+    const int g = blockIdx.z;
+    transpose_tile(src, ld_src, C, rows, counts ? counts[g] : static_rows, offsets ? offsets[g] : 0, dst, ld_dst);
+}
+
+// the same plain transpose [R][C] -> [C][r8(R)] of up to 12 separate matrices of one shape in ONE launch (the per-expert weight
+// copies of the backward composites: 30 launches of ~10 us each per layer became 5)
+struct trans_ptrs { const uint16_t* src[12]; uint16_t* dst[12]; };
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const trans_ptrs p, int ld_src, int C, int R, int ld_dst) {
+    transpose_tile(p.src[blockIdx.z], ld_src, C, nullptr, R, 0, p.dst[blockIdx.z], ld_dst);
+}
+static int transpose_multi(const uint16_t* const* src, uint16_t* const* dst, int n, int ld_src, int C, int R, int ld_dst, umoe_stream_t stream) {
+    UMOE_REQUIRE(n >= 1 && n <= 12 && (ld_dst & 7) == 0, "transpose_multi: 1..12 matrices, ld_dst %% 8");
+    trans_ptrs p{};
+    for (int i = 0; i < n; ++i) { p.src[i] = src[i]; p.dst[i] = dst[i]; }
+    dim3 grid((unsigned)ceil_div(((R + 7) & ~7), 64), (unsigned)ceil_div(C, 64), (unsigned)n);
+    transpose_multi_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, ld_src, C, R, ld_dst);
+    UMOE_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int umoe_transpose_slots(const uint16_t* src, int ld_src, int C, const int32_t* rows, const int32_t* counts,
@@ -736,11 +756,18 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     const int G = a->num_groups, D = a->D, I = a->I, S = a->max_rows;
     int rc;
     // transposed weight copies: Wd^T [I][r8(D)], (Wg^T | Wu^T) [D][2I]
-    for (int g = 0; g < G; ++g) {
-        if ((rc = umoe_transpose_slots(a->w_down[g], I, I, nullptr, nullptr, nullptr, 1, D, wdT + (size_t)g * I * r8(D), r8(D), stream))) return rc;
-        uint16_t* t = wguT + (size_t)g * D * 2 * I;
-        if ((rc = umoe_transpose_slots(a->w_gate[g], D, D, nullptr, nullptr, nullptr, 1, I, t, 2 * I, stream))) return rc;
-        if ((rc = umoe_transpose_slots(a->w_up[g], D, D, nullptr, nullptr, nullptr, 1, I, t + I, 2 * I, stream))) return rc;
+    {
+        uint16_t* d1[12];
+        uint16_t* d2[12];
+        uint16_t* d3[12];
+        for (int g = 0; g < G; ++g) {
+            d1[g] = wdT + (size_t)g * I * r8(D);
+            d2[g] = wguT + (size_t)g * D * 2 * I;
+            d3[g] = d2[g] + I;
+        }
+        if ((rc = transpose_multi(a->w_down, d1, G, I, I, D, r8(D), stream))) return rc;      // Wd [D][I] -> [I][r8(D)]
+        if ((rc = transpose_multi(a->w_gate, d2, G, D, D, I, 2 * I, stream))) return rc;      // Wg [I][D] -> [D][2I] left half
+        if ((rc = transpose_multi(a->w_up, d3, G, D, D, I, 2 * I, stream))) return rc;        // Wu        -> right half
     }
     umoe_tgroup_t tg[12];
     auto rows_of = [&](umoe_tgroup_t& t, int g) {
