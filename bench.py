@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--parallel", default="auto", choices=["auto", "ep", "replica"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     return ap.parse_args()
 
 
@@ -208,10 +208,10 @@ def cpu_baseline(args):
             pred = OD.sample_next_token(guided.reshape(B * cfg.codec_channels, -1), 1.2, 0.95, 45, cfg.codec_eos_value)
             tok = pred.view(B, 1, cfg.codec_channels)
             times.append(time.perf_counter() - t0)
-    steady = times[1:]                                   # first step = warm-up
-    sec = sum(steady) / len(steady)
+    steady = sorted(times[1:])                           # first step = warm-up
+    sec = steady[len(steady) // 2]                       # median
     return {"value": round(B / sec, 3), "unit": "audio-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(steady)} decode steps (after 1 warm-up) of the full {cfg.num_hidden_layers}-layer model, batch {B} "
+            "sample": f"median of {len(steady)} decode steps (after 1 warm-up) of the full {cfg.num_hidden_layers}-layer model, batch {B} "
                       f"(16 CFG rows), synthetic KV cache of {L} tokens, torch-CPU bf16 oracle (oracle/decode.py), "
                       f"{sec * 1e3:.0f} ms/step"}
 
