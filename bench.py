@@ -140,7 +140,7 @@ def roofline(info):
             "traffic": traffic, "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(ms * 1e3, 2),
             "launches_per_step": n, "experts_hit_per_layer": round(U, 2),
             "note": "achieved = algorithmic bytes / HIP-event interval on the launch stream (eager profiling pass right after the "
-                    "timed region; the interval includes the launch gap, rocprofv3 durations are in profiles/r01f_decode_kernels.md); "
+                    "timed region; the interval includes the launch gap, rocprofv3 durations are in profiles/r01h_decode_kernels.md); "
                     "traffic = FETCH_SIZE*2 + WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r01f_pmc_traffic.md)"}
 
 
