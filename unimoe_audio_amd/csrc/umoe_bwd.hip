@@ -477,12 +477,27 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const uint16_t* __rest
     }
 }
 
+// column sums of the per-workgroup partial rows: 64 columns per workgroup, wave w adds the parts p = w (mod 4) on four
+// independent chains (16 loads in flight per column instead of one dependent load per part: 111 -> ~10 us at 512 parts),
+// fixed association: ((chain sums of wave 0) + wave 1) + wave 2) + wave 3
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ part, int n_part, int D, uint16_t* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
-    float acc = 0.f;
-    for (int p = 0; p < n_part; ++p) acc += part[(size_t)p * D + c];
-    out[c] = f2bf(acc);
+    __shared__ float sh[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < D) {
+        int p = wave;
+        for (; p + 12 < n_part; p += 16) {
+            a0 += part[(size_t)p * D + c];
+            a1 += part[(size_t)(p + 4) * D + c];
+            a2 += part[(size_t)(p + 8) * D + c];
+            a3 += part[(size_t)(p + 12) * D + c];
+        }
+        for (; p < n_part; p += 4) a0 += part[(size_t)p * D + c];
+    }
+    sh[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && c < D) out[c] = f2bf(((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]);
 }
 
 extern "C" int umoe_rmsnorm_residual_bwd(const uint16_t* h, const uint16_t* w, const uint16_t* dy, const uint16_t* dsum, float eps,
@@ -496,7 +511,7 @@ extern "C" int umoe_rmsnorm_residual_bwd(const uint16_t* h, const uint16_t* w, c
     UMOE_REQUIRE(ws_floats >= (size_t)used * D, "umoe_rmsnorm_residual_bwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)used * D);
     rmsnorm_bwd_kernel<<<dim3((unsigned)used), 256, 0, (hipStream_t)stream>>>(h, w, dy, dsum, eps, S, D, rpw, dh, ws);
     UMOE_LAUNCH_CHECK();
-    colsum_kernel<<<dim3((unsigned)ceil_div(D, 256)), 256, 0, (hipStream_t)stream>>>(ws, used, D, dw);
+    colsum_kernel<<<dim3((unsigned)ceil_div(D, 64)), 256, 0, (hipStream_t)stream>>>(ws, used, D, dw);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
