@@ -291,3 +291,26 @@ def test_training_step_vs_autograd_oracle(dev):
     routed = sorted(e[0] for e in worst if discrete(e[1]))
     assert dense[0][0] < 0.10 and dense[len(dense) // 2][0] < 0.04, dense[:6]
     assert routed[len(routed) // 2] < 0.06 and routed[-1] < 0.30, routed[-6:]
+
+
+def test_checkpoint_round_trip_generates_identical_codes(dev, tmp_path):
+    """unimoe_audio_amd.checkpoint: HF-style shards (reference key spelling, index json) -> from_pretrained straight onto the
+    device -> the same codes, bit for bit, as the model the checkpoint was written from (same kernels, same weights)."""
+    from unimoe_audio_amd import checkpoint as CK
+    from unimoe_audio_amd.codec_utils import DecoderOutput, prepare_audio_prompt
+    from unimoe_audio_amd.model import UniAudioRVQQwen2_5VLMoEForConditionalGeneration as Model
+    cfg = small_cfg()
+    m, w = build(cfg, 21, 0.08)
+    d = str(tmp_path / "ckpt")
+    CK.save_checkpoint(w, d, max_shard_bytes=400_000)
+    B, T, max_tokens = 2, 10, 24
+    ids, am, codec = prompt(cfg, B, T, 9, [1, 0, 0, 0])
+    pre, psteps = prepare_audio_prompt(cfg, [None] * B)
+    outs = []
+    for model in (m.to(dev), Model.from_pretrained(d, torch_dtype=torch.bfloat16, attn_implementation="sdpa", device=dev, config=small_cfg())):
+        assert next(model.parameters()).device.type == "cuda" and next(model.parameters()).dtype == torch.bfloat16
+        dec = DecoderOutput(pre.clone(), psteps, dev)
+        codes, lengths = model.generate(ids, am, dec, max_tokens, 5, codec_input_ids=codec, cfg_scale=2.0, do_sample=True,
+                                        temperature=1.1, top_p=0.9, eos_prob_mul_factor=0.8, seed=5)
+        outs.append((codes.cpu(), lengths.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

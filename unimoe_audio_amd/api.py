@@ -51,23 +51,8 @@ class UniMoEAudio:
 
     # ---- third-party assets ---------------------------------------------------------------------------------------
     def _load_weights(self, model_path):
-        import glob
-        from safetensors import safe_open
-        shards = sorted(glob.glob(os.path.join(model_path or "", "*.safetensors")))
-        if not shards:
-            raise FileNotFoundError(f"no *.safetensors under {model_path!r} (the reference downloads them from the HF hub)")
-        sd = {}
-        for sh in shards:
-            with safe_open(sh, framework="pt") as f:
-                for k in f.keys():
-                    kk = k
-                    if kk.startswith("model.") and not kk.startswith("model.language_model"):   # model.py:464-467
-                        kk = "language_model." + kk[len("model."):]
-                    sd[kk] = f.get_tensor(k)
-        missing, unexpected = self.model.load_state_dict(sd, strict=False)
-        hot = [m for m in missing if "visual" not in m and "lm_head" not in m]
-        if hot:
-            raise KeyError(f"checkpoint lacks hot-path tensors, e.g. {hot[:4]}")
+        from . import checkpoint
+        checkpoint.load_checkpoint(self.model, model_path or "")      # HF shards (+ index), reference key spelling, streamed
 
     @property
     def tokenizer(self):

@@ -112,6 +112,14 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
     def device(self):
         return next(self.parameters()).device
 
+    @classmethod
+    def from_pretrained(cls, local_dir: str, torch_dtype=torch.bfloat16, attn_implementation: Optional[str] = None, device=None,
+                        ep_rank: int = 0, ep_size: int = 1, config=None):
+        """Reference signature (utils/UniMoE_Audio_mod.py:79-92) for local checkpoint directories; see checkpoint.py."""
+        from . import checkpoint
+        return checkpoint.from_pretrained(cls, local_dir, torch_dtype=torch_dtype, attn_implementation=attn_implementation,
+                                          device=device, ep_rank=ep_rank, ep_size=ep_size, config=config)
+
     @torch.no_grad()
     def init_synthetic(self, seed: int = 1234, std: Optional[float] = None):
         """N(0, initializer_range^2) Linear/Embedding weights, unit RMSNorm, zero biases; seed + layer index per
