@@ -239,6 +239,39 @@ if "flat" in which:
             t = timeit(lambda i: ops.grouped_gemm(tabs[i % R], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=nt, waves=8))
             print("dense down order", name, "nt", nt, f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)
 
+if "ragged" in which:
+    # in-situ shape of the routed experts' gate/up at training size: 6240 tokens, ~3.55 of 8 experts per token
+    M = 6240
+    xa = rnd(M, D) * 50
+    mask = (torch.rand(M, 11, device=dev) < 3.55 / 8).to(torch.int32)
+    disp = ops.dispatch_build(mask, 8)
+    slots = int(disp["offsets"][8].item())
+    wgs, wus = [rnd(Id, D) for _ in range(8)], [rnd(Id, D) for _ in range(8)]
+    hb = torch.empty(slots + 64, Id, device=dev, dtype=torch.bfloat16)
+    aux = torch.empty(slots + 64, 2 * Id, device=dev, dtype=torch.bfloat16)
+    fl = 4 * slots * Id * D
+    g_r = [dict(w=wgs[e], w2=wus[e], rows=disp["slot_token"], row_off=disp["offsets"][e:e + 1], count=disp["counts"][e:e + 1]) for e in range(8)]
+    t = timeit(lambda i: ops.tiled_gemm(g_r, xa, hb, max_rows=M, epilogue=ops.EPI_SWIGLU), iters=20)
+    print(f"ragged gate/up 8 experts, {slots} slots, gather list: {t:.1f} us  {fl/t/1e6:.0f} TFLOP/s", flush=True)
+    t = timeit(lambda i: ops.tiled_gemm(g_r, xa, hb, max_rows=M, epilogue=ops.EPI_SWIGLU, aux_out=aux), iters=20)
+    print(f"  + pre-activation outputs (training forward): {t:.1f} us  {fl/t/1e6:.0f} TFLOP/s", flush=True)
+    sets = []
+    for r in range(3):       # 3 x 180 MB of expert weights: more than the 256 MiB Infinity Cache -> every launch streams from HBM
+        wg2, wu2 = [rnd(Id, D) for _ in range(8)], [rnd(Id, D) for _ in range(8)]
+        sets.append([dict(w=wg2[e], w2=wu2[e], rows=disp["slot_token"], row_off=disp["offsets"][e:e + 1], count=disp["counts"][e:e + 1]) for e in range(8)])
+    t = timeit(lambda i: ops.tiled_gemm(sets[i % 3], xa, hb, max_rows=M, epilogue=ops.EPI_SWIGLU, aux_out=aux), iters=21)
+    print(f"  + weights rotating over 3 sets (cold, as inside the layer loop): {t:.1f} us  {fl/t/1e6:.0f} TFLOP/s", flush=True)
+    t = timeit(lambda i: ops.tiled_gemm(sets[i % 3], xa, hb, max_rows=M, epilogue=ops.EPI_SWIGLU, aux_out=aux), iters=1500, warm=300)
+    print(f"  the same, 1500 launches back to back (~1 s of sustained MFMA load: clocks): {t:.1f} us  {fl/t/1e6:.0f} TFLOP/s", flush=True)
+    xs = torch.empty(slots + 64, D, device=dev, dtype=torch.bfloat16).normal_()
+    g_c = [dict(w=wgs[e], w2=wus[e], row_off=disp["offsets"][e:e + 1], count=disp["counts"][e:e + 1]) for e in range(8)]
+    t = timeit(lambda i: ops.tiled_gemm(g_c, xs, hb, max_rows=M, epilogue=ops.EPI_SWIGLU), iters=20)
+    print(f"  contiguous slot rows instead of the gather list: {t:.1f} us  {fl/t/1e6:.0f} TFLOP/s", flush=True)
+    per = slots // 8
+    g_s = [dict(w=wgs[e], w2=wus[e], static_count=per, a_row_base=e * per, out_row_base=e * per) for e in range(8)]
+    t = timeit(lambda i: ops.tiled_gemm(g_s, xs, hb, max_rows=per, epilogue=ops.EPI_SWIGLU), iters=20)
+    print(f"  static groups of {per} rows (tight grid, contiguous XCD ranges): {t:.1f} us  {4*8*per*Id*D/t/1e6:.0f} TFLOP/s", flush=True)
+
 if "router" in which:
     gw = rnd(11, D)
     nw = torch.ones(D, device=dev, dtype=torch.bfloat16)

@@ -423,13 +423,14 @@ __device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const 
 //   WAR: W(v+3) overwrites W(v-1), last read in phase 2v-2; tokens(v+3) overwrite tokens(v-1), last read in phase 2v-1: two
 //        phases earlier, i.e. also the lagging group has retired those reads (lgkmcnt) before any wave issues the DMA.
 //   Tiles beyond K are staged from the zero block, so the vmcnt arithmetic is the same in every iteration.
-template <int EPI, int PRIO>
+template <int EPI, int PRIO, int NS>
 __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args p, const tg_pack gp, const int epi_lds_mask, const int nx, const int ny, const int nz, const int ragged_order) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef UMOE_PP_STAMPS
     const unsigned long long t_entry = clock64(), w_entry = wall_clock64();
 #endif
     constexpr int UNIT = 256 * 64, SLOT = 2 * UNIT;
+    constexpr int AH = NS - 1;                 // the DMA runs AH tiles ahead (NS ring slots: 4 = 128 KiB, 5 = all 160 KiB of the CU)
     constexpr bool SW = EPI == UMOE_EPI_SWIGLU;
     constexpr int NTILE = SW ? 128 : 256;
     // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by linear id (1-D launch), so the workgroups with
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     auto stage = [&](const long (&del)[2], const int unit_off, const int tile) {
         const int k0 = tile * 32;
         const long live = (k0 + gch * 8 < K) ? -1L : 0L;      // K tail and the tiles staged past the end read zeros
-        char* base = smem + (tile & 3) * SLOT + unit_off;
+        char* base = smem + (tile % NS) * SLOT + unit_off;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const long d = del[q] == 0 ? 0 : ((del[q] + 2L * k0) & live);
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     for (int q = 0; q < 2; ++q) {
         tinc[q] = tdel[q] ? 64 : 0;
         winc[q] = wdel[q] ? 64 : 0;
-        tptr[q] = zero + tdel[q] + 3 * tinc[q];      // the prologue stages tiles 0..2
-        wptr[q] = zero + wdel[q] + 3 * winc[q];
+        tptr[q] = zero + tdel[q] + AH * tinc[q];     // the prologue stages tiles 0..AH-1
+        wptr[q] = zero + wdel[q] + AH * winc[q];
     }
     auto stage_run = [&](const char* (&ptr)[2], const long (&inc)[2], const int unit_off, const int slot_off) {
         char* base = smem + slot_off + unit_off;
@@ -552,13 +553,13 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     auto wfo = [](int j) { return SW ? ((j & 1) * 1024 + (j >> 1) * 8192) : j * 1024; };
 
     const int KT = (K + 31) >> 5;
-    // prologue: tiles 0..2 in flight, tile 0 landed and visible
+    // prologue: tiles 0..AH-1 in flight, tile 0 landed and visible
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < AH; ++u) {
         stage(wdel, 0, u);
         stage(tdel, UNIT, u);
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind group 0 from here on
     if (PRIO == 2 && wr == 1) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half (it loses every arbitration by age)
@@ -573,8 +574,8 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
 #endif
     auto tile_step = [&](const int v, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const int so = (v & 3) * SLOT;               // ring slot of tile v (read); tile v + 3 goes to slot (v + 3) & 3
-        const int sn = ((v + 3) & 3) * SLOT;
+        const int so = (v % NS) * SLOT;              // ring slot of tile v (read); tile v + AH goes to slot (v + AH) % NS
+        const int sn = ((v + AH) % NS) * SLOT;
         const char* Wb = smem + so + wbase;
         const char* Tb = smem + so + tbase;
         bf16x8_t wf[4], af[4];
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + i * 1024));
         if (STEADY) stage_run(wptr, winc, 0, sn);
-        else stage(wdel, 0, v + 3);
+        else stage(wdel, 0, v + AH);
         PP_ST(1);
         __builtin_amdgcn_s_barrier();
         PP_ST(2);
@@ -602,9 +603,9 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + (4 + i) * 1024));
         if (STEADY) stage_run(tptr, tinc, UNIT, sn);
-        else stage(tdel, UNIT, v + 3);
+        else stage(tdel, UNIT, v + AH);
         PP_ST(5);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");    // all but the AH - 1 newest tiles have landed: tile v + 1 is in
         PP_ST(6);
         __builtin_amdgcn_s_barrier();
         PP_ST(7);
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     };
     // tiles v + 3 <= KT - 2 lie entirely inside K (only the last tile can hold the K tail): running pointers; the last four
     // iterations stage the tail tile and the zero tiles with the arithmetic addresses
-    const int v_steady = KT - 4 > 0 ? KT - 4 : 0;
+    const int v_steady = KT - (AH + 1) > 0 ? KT - (AH + 1) : 0;
     int v = 0;
     for (; v < v_steady; ++v) tile_step(v, std::true_type{});
     for (; v < KT; ++v) tile_step(v, std::false_type{});
@@ -655,15 +656,15 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     tg_epilogue<EPI, 8>(p, g, acc, count, roff, row0 + 128 * wr, fbase, lane);
 }
 
-template <int EPI, int PRIO>
+template <int EPI, int PRIO, int NS>
 static int launch_tgemm_pp_v(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
     tg_pack gp;
     memset(&gp, 0, sizeof(gp));
     memcpy(gp.g, a->groups, sizeof(umoe_tgroup_t) * a->num_groups);
-    constexpr int lds = 4 * 2 * 256 * 64;
+    constexpr int lds = NS * 2 * 256 * 64;
     static bool configured = false;
     if (!configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_pp_kernel<EPI, PRIO>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_pp_kernel<EPI, PRIO, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
     const int ntile = EPI == UMOE_EPI_SWIGLU ? 128 : 256;
@@ -680,7 +681,7 @@ static int launch_tgemm_pp_v(const umoe_tgemm_args* a, int max_n, hipStream_t s)
         const char* v = getenv("UMOE_TGEMM_EPI_LDS");
         mask = v ? atoi(v) : 6;
     }
-    tgemm_pp_kernel<EPI, PRIO><<<grid, 512, lds, s>>>(*a, gp, mask, nx, ny, nz, ragged);
+    tgemm_pp_kernel<EPI, PRIO, NS><<<grid, 512, lds, s>>>(*a, gp, mask, nx, ny, nz, ragged);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -725,14 +726,17 @@ static int tgemm_tm(const umoe_tgemm_args* a) {
 
 template <int EPI>
 static int launch_tgemm_pp(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
-    static int prio = -1;
+    static int prio = -1, ring = -1;
     if (prio < 0) {
         const char* v = getenv("UMOE_TGEMM_PRIO");
         prio = v ? atoi(v) : 1;
+        const char* r = getenv("UMOE_TGEMM_RING");
+        ring = r ? atoi(r) : 4;
     }
-    if (prio == 0) return launch_tgemm_pp_v<EPI, 0>(a, max_n, s);
-    if (prio == 2) return launch_tgemm_pp_v<EPI, 2>(a, max_n, s);
-    return launch_tgemm_pp_v<EPI, 1>(a, max_n, s);
+    if (prio == 0) return launch_tgemm_pp_v<EPI, 0, 4>(a, max_n, s);
+    if (prio == 2) return launch_tgemm_pp_v<EPI, 2, 4>(a, max_n, s);
+    if (ring == 4) return launch_tgemm_pp_v<EPI, 1, 4>(a, max_n, s);
+    return launch_tgemm_pp_v<EPI, 1, 5>(a, max_n, s);
 }
 
 // 256 x 256 ping-pong tiles once they fill the chip (one workgroup per CU)
