@@ -2,7 +2,12 @@
 //
 //   Y[rows(g), N] = epilogue( A[rows(g), K] * W_g^T ),  W_g row-major [N][K] bf16
 //
-// Design (MI355X / gfx950):
+// Two kernels behind umoe_tiled_gemm (same arguments, same results up to fp32 summation order):
+//  * tgemm_pp_kernel (further down): 256 x 256 tiles, 8 waves in two groups running one barrier apart ("ping-pong"), chosen for
+//    launches of >= 1024 rows that fill the chip with such tiles -- 0.85-1.0 PFLOP/s at the prefill / training shapes;
+//  * tgemm_kernel: the small-tile kernel described next, for everything else (few rows, 64-80-tile weight gradients).
+//
+// Small-tile design (MI355X / gfx950):
 //  * one 256-thread workgroup per 128 x 128 output tile, 4 waves as 2 (rows) x 2 (columns), each wave a 64 x 64 sub-tile
 //    = 4 x 4 v_mfma_f32_16x16x32_bf16 accumulators (64 registers);
 //  * tiles are staged by LDS-DMA (global_load_lds_dwordx4: no data registers, no ds_write pass; the swizzle sits on the
@@ -10,8 +15,8 @@
 //    DMA of tile t+2 in flight across the barrier (counted vmcnt + raw s_barrier); fewer rows: 128-token tiles, K steps of 64,
 //    two stages; register staging kept as a variant;
 //  * LDS image: 128-byte rows (64 bf16), 16-byte chunk c of row r at r*128 + ((c ^ ((r >> 1) & 7)) * 16): the global loads
-//    and the LDS writes are contiguous per row (8 lanes x 16 B), the ds_read_b128 operand reads (16 rows x one chunk)
-//    touch every bank once;
+//    and the LDS writes are contiguous per row (8 lanes x 16 B), the ds_read_b128 operand reads touch every bank once
+//    (64-byte rows of the K-32 variants: see tg_swz);
 //  * weights are the MFMA A operand, activations the B operand (as in umoe_gemm.hip): a lane ends with 4 consecutive
 //    output features of one token -> 8-byte bf16 stores;
 //  * ragged groups: gather list / row count / row offset are read on device, workgroups beyond the count exit.
@@ -414,8 +419,9 @@ __device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const 
 // accumulators (128 registers).  Each SIMD carries one wave of each group; the groups run ONE BARRIER APART, so while group 0
 // issues its 16 MFMAs group 1 reads its operands / issues the next LDS-DMA, and vice versa -- the matrix pipe of every SIMD
 // always has a wave in its MFMA segment (MI355X_MICROARCH.md, LDS section: one wave per SIMD cannot hide its own ds_reads).
-//   K runs in tiles of 32 (one MFMA k-step); LDS = ring of 4 tiles x [W unit 256 rows x 64 B | token unit 256 rows x 64 B] =
-//   128 KiB; a unit is staged by all 8 waves (2 global_load_lds_dwordx4 each) and the DMA runs THREE tiles ahead.
+//   K runs in tiles of 32 (one MFMA k-step); LDS = ring of NS = 4 tiles x [W unit 256 rows x 64 B | token unit 256 rows x 64 B] =
+//   128 KiB; a unit is staged by all 8 waves (2 global_load_lds_dwordx4 each) and the DMA runs NS - 1 = THREE tiles ahead
+//   (the comments below use NS = 4; NS = 5 is the measured-slower experiment UMOE_TGEMM_RING=5).
 //   phase 2v   : L: read W(v) (4 fragments) + tokens(v) first half (4); stage W(v+3)         | barrier | M: 16 MFMA | barrier
 //   phase 2v+1 : L: read tokens(v) second half (4); stage tokens(v+3); s_waitcnt vmcnt(8)    | barrier | M: 16 MFMA | barrier
 //   RAW: a wave's vmcnt(8) in phase 2v+1 retires ITS pieces of tile v+1 (the 8 newer DMAs are W/tokens of v+2, v+3); the reads
