@@ -47,3 +47,27 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "from oracle" not in src and "import oracle" not in src, f
                 assert "#include \"../../oracle" not in src and "router_oracle" not in src.replace("oracle/router_oracle.c", ""), f
+
+
+def test_no_mfma_is_predicated_through_exec(tmp_path):
+    """MFMA ignores EXEC: a guard around an MFMA must be a scalar (wave-uniform) branch.  Compile the MFMA kernels to assembly
+    and check that no v_mfma directly follows an s_and_saveexec (scripts/scan_mfma_exec.py; the hazard doubled the last k-step of
+    partial chunks in the weight-streaming GEMM before the slice bounds were pinned into SGPRs)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    from scan_mfma_exec import scan
+    csrc = os.path.join(root, "unimoe_audio_amd", "csrc")
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    procs = []
+    for f in ("umoe_gemm", "umoe_tgemm", "umoe_attn", "umoe_attn_bwd"):
+        out = str(tmp_path / (f + ".s"))
+        procs.append((f, out, subprocess.Popen([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+                                                "--offload-arch=gfx950", "-I" + os.path.join(root, "include"), "-I" + csrc, "--cuda-device-only", "-S",
+                                                os.path.join(csrc, f + ".hip"), "-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    for f, out, pr in procs:
+        assert pr.wait(timeout=600) == 0, f
+        n, bad = scan(out)
+        assert n > 0 and not bad, (f, bad[:3])

@@ -114,7 +114,12 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     const int ia = (KB * ks) / ksplit, ib = (KB * (ks + 1)) / ksplit;
     const int QS = (((ib - ia) * 16) + 255) & ~255;  // bytes of one staged K-quarter slice of a row, padded to 256
     const int RS = QS * 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform by construction: keep it (and the K split i0 / i1 derived from it) in SGPRs, so that every guard around an MFMA
+    // is a SCALAR branch.  With a per-lane condition hipcc may predicate a short block through EXEC without a skip branch, and
+    // MFMA ignores EXEC: the guarded MFMA of a partial chunk would then run on its clamped duplicate operands (seen in an
+    // experiment with register-resident activations: last k-step counted twice; tests/test_abi_cpu.py scans the assembly).
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- weight stream set-up: the first chunk is requested BEFORE anything that depends on device-produced data
     //      (row counts, gather lists, activations), so the HBM latency of the stream overlaps the whole prologue ----
@@ -129,6 +134,9 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
         i0 = ia + ((ib - ia) * wave) / WV;
         i1 = ia + ((ib - ia) * (wave + 1)) / WV;
     }
+    // (K may have come from a descriptor in memory: pin the wave-uniform slice bounds into SGPRs, see `wave` above)
+    i0 = __builtin_amdgcn_readfirstlane(i0);
+    i1 = __builtin_amdgcn_readfirstlane(i1);
     f32x4_t acc[NT];
     const u32x4_t* wp[NT];
 #pragma unroll
