@@ -73,6 +73,9 @@ typedef struct {
     float* routing_w;         /* [S][n_dyn] T-rounded values held in fp32 */
     float* global_w;          /* [S][E]     T-rounded values held in fp32 */
     float* moe_w;             /* [S][n_real] = global_w * mask */
+    int norm_only;            /* 1: only h_out = RMSNorm(x) with the router's own arithmetic (x, norm_w, h_out; S <= 256, D 2048 / 4096):
+                               * the launch the decode engine puts in front of the expert GEMM when the router itself rides inside
+                               * that GEMM's launch (umoe_gemm_args.fused_router) */
 } umoe_router_args;
 int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 
@@ -156,6 +159,9 @@ typedef struct {
                                * take equal slices of ALL groups' gate/up pairs (<= 7 each; per-CU byte balance) */
     int cache_policy;         /* reserved (0): the weight stream is always non-temporal -- a default-policy variant and an
                                * Infinity Cache warm-up were measured and bought nothing */
+    const umoe_router_args* fused_router; /* optional HOST pointer (SwiGLU, nt = 14, <= 16 rows, n_dyn 9 / n_fix 2, D 2048 / 4096, S <= 16):
+                               * the router of these tokens runs INSIDE this launch as S extra workgroups (its outputs are complete when
+                               * the launch is); the GEMM itself must not depend on them (dense-expert decode: h_out NULL, see norm_only) */
 } umoe_gemm_args;
 #define UMOE_GROUPS_INLINE 12
 

@@ -76,6 +76,7 @@ struct umoe_engine {
     // decode with >= 6 rows: every routed expert is hit with probability ~1, so each expert computes ALL rows (no gather
     // lists, no dispatch kernel, no device-produced row counts in the GEMM prologues) and the combine selects by mask
     bool dense_experts = true;
+    bool fuse_router = true;     // UMOE_FUSE_ROUTER: dense decode runs the router inside the gate/up launch (see run_layer)
     bool attn_single = false;    // UMOE_ATTN_SINGLE: decode attention merges its key splits in the same launch (umoe_attn_args.sync);
                                  // measured 3.644 vs 3.585 ms/step: ticket + coherent re-read cost more than the combine launch
     int flat_wgs = 0;            // UMOE_FLAT_WGS: workgroups of the flat gate/up launch; measured 42.4 us (256 slices of 6-7
@@ -244,6 +245,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (const char* v = getenv("UMOE_TILED_PREFILL")) e->tiled_prefill = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FLAT_WGS")) e->flat_wgs = atoi(v);
     if (const char* v = getenv("UMOE_ATTN_SINGLE")) e->attn_single = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_FUSE_ROUTER")) e->fuse_router = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -420,8 +422,21 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         ra.expert_mask = e->all_mask + (size_t)l * c.rows * E;
         ra.top_k = e->all_topk + (size_t)l * c.rows;
     }
-    if (dense) rc = umoe_router_fwd(&ra, s);   // no dispatch tables: the combine reads the mask
-    else rc = umoe_router_dispatch_fwd(&ra, e->counts, e->offsets, e->slot_token, e->slot_of, s);
+    // dense decode: the GEMMs do not read the routing results (every expert computes every row), only the combine does -- so the
+    // router rides INSIDE the gate/up launch as 16 extra workgroups and only the RMSNorm (h2, which gate/up needs) stays in the
+    // chain as its own small launch: the 4.4 us serial routing chain per token leaves the critical path.
+    const bool fuse_router = dense && e->fuse_router && !tiled && !(e->overlap_shared && c.n_fix > 0) && c.n_dyn == 9 && c.n_fix == 2 &&
+                             (D == 2048 || D == 4096) && n_tok <= 16 && !(e->flat_wgs > 0);
+    if (fuse_router) {
+        umoe_router_args rn = ra;
+        rn.norm_only = 1;
+        rc = umoe_router_fwd(&rn, s);
+        ra.h_out = nullptr;
+    } else if (dense) {
+        rc = umoe_router_fwd(&ra, s);   // no dispatch tables: the combine reads the mask
+    } else {
+        rc = umoe_router_dispatch_fwd(&ra, e->counts, e->offsets, e->slot_token, e->slot_of, s);
+    }
     if (rc) return rc;
     PROF(K_ROUTER);
     // 7./8. experts.  The shared experts need no routing: with `overlap_shared` they run on a second stream from the
@@ -435,6 +450,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     gu.prologue = UMOE_PRO_PLAIN; gu.epilogue = UMOE_EPI_SWIGLU;
     if (dense) {             // per-CU byte balance decides this kernel (see umoe_gemm.hip): 7 pairs per workgroup, flat slices
         gu.nt = 14;
+        if (fuse_router) gu.fused_router = &ra;
         if (e->flat_wgs > 0 && ceil_div((c.n_real * c.inter_dyn + c.n_fix * c.inter_shared) / 16, e->flat_wgs) <= 7) gu.flat_wgs = e->flat_wgs;
     }
     // (dense mode with the post-attention RMSNorm in this launch's staging prologue, so that it would not wait for the

@@ -18,6 +18,7 @@
 //    never synchronises on the router's result.
 // Roofline: HBM. Algorithmic bytes per launch = sum over groups hit of N*K*2 (+ activations).
 #include "umoe_common.h"
+#include "umoe_router_dev.h"
 #include <string.h>
 
 // ------------------------------------------------------------------------------------ packing
@@ -71,9 +72,24 @@ __device__ __forceinline__ int lds_chunk_off(int QS, int h, int i, int m) {
 
 struct umoe_group_pack { umoe_group_t g[UMOE_GROUPS_INLINE]; };
 
-template <int NT, int U, int PRO, int EPI, int WV>
-__global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp) {
+// FR ("fused router", umoe_gemm_args.fused_router): the z-slice in front of the first group holds one workgroup per token that runs the
+// Top-P router (threads 0..255; umoe_router_dev.h) instead of a GEMM tile -- 16 workgroups on CUs the 226 GEMM workgroups leave
+// idle.  The GEMM of the dense-expert decode layout does not read the router's outputs, the combine launch after it does.
+template <int NT, int U, int PRO, int EPI, int WV, bool FR = false>
+__global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_router_args ra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (FR) {
+        if (blockIdx.z == 0) {      // FIRST in dispatch order: the router's loads go out before the weight stream fills the memory queues
+                                    // (behind the last group the same workgroups took 4 us longer than the whole GEMM)
+            if (blockIdx.x < (unsigned)ra.S && blockIdx.y == 0 && threadIdx.x < 256) {
+                TL_ENTER(5);
+                if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, blockIdx.x, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
+                else router4_body<9, 2, 0, false>(ra, blockIdx.x, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
+                TL_EXIT(5);
+            }
+            return;
+        }
+    }
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     constexpr int KID = EPI == UMOE_EPI_SWIGLU ? 2 : (EPI == UMOE_EPI_F32 ? 4 : (EPI == UMOE_EPI_BF16_RESID ? 1 : (NT == 1 ? 0 : 3)));
     (void)KID;
@@ -83,7 +99,8 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     // p.flat_wgs equal slices of ALL groups' gate/up pairs, so every CU streams the same number of bytes whatever the
     // group sizes are (the per-CU byte balance decides this kernel, see the launcher).  A slice may straddle two groups.
     const bool flat = EPI == UMOE_EPI_SWIGLU && p.flat_wgs > 0;
-    const umoe_group_t g = p.groups_host ? gp.g[flat ? 0 : blockIdx.z] : p.groups[blockIdx.z];
+    const unsigned zg = blockIdx.z - (FR ? 1u : 0u);      // group index
+    const umoe_group_t g = p.groups_host ? gp.g[flat ? 0 : zg] : p.groups[zg];
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int ks = blockIdx.x % ksplit;      // K-slice of this workgroup (fp32 partial slab `ks`)
     const int nb0 = (blockIdx.x / ksplit) * NT;
@@ -416,14 +433,14 @@ static size_t gemm_lds_bytes(int max_k, int NT, int WV, int ksplit, int pro = UM
     return a > red ? a : red;
 }
 
-template <int NT, int U, int PRO, int EPI, int WV = 4>
+template <int NT, int U, int PRO, int EPI, int WV = 4, bool FR = false>
 static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
     const int ksplit = a->ksplit > 1 ? a->ksplit : 1;
     const size_t lds = gemm_lds_bytes(a->max_k, NT, WV, ksplit, PRO);
     UMOE_REQUIRE(lds <= 160 * 1024, "umoe_grouped_gemm: K=%d needs %zu bytes of LDS (> 160 KiB)", a->max_k, lds);
     static size_t configured = 0;  // per instantiation
     if (lds > configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, U, PRO, EPI, WV>),
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, U, PRO, EPI, WV, FR>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
@@ -437,7 +454,13 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
         b.groups_host = nullptr;
         memset(&gp, 0, sizeof(umoe_group_t));
     }
-    wstream_gemm<NT, U, PRO, EPI, WV><<<grid, WV * 64, lds, s>>>(b, gp);
+    umoe_router_args ra;
+    memset(&ra, 0, sizeof(ra));
+    if (FR) {
+        ra = *a->fused_router;
+        grid.z += 1;                 // the router's workgroups: x = token, z = 0 (in front of the first group)
+    }
+    wstream_gemm<NT, U, PRO, EPI, WV, FR><<<grid, WV * 64, lds, s>>>(b, gp, ra);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -484,6 +507,8 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
     UMOE_REQUIRE((a->lda & 7) == 0, "umoe_grouped_gemm: lda must be a multiple of 8 (16-byte rows)");
     UMOE_REQUIRE(a->ksplit <= 1 || (a->epilogue == UMOE_EPI_F32_RAW && a->prologue == UMOE_PRO_PLAIN && a->ksplit <= 4),
                  "umoe_grouped_gemm: ksplit > 1 needs the plain prologue and the raw fp32 partial-slab epilogue");
+    UMOE_REQUIRE(!a->fused_router || (a->epilogue == UMOE_EPI_SWIGLU && a->prologue == UMOE_PRO_PLAIN && a->nt == 14 && a->flat_wgs == 0),
+                 "umoe_grouped_gemm: fused_router rides only in the plain SwiGLU launch with nt = 14");
     hipStream_t s = (hipStream_t)stream;
     const int pro = a->prologue, epi = a->epilogue;
     if (pro == UMOE_PRO_RMSNORM) {
@@ -531,7 +556,17 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
             // 7 gate/up pairs per 8-wave workgroup: 226 workgroups for the dense decode shape = at most ONE per CU.  The
             // per-CU byte balance decides this kernel (scripts/kbench.py flat): NT 8 -> 387 workgroups, half of the CUs carry
             // two: 39.3 us; NT 12 -> 262 workgroups, six CUs carry two: 51.0 us; NT 14: 35.3-37.0 us; NT 16 (198 CUs): 43.0 us
-            if (nt == 14) return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s);
+            if (nt == 14) {
+                if (a->fused_router) {
+                    const umoe_router_args* r = a->fused_router;
+                    UMOE_REQUIRE(a->max_rows <= 16 && r->S <= ceil_div(a->max_n_blocks, 14) && r->n_dyn == 9 && r->n_fix == 2 &&
+                                     (r->D == 2048 || r->D == 4096) && r->x && r->gate_w && r->expert_mask && !r->logits_in && !r->norm_only,
+                                 "umoe_grouped_gemm: fused_router needs <= 16 rows, n_dyn 9 / n_fix 2, D 2048 / 4096, S <= %d workgroups of the launch",
+                                 ceil_div(a->max_n_blocks, 14));
+                    return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8, true>(a, s);
+                }
+                return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s);
+            }
             return use8(a, 8) ? launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s)
                                  : launch_gemm<8, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
         }
