@@ -128,20 +128,20 @@ def roofline(info):
     bytes_per_launch = (U * 2 * Id * D + cfg.mlp_fixed_expert_num * 2 * Is * D) * 2.0
     ms, n = info["prof"]["gateup"]
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    kname = "wstream_gemm<14, 1, 0, 2, 8>"
+    kname = "wstream_gemm<14, 1, 0, 2, 8, true>"
     traffic = None
     try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
-        with open(os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")) as f:
             traffic = json.load(f)["kernels"][kname]["traffic_bytes"]
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": kname + " (grouped gate/up SwiGLU, 8 routed + 2 shared experts in one launch)",
+    return {"bound": "hbm", "kernel": kname + " (grouped gate/up SwiGLU, 8 routed + 2 shared experts in one launch; the launch also carries the router's 16 workgroups)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(ms * 1e3, 2),
             "launches_per_step": n, "experts_hit_per_layer": round(U, 2),
             "note": "achieved = algorithmic bytes / HIP-event interval on the launch stream (eager profiling pass right after the "
                     "timed region; the interval includes the launch gap, rocprofv3 durations are in profiles/r01h_decode_kernels.md); "
-                    "traffic = FETCH_SIZE*2 + WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r01f_pmc_traffic.md)"}
+                    "traffic = FETCH_SIZE*2 + WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r01h_pmc_traffic.md)"}
 
 
 def cpu_baseline(args):
