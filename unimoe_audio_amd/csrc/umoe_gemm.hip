@@ -20,6 +20,7 @@
 #include "umoe_common.h"
 #include "umoe_router_dev.h"
 #include <string.h>
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ packing
 __global__ void pack_kernel(const uint16_t* __restrict__ Wa, const uint16_t* __restrict__ Wb, int N, int K, int KB,
@@ -76,15 +77,28 @@ struct umoe_group_pack { umoe_group_t g[UMOE_GROUPS_INLINE]; };
 // Top-P router (threads 0..255; umoe_router_dev.h) instead of a GEMM tile -- 16 workgroups on CUs the 226 GEMM workgroups leave
 // idle.  The GEMM of the dense-expert decode layout does not read the router's outputs, the combine launch after it does.
 template <int NT, int U, int PRO, int EPI, int WV, bool FR = false>
-__global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_router_args ra) {
+__global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_router_args ra, const int rider_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // riders (FR).  rider_mode 1: an extra z-slice in front of the first group (x = token); 2: the launch's DEAD workgroups (x beyond
+    // a short group's tiles -- the grid is a box over the widest group) take the tokens in (z, x) order: no extra workgroups, the
+    // launch still fits the chip in one wave (with the extra slice 275 workgroups were launched on 256 CUs and 7 real GEMM tiles
+    // waited for a CU).
     if constexpr (FR) {
-        if (blockIdx.z == 0) {      // FIRST in dispatch order: the router's loads go out before the weight stream fills the memory queues
-                                    // (behind the last group the same workgroups took 4 us longer than the whole GEMM)
-            if (blockIdx.x < (unsigned)ra.S && blockIdx.y == 0 && threadIdx.x < 256) {
+        int token = -1;
+        if (rider_mode == 1) {
+            if (blockIdx.z == 0) token = (int)blockIdx.x;
+        } else {
+            const int live = (gp.g[blockIdx.z].n_blocks + NT - 1) / NT;
+            if ((int)blockIdx.x >= live) {
+                token = (int)blockIdx.x - live;
+                for (unsigned i = 0; i < blockIdx.z; ++i) token += (int)gridDim.x - (gp.g[i].n_blocks + NT - 1) / NT;
+            }
+        }
+        if (token >= 0) {
+            if (token < ra.S && blockIdx.y == 0 && threadIdx.x < 256) {
                 TL_ENTER(5);
-                if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, blockIdx.x, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
-                else router4_body<9, 2, 0, false>(ra, blockIdx.x, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
+                if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
+                else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
                 TL_EXIT(5);
             }
             return;
@@ -99,7 +113,7 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     // p.flat_wgs equal slices of ALL groups' gate/up pairs, so every CU streams the same number of bytes whatever the
     // group sizes are (the per-CU byte balance decides this kernel, see the launcher).  A slice may straddle two groups.
     const bool flat = EPI == UMOE_EPI_SWIGLU && p.flat_wgs > 0;
-    const unsigned zg = blockIdx.z - (FR ? 1u : 0u);      // group index
+    const unsigned zg = blockIdx.z - ((FR && rider_mode == 1) ? 1u : 0u);      // group index
     const umoe_group_t g = p.groups_host ? gp.g[flat ? 0 : zg] : p.groups[zg];
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int ks = blockIdx.x % ksplit;      // K-slice of this workgroup (fp32 partial slab `ks`)
@@ -456,11 +470,17 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
     }
     umoe_router_args ra;
     memset(&ra, 0, sizeof(ra));
+    int rider_mode = 0;
     if (FR) {
         ra = *a->fused_router;
-        grid.z += 1;                 // the router's workgroups: x = token, z = 0 (in front of the first group)
+        int dead = 0;                // workgroups of the box that have no tile (FR requires the host descriptors)
+        for (int i = 0; i < a->num_groups; ++i) dead += (int)grid.x - ceil_div(a->groups_host[i].n_blocks, NT);
+        static int force = -1;
+        if (force < 0) { const char* v = getenv("UMOE_RIDER_MODE"); force = v ? atoi(v) : 0; }
+        rider_mode = (dead >= ra.S && ksplit == 1 && grid.y == 1 && force != 1) ? 2 : 1;
+        if (rider_mode == 1) grid.z += 1;        // the router's workgroups: x = token, z = 0 (in front of the first group)
     }
-    wstream_gemm<NT, U, PRO, EPI, WV, FR><<<grid, WV * 64, lds, s>>>(b, gp, ra);
+    wstream_gemm<NT, U, PRO, EPI, WV, FR><<<grid, WV * 64, lds, s>>>(b, gp, ra, rider_mode);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -560,7 +580,8 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
                 if (a->fused_router) {
                     const umoe_router_args* r = a->fused_router;
                     UMOE_REQUIRE(a->max_rows <= 16 && r->S <= ceil_div(a->max_n_blocks, 14) && r->n_dyn == 9 && r->n_fix == 2 &&
-                                     (r->D == 2048 || r->D == 4096) && r->x && r->gate_w && r->expert_mask && !r->logits_in && !r->norm_only,
+                                     (r->D == 2048 || r->D == 4096) && r->x && r->gate_w && r->expert_mask && !r->logits_in && !r->norm_only &&
+                                     a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE,
                                  "umoe_grouped_gemm: fused_router needs <= 16 rows, n_dyn 9 / n_fix 2, D 2048 / 4096, S <= %d workgroups of the launch",
                                  ceil_div(a->max_n_blocks, 14));
                     return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8, true>(a, s);
