@@ -135,7 +135,7 @@ def roofline(info):
             traffic = json.load(f)["kernels"][kname]["traffic_bytes"]
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": kname + " (grouped gate/up SwiGLU, 8 routed + 2 shared experts in one launch; the launch also carries the router's 16 workgroups)",
+    return {"bound": "hbm", "kernel": kname + " (grouped gate/up SwiGLU, 8 routed + 2 shared experts in one launch; 16 of its tile-less workgroups run the Top-P router)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(ms * 1e3, 2),
             "launches_per_step": n, "experts_hit_per_layer": round(U, 2),
