@@ -71,3 +71,30 @@ def test_no_mfma_is_predicated_through_exec(tmp_path):
         assert pr.wait(timeout=600) == 0, f
         n, bad = scan(out)
         assert n > 0 and not bad, (f, bad[:3])
+
+
+def test_ctypes_mirrors_have_the_size_and_offsets_of_the_c_structs(tmp_path):
+    """unimoe_audio_amd/_lib.py mirrors every argument struct of include/umoe.h by hand: compile a probe with gcc and compare
+    sizeof and the offset of every field (the field NAMES must exist in the C struct too)."""
+    import ctypes as C
+    import subprocess
+    from unimoe_audio_amd import _lib as L
+    pairs = {"umoe_router_args": L.RouterArgs, "umoe_group_t": L.Group, "umoe_gemm_args": L.GemmArgs, "umoe_tgroup_t": L.TGroup,
+             "umoe_tgemm_args": L.TGemmArgs, "umoe_swiglu_bwd_args": L.SwigluBwdArgs, "umoe_attn_bwd_args": L.AttnBwdArgs,
+             "umoe_combine_args": L.CombineArgs, "umoe_rope_args": L.RopeArgs, "umoe_attn_args": L.AttnArgs,
+             "umoe_sample_args": L.SampleArgs, "umoe_engine_cfg": L.EngineCfg, "umoe_layer_weights": L.LayerWeights,
+             "umoe_decode_io": L.DecodeIO}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "umoe.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        src.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            src.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src += ['  return 0;', '}']
+    cfile, exe = tmp_path / "probe.c", tmp_path / "probe"
+    cfile.write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-I" + os.path.join(ROOT, "include"), str(cfile), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == C.sizeof(cls), (cname, got[cname], C.sizeof(cls))
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
