@@ -314,3 +314,34 @@ def test_checkpoint_round_trip_generates_identical_codes(dev, tmp_path):
                                         temperature=1.1, top_p=0.9, eos_prob_mul_factor=0.8, seed=5)
         outs.append((codes.cpu(), lengths.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_router_riding_in_the_gate_up_launch_is_bit_identical(dev, monkeypatch):
+    """Dense decode runs the Top-P router as rider workgroups inside the gate/up launch (umoe_gemm_args.fused_router) behind an
+    RMSNorm-only launch (umoe_router_args.norm_only).  Same arithmetic, same order: the generated codes and the per-layer router
+    integers equal those of the separate router launch (UMOE_FUSE_ROUTER=0) bit for bit, in both rider placements."""
+    from unimoe_audio_amd.codec_utils import DecoderOutput, prepare_audio_prompt
+    cfg = small_cfg(hidden_size=2048, num_attention_heads=16, num_key_value_heads=2, num_hidden_layers=2,
+                    dynamic_intermediate_size=2752, shared_intermediate_size=1376)      # the fused path needs the real D / expert sizes
+    B, T, max_tokens = 8, 12, 10
+    ids, am, codec = prompt(cfg, B, T, 4, [1] + [0] * (2 * B - 1))
+    pre, psteps = prepare_audio_prompt(cfg, [None] * B)
+    outs = []
+    for fuse, mode in (("0", "0"), ("1", "1"), ("1", "0")):
+        monkeypatch.setenv("UMOE_FUSE_ROUTER", fuse)
+        monkeypatch.setenv("UMOE_RIDER_MODE", mode)
+        m, _ = build(cfg, 31, 0.03)
+        m = m.to(dev)
+        dec = DecoderOutput(pre.clone(), psteps, dev)
+        codes, lengths = m.generate(ids, am, dec, max_tokens, 4, codec_input_ids=codec, cfg_scale=2.0, do_sample=True, temperature=1.0,
+                                    top_p=0.9, eos_prob_mul_factor=0.8, seed=3)
+        eng = m._engine
+        stats = eng.router_stats() if hasattr(eng, "router_stats") else None
+        outs.append((codes.cpu(), lengths.cpu(), stats))
+        del m
+        torch.cuda.empty_cache()
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+        if o[2] is not None and outs[0][2] is not None:
+            for a, b in zip(o[2], outs[0][2]):
+                assert torch.equal(a.cpu(), b.cpu())

@@ -475,8 +475,8 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
         ra = *a->fused_router;
         int dead = 0;                // workgroups of the box that have no tile (FR requires the host descriptors)
         for (int i = 0; i < a->num_groups; ++i) dead += (int)grid.x - ceil_div(a->groups_host[i].n_blocks, NT);
-        static int force = -1;
-        if (force < 0) { const char* v = getenv("UMOE_RIDER_MODE"); force = v ? atoi(v) : 0; }
+        const char* fv = getenv("UMOE_RIDER_MODE");      // (read per launch: the decode graph captures it once; tests toggle it)
+        const int force = fv ? atoi(fv) : 0;
         rider_mode = (dead >= ra.S && ksplit == 1 && grid.y == 1 && force != 1) ? 2 : 1;
         if (rider_mode == 1) grid.z += 1;        // the router's workgroups: x = token, z = 0 (in front of the first group)
     }
