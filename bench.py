@@ -79,7 +79,7 @@ def gpu_run(args, rank, world, device):
     torch.cuda.synchronize()
     t_build = time.time() - t0
     max_tokens = K + W + 64
-    eng = model.engine(B, T, max_tokens, attn_splits=8)
+    eng = model.engine(B, T, max_tokens, attn_splits=int(os.environ.get("UMOE_ATTN_SPLITS", "8")))   # (experiment knob; 8 measured best)
     ids, am, codec = synth_prompt(cfg, B, T, device)
     x = model.calculate_input_embedding(ids, codec)
     torch.cuda.synchronize()
