@@ -55,15 +55,26 @@ def prompt(cfg, B, T, seed, pads):
     return ids, am, codec
 
 
-def test_teacher_forced_steps_logits_and_router_ints(dev):
+@pytest.mark.parametrize("full_width", [False, True])
+def test_teacher_forced_steps_logits_and_router_ints(dev, full_width):
     """Every decode step fed the ORACLE's tokens: per-step logits within tolerance, arg-max codes agree, router ints
-    of every layer equal the oracle's wherever the router logits agree bit-for-bit."""
+    of every layer equal the oracle's wherever the router logits agree bit-for-bit.
+    full_width: the reference's layer sizes (D 2048, 16 / 2 heads, experts 2752 / 1376) at batch 8 = 16 CFG rows, two layers -- the
+    headline decode path itself (dense-expert layout, 14-block gate/up with the router riding in it, RMSNorm-only launch,
+    tiled prefill) against the CPU oracle."""
     from oracle import decode as OD
     from unimoe_audio_amd.codec_utils import DecoderOutput, prepare_audio_prompt
-    cfg = small_cfg()
-    m, w = build(cfg, 1, 0.06)
-    B, T, steps = 2, 12, 24
-    ids, am, codec = prompt(cfg, B, T, 2, [3, 0, 1, 0])
+    if full_width:
+        cfg = small_cfg(hidden_size=2048, num_attention_heads=16, num_key_value_heads=2, dynamic_intermediate_size=2752,
+                        shared_intermediate_size=1376)
+        m, w = build(cfg, 1, 0.02)
+        B, T, steps = 8, 12, 8
+        ids, am, codec = prompt(cfg, B, T, 2, [3, 0, 1, 0] + [0] * 12)
+    else:
+        cfg = small_cfg()
+        m, w = build(cfg, 1, 0.06)
+        B, T, steps = 2, 12, 24
+        ids, am, codec = prompt(cfg, B, T, 2, [3, 0, 1, 0])
     pre, psteps = OD.prepare_audio_prompt(cfg, [None] * B)
     gen = OD.GenerateOracle(cfg, w)
     MAXT = steps + 40                              # forced EOS (cur >= max_tokens - 18) stays outside the compared window
