@@ -252,6 +252,22 @@ int umoe_ep_comm_create(const void* uid128, int rank, int nranks, void** comm_ou
 int umoe_ep_comm_destroy(void* comm);
 int umoe_ep_all_to_all(void* comm, const void* send, void* recv, size_t bytes_per_peer, int nranks, umoe_stream_t stream);
 
+/* Peer exchange of the expert-parallel DECODE engine (umoe_engine_cfg.ep_size > 1): xGMI peer stores inside the captured step
+ * graph instead of a collective call.  Every rank owns one exchange REGION (uncached device memory: flags + the dispatch slab
+ * [ep][rows][D] + the return slab [n_real][rows][D]); ranks map each other's regions through HIP IPC handles once, at connect
+ * time.  Per layer: rank r pushes its normalised rows into tile r of every peer's dispatch slab (the DENSE form of the
+ * reference's first all-to-all, core.py:467: at <= 16 rows per rank every expert is hit anyway, so every rank receives every
+ * row and the routing result is only needed by the combine), computes its local experts on all ep*rows rows, and pushes the
+ * outputs for rank t's rows into the return slab of rank t (second all-to-all, core.py:480).  Payload and flags are
+ * system-scope write-through stores (sc0 sc1), drained per wave before ONE lane publishes the epoch; receivers poll with
+ * system-scope loads (bounded spin: a timeout sets the engine's error word, see umoe_engine_ep_error) and copy the slab into
+ * ordinary device memory for the GEMMs.  Epoch = decode step * layers + layer + 1, counted on the device: graph replays need
+ * no host value.  All ranks must run the same sequence of decode steps. */
+#define UMOE_MAX_EP 8
+int umoe_ep_ipc_export(const void* dev_ptr, void* handle64_out);      /* hipIpcGetMemHandle: 64 opaque bytes */
+int umoe_ep_ipc_open(const void* handle64, void** dev_ptr_out);       /* hipIpcOpenMemHandle (lazy peer access) */
+int umoe_ep_ipc_close(void* dev_ptr);
+
 /* ------------------------------------------------------------------ backward pieces (training, BASELINE config 3)
  * The contractions run on umoe_tiled_gemm (operands K-contiguous): dX = dY * W uses a transposed weight copy, dW = dY^T X
  * contracts over the slot columns of transposed, 8-aligned, zero-padded buffers built by umoe_transpose_slots
@@ -492,7 +508,8 @@ typedef struct {
     int Lmax;                 /* KV slots per row */
     int Tmax;                 /* token buffer length */
     int attn_splits;
-    int ep_rank, ep_size;     /* expert parallel: this rank owns experts [rank*n_real/size, ...) */
+    int ep_rank, ep_size;     /* expert parallel decode: this rank owns experts [rank*n_real/size, ...); ep_size in {1,2,4,8},
+                               * rows <= 16 per rank; see umoe_engine_ep_connect */
 } umoe_engine_cfg;
 
 typedef struct {
@@ -546,6 +563,19 @@ int umoe_engine_replay(umoe_engine* e, umoe_stream_t stream);
  * {qkv, rope, attn, oproj, router, dispatch, gateup, down, combine, embed, head, sample, delay} */
 int umoe_engine_profile_step(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream, float* ms, int* launches,
                              int n);
+/* Expert parallel decode (ep_size > 1).  umoe_engine_set_layer then takes exp_gu / exp_dn of the n_real / ep_size LOCAL experts
+ * (global ids [ep_rank * E_loc, (ep_rank + 1) * E_loc), core.py:505) and, for the prefill, the row-major tensors of ALL n_real
+ * experts (the prefill is not timed and runs replicated; the decode step is what is sharded).
+ * umoe_engine_ep_region: this rank's exchange region (export with umoe_ep_ipc_export).
+ * umoe_engine_ep_connect: peers[p] = rank p's region as mapped in this process (peers[ep_rank] = own base).
+ *   mode UMOE_EP_PEER: xGMI peer stores; UMOE_EP_LOOPBACK: single-GPU emulation of ONE rank of an ep_size job for timing
+ *   (every peer is this engine itself: tile p of the local slabs stands for rank p; results are not the model's);
+ *   UMOE_EP_RCCL: `rccl_comm` (ncclComm_t) carries the same exchange as ncclAllGather + grouped ncclSend/ncclRecv.
+ * umoe_engine_ep_error: synchronises `stream` and returns the sticky error word (0 = none; 1 = a receive timed out). */
+enum { UMOE_EP_PEER = 0, UMOE_EP_LOOPBACK = 1, UMOE_EP_RCCL = 2 };
+int umoe_engine_ep_region(umoe_engine* e, void** base_out, size_t* bytes_out);
+int umoe_engine_ep_connect(umoe_engine* e, void* const* peers, void* rccl_comm, int mode);
+int umoe_engine_ep_error(umoe_engine* e, umoe_stream_t stream, int* code_out);
 /* introspection for parity tests: device pointers into the workspace */
 const void* umoe_engine_buffer(umoe_engine* e, const char* name, size_t* bytes);
 

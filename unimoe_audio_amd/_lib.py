@@ -134,7 +134,12 @@ EXPORTS = [
     "umoe_swiglu_bwd_workspace_bytes", "umoe_grouped_swiglu_bwd", "umoe_shared_swiglu_bwd",
     "umoe_attn_prefill_bwd_workspace_bytes", "umoe_attn_prefill_bwd",
     "umoe_ep_unique_id", "umoe_ep_comm_create", "umoe_ep_comm_destroy", "umoe_ep_all_to_all",
+    "umoe_ep_ipc_export", "umoe_ep_ipc_open", "umoe_ep_ipc_close", "umoe_engine_ep_region", "umoe_engine_ep_connect",
+    "umoe_engine_ep_error",
 ]
+
+EP_PEER, EP_LOOPBACK, EP_RCCL = 0, 1, 2
+MAX_EP = 8
 
 
 def lib():
@@ -181,6 +186,12 @@ def lib():
         L.umoe_ep_comm_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
         L.umoe_ep_comm_destroy.argtypes = [vp]
         L.umoe_ep_all_to_all.argtypes = [vp, vp, vp, C.c_size_t, i32, vp]
+        L.umoe_ep_ipc_export.argtypes = [vp, vp]
+        L.umoe_ep_ipc_open.argtypes = [vp, C.POINTER(vp)]
+        L.umoe_ep_ipc_close.argtypes = [vp]
+        L.umoe_engine_ep_region.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        L.umoe_engine_ep_connect.argtypes = [vp, C.POINTER(vp), vp, i32]
+        L.umoe_engine_ep_error.argtypes = [vp, vp, C.POINTER(i32)]
         L.umoe_router_dispatch_fwd.argtypes = [C.POINTER(RouterArgs), vp, vp, vp, vp, vp]
         L.umoe_permute_fwd.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.umoe_grouped_gemm.argtypes = [C.POINTER(GemmArgs), vp]

@@ -115,13 +115,29 @@ def load_checkpoint(model: torch.nn.Module, path: str, ep_rank: int = 0, ep_size
             continue
         if tuple(dst.shape) != tuple(t.shape):
             raise ValueError(f"{key}: checkpoint shape {tuple(t.shape)} != parameter shape {tuple(dst.shape)}")
-        dst.data.copy_(t.to(dst.dtype), non_blocking=False)
+        dst.copy_(t.to(dst.dtype), non_blocking=False)     # (not `.data.copy_`: the in-place op must bump `_version`)
         seen.add(key)
+    invalidate_packed(model)
     missing = [k for k in target if k not in seen]
     hot = [k for k in missing if not k.startswith(COLD_PREFIXES)]
     if strict_hot and hot:
         raise KeyError(f"checkpoint {path!r} lacks {len(hot)} hot-path tensors, e.g. {hot[:4]}")
     return missing, [k for k in unexpected if not k.startswith(COLD_PREFIXES)]
+
+
+def invalidate_packed(model: torch.nn.Module) -> None:
+    """Drop every MFMA-packed weight copy derived from the parameters (model.packed(), each DCMoE block's prepare()) and the
+    decode engine built on them: the next forward / generate re-packs from the live tensors.  Called after every load; call it
+    yourself after writing parameters through `.data` (which does not bump `_version`, the caches' key)."""
+    if hasattr(model, "_pk"):
+        model._pk, model._pk_key = None, None
+    for m in model.modules():
+        if hasattr(m, "_packed"):
+            m._packed, m._packed_key = None, None
+    eng = getattr(model, "_engine", None)
+    if eng is not None:
+        eng.close()
+        model._engine = None
 
 
 def save_checkpoint(state: Dict[str, "torch.Tensor"], path: str, max_shard_bytes: int = 4 << 30, reference_keys: bool = True) -> List[str]:

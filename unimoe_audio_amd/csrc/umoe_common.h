@@ -166,3 +166,25 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 }
 #endif
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- expert-parallel peer exchange (umoe_ep.hip; used by the decode engine) -----------------------------------------
+// Region of one rank (uncached device memory, mapped by every peer through HIP IPC):
+//   [flag block: 2 kinds x UMOE_MAX_EP tiles x UMOE_EP_PARTS words, one 64-byte line each][dispatch slab][return slab]
+#define UMOE_EP_PARTS 4
+#define UMOE_EP_FLAG_BYTES (2 * UMOE_MAX_EP * UMOE_EP_PARTS * 64)
+struct umoe_ep_xfer {          // one push (local rows -> every peer's slab) or pull (own slab -> local buffer); by value
+    char* peer_base[UMOE_MAX_EP];  // region base of every rank as mapped in this process
+    const char* src;           // push: local source of the chunk for peer p = src + p * src_stride
+    long src_stride;
+    char* dst;                 // pull: local destination of tile p = dst + p * chunk
+    size_t chunk;              // bytes per tile (multiple of UMOE_EP_PARTS * 16)
+    size_t data_off;           // slab offset inside a region
+    int kind;                  // 0 dispatch, 1 return: selects the flag block half
+    int rank, size, loopback;
+    const uint32_t* step;      // device word: decode steps taken so far
+    int layer, layers;         // epoch = *step * layers + layer + 1
+    uint32_t* err;             // device word, sticky: 1 = a receive timed out
+};
+int umoe_ep_push(const umoe_ep_xfer& x, hipStream_t s);
+int umoe_ep_pull(const umoe_ep_xfer& x, hipStream_t s);
+int umoe_ep_rccl_allgather(void* comm, const void* send, void* recv, size_t bytes, hipStream_t s);

@@ -88,6 +88,17 @@ struct umoe_engine {
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_kind;
     size_t ev_used = 0;
+    // expert parallel decode (c.ep_size > 1): see include/umoe.h "Peer exchange"
+    int E_loc = 0;                        // local routed experts = n_real / ep_size
+    char* ep_region = nullptr;            // flags + dispatch slab + return slab (uncached device memory, IPC-exported)
+    size_t ep_region_bytes = 0;
+    int ep_mem_kind = 0;                  // 1 uncached, 2 fine-grained, 3 plain hipMalloc (what the runtime granted)
+    char* ep_peers[UMOE_MAX_EP] = {};
+    void* ep_comm = nullptr;
+    int ep_mode = -1;                     // -1 = not connected
+    uint32_t* ep_words = nullptr;         // [0] decode steps taken (epoch base), [1] sticky error word; own allocation: survives workspace growth
+    uint16_t* xg = nullptr;               // [ep][rows][D] normalised rows of every rank (tile ep_rank is written locally)
+    bool ep_decode(int n_tok) const { return c.ep_size > 1 && n_tok == c.rows; }
     int groups_per_layer() const { return 2 + 2 * (c.n_real + c.n_fix); }
 };
 
@@ -108,7 +119,10 @@ static size_t carve(umoe_engine* e, int n_tok, char* base) {
     e->q_r = k.take<uint16_t>((size_t)n_tok * HD);
     e->attn_out = k.take<uint16_t>((size_t)n_tok * HD);
     e->hbuf = k.take<uint16_t>(slots * Imax);
-    e->ybuf = k.take<uint16_t>(slots * D);
+    // expert parallel: behind the dense-layout rows [expert][row] and the shared experts' rows, ybuf also holds the outputs of
+    // the LOCAL experts for every rank's rows, [dest rank][local expert][row], which the return exchange ships
+    e->ybuf = k.take<uint16_t>(slots * D + (c.ep_size > 1 ? (size_t)c.n_real * c.rows * D : 0));
+    e->xg = k.take<uint16_t>(c.ep_size > 1 ? (size_t)c.ep_size * c.rows * D : 0);
     e->part_o = k.take<float>((size_t)n_tok * c.heads * splits * c.head_dim);
     e->part_ml = k.take<float>((size_t)n_tok * c.heads * splits * 2);
     e->logits = k.take<float>((size_t)c.rows * c.codec_channels * c.codec_vocab);
@@ -155,6 +169,7 @@ static int ensure_workspace(umoe_engine* e, int n_tok) {
 
 // group table for a pass over n_tok tokens
 static bool dense_mode(const umoe_engine* e, int n_tok) {
+    if (e->ep_decode(n_tok)) return true;   // expert parallel decode IS the dense layout: every rank's rows visit every expert
     return e->dense_experts && n_tok == e->c.rows && n_tok <= 16 && n_tok >= 6 && !e->overlap_shared;
 }
 
@@ -178,9 +193,34 @@ static int build_groups(umoe_engine* e, int n_tok, hipStream_t s) {
         g[1].w = L.w.o_w; g[1].static_count = n_tok; g[1].n_blocks = c.hidden / 16; g[1].k = c.heads * c.head_dim;
         umoe_group_t* gu = g + 2;
         umoe_group_t* dn = g + 2 + G;
+        if (e->ep_decode(n_tok)) {
+            // expert parallel decode: one group per (local expert x, source rank t) over the gathered rows xg[t][row]; h rows
+            // (x*ep + t)*rows; outputs for rank t's rows at ybuf rows yloc0 + (t*E_loc + x)*rows (shipped by the return push),
+            // the own rank's straight into the dense layout row (global expert)*rows the combine reads (peer modes)
+            const int ep = c.ep_size, El = e->E_loc, yloc0 = (c.n_real + c.n_fix) * n_tok;
+            const bool own_direct = e->ep_mode != UMOE_EP_RCCL;
+            for (int x = 0; x < El; ++x)
+                for (int t = 0; t < ep; ++t) {
+                    const int q = x * ep + t;
+                    gu[q].w = L.exp_gu[x]; gu[q].n_blocks = 2 * c.inter_dyn / 16; gu[q].k = c.hidden;
+                    gu[q].static_count = n_tok; gu[q].a_row_base = t * n_tok; gu[q].out_row_base = q * n_tok;
+                    dn[q].w = L.exp_dn[x]; dn[q].n_blocks = c.hidden / 16; dn[q].k = c.inter_dyn;
+                    dn[q].static_count = n_tok; dn[q].a_row_base = q * n_tok;
+                    dn[q].out_row_base = (t == c.ep_rank && own_direct) ? (c.ep_rank * El + x) * n_tok : yloc0 + (t * El + x) * n_tok;
+                }
+            for (int i = 0; i < c.n_fix; ++i) {
+                const int x = c.n_real + i;
+                gu[x].w = L.sh_gu[i]; gu[x].static_count = n_tok; gu[x].a_row_base = c.ep_rank * n_tok;   // own tile of xg
+                gu[x].out_row_base = slots_routed + i * n_tok; gu[x].n_blocks = 2 * c.inter_shared / 16; gu[x].k = c.hidden;
+                dn[x].w = L.sh_dn[i]; dn[x].static_count = n_tok; dn[x].a_row_base = slots_routed + i * n_tok;
+                dn[x].out_row_base = slots_routed + i * n_tok; dn[x].n_blocks = c.hidden / 16; dn[x].k = c.inter_shared;
+            }
+            continue;
+        }
+        const int n_packed = c.ep_size > 1 ? 0 : c.n_real;   // expert parallel prefill: tiled kernels on the row-major tensors only
         for (int x = 0; x < c.n_real; ++x) {
-            gu[x].w = L.exp_gu[x]; gu[x].n_blocks = 2 * c.inter_dyn / 16; gu[x].k = c.hidden;
-            dn[x].w = L.exp_dn[x]; dn[x].n_blocks = c.hidden / 16; dn[x].k = c.inter_dyn;
+            gu[x].w = x < n_packed ? L.exp_gu[x] : nullptr; gu[x].n_blocks = 2 * c.inter_dyn / 16; gu[x].k = c.hidden;
+            dn[x].w = x < n_packed ? L.exp_dn[x] : nullptr; dn[x].n_blocks = c.hidden / 16; dn[x].k = c.inter_dyn;
             if (dense) {   // expert x owns rows [x*n_tok, (x+1)*n_tok) of the h / y buffers, token order
                 gu[x].static_count = n_tok; gu[x].out_row_base = x * n_tok;
                 dn[x].static_count = n_tok; dn[x].a_row_base = x * n_tok; dn[x].out_row_base = x * n_tok;
@@ -214,9 +254,16 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
                  "umoe_engine: hidden %% 128 and intermediate sizes %% 32 must be 0");
     UMOE_REQUIRE(cfg->rows > 0 && cfg->rows % 2 == 0 && cfg->rows / 2 <= 256, "umoe_engine: rows must be 2*batch, batch <= 256");
     UMOE_REQUIRE(cfg->n_dyn + cfg->n_fix <= UMOE_MAXE && cfg->n_real <= cfg->n_dyn, "umoe_engine: bad expert counts");
-    UMOE_REQUIRE(cfg->ep_size <= 1, "umoe_engine: expert parallel runs through the Python EP path (ep_size=%d)", cfg->ep_size);
+    const int ep = cfg->ep_size > 1 ? cfg->ep_size : 1;
+    UMOE_REQUIRE(ep == 1 || ((ep == 2 || ep == 4 || ep == 8) && cfg->n_real % ep == 0 && cfg->ep_rank >= 0 && cfg->ep_rank < ep &&
+                             cfg->rows <= 16 && cfg->n_real + cfg->n_fix <= UMOE_GROUPS_INLINE),
+                 "umoe_engine: expert parallel decode needs ep_size 2/4/8 dividing n_real=%d, 0 <= ep_rank < ep_size, rows <= 16 (ep_size=%d rank=%d rows=%d)",
+                 cfg->n_real, cfg->ep_size, cfg->ep_rank, cfg->rows);
     umoe_engine* e = new umoe_engine();
     e->c = *cfg;
+    e->c.ep_size = ep;
+    if (ep == 1) e->c.ep_rank = 0;
+    e->E_loc = cfg->n_real / ep;
     if (e->c.attn_splits < 1) e->c.attn_splits = 1;
     e->layers.resize(cfg->layers);
     const size_t kv = (size_t)cfg->layers * cfg->rows * cfg->kv_heads * cfg->Lmax * cfg->head_dim;
@@ -232,6 +279,27 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (ensure_workspace(e, cfg->rows)) {
         umoe_engine_destroy(e);
         return -2;
+    }
+    if (hipMalloc(&e->ep_words, 64) != hipSuccess || hipMemset(e->ep_words, 0, 64) != hipSuccess) {
+        umoe_set_error("umoe_engine_create: hipMalloc failed (state words)");
+        umoe_engine_destroy(e);
+        return -2;
+    }
+    if (ep > 1) {
+        // exchange region: peers store into it over xGMI and this GPU reads it while a kernel runs -> uncached (MTYPE UC) device
+        // memory where the runtime grants it, fine-grained otherwise; every access of it is an sc0 sc1 access anyway (umoe_ep.hip)
+        const size_t tile = (size_t)cfg->rows * cfg->hidden * 2;
+        e->ep_region_bytes = UMOE_EP_FLAG_BYTES + (size_t)ep * tile + (size_t)cfg->n_real * tile;
+        void* r = nullptr;
+        if (hipExtMallocWithFlags(&r, e->ep_region_bytes, hipDeviceMallocUncached) == hipSuccess) e->ep_mem_kind = 1;
+        else if ((void)hipGetLastError(), hipExtMallocWithFlags(&r, e->ep_region_bytes, hipDeviceMallocFinegrained) == hipSuccess) e->ep_mem_kind = 2;
+        else if ((void)hipGetLastError(), hipMalloc(&r, e->ep_region_bytes) == hipSuccess) e->ep_mem_kind = 3;
+        if (!r || hipMemset(r, 0, e->ep_region_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            umoe_set_error("umoe_engine_create: exchange region allocation failed (%zu bytes)", e->ep_region_bytes);
+            umoe_engine_destroy(e);
+            return -2;
+        }
+        e->ep_region = (char*)r;
     }
     if (hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -259,6 +327,8 @@ extern "C" void umoe_engine_destroy(umoe_engine* e) {
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->s2) (void)hipStreamDestroy(e->s2);
     if (e->ws) (void)hipFree(e->ws);
+    if (e->ep_region) (void)hipFree(e->ep_region);
+    if (e->ep_words) (void)hipFree(e->ep_words);
     if (e->k_cache) (void)hipFree(e->k_cache);
     if (e->v_cache) (void)hipFree(e->v_cache);
     if (e->d_delay) (void)hipFree(e->d_delay);
@@ -270,8 +340,8 @@ extern "C" int umoe_engine_set_layer(umoe_engine* e, int layer, const umoe_layer
     UMOE_REQUIRE(e && w && layer >= 0 && layer < e->c.layers, "umoe_engine_set_layer: bad layer %d", layer);
     LayerDev& L = e->layers[layer];
     L.w = *w;
-    L.exp_gu.assign(w->exp_gu, w->exp_gu + e->c.n_real);
-    L.exp_dn.assign(w->exp_dn, w->exp_dn + e->c.n_real);
+    L.exp_gu.assign(w->exp_gu, w->exp_gu + e->E_loc);     // expert parallel: the LOCAL experts' packed weights only
+    L.exp_dn.assign(w->exp_dn, w->exp_dn + e->E_loc);
     L.sh_gu.assign(w->sh_gu, w->sh_gu + e->c.n_fix);
     L.sh_dn.assign(w->sh_dn, w->sh_dn + e->c.n_fix);
     L.has_rm = w->rm_qkv && w->rm_o && w->rm_exp_gate && w->rm_exp_up && w->rm_exp_down &&
@@ -307,6 +377,46 @@ extern "C" int umoe_engine_set_globals(umoe_engine* e, const uint16_t* final_nor
 
 extern "C" size_t umoe_engine_workspace_bytes(const umoe_engine* e) { return e ? e->ws_bytes : 0; }
 
+// ------------------------------------------------------------------------------------ expert parallel plumbing
+extern "C" int umoe_engine_ep_region(umoe_engine* e, void** base_out, size_t* bytes_out) {
+    UMOE_REQUIRE(e && base_out && bytes_out, "umoe_engine_ep_region: null argument");
+    UMOE_REQUIRE(e->c.ep_size > 1 && e->ep_region, "umoe_engine_ep_region: engine was created with ep_size 1");
+    *base_out = e->ep_region;
+    *bytes_out = e->ep_region_bytes;
+    return 0;
+}
+
+extern "C" int umoe_engine_ep_connect(umoe_engine* e, void* const* peers, void* rccl_comm, int mode) {
+    UMOE_REQUIRE(e && e->c.ep_size > 1, "umoe_engine_ep_connect: engine was created with ep_size 1");
+    UMOE_REQUIRE(mode == UMOE_EP_PEER || mode == UMOE_EP_LOOPBACK || mode == UMOE_EP_RCCL, "umoe_engine_ep_connect: bad mode %d", mode);
+    if (mode == UMOE_EP_RCCL) {
+        UMOE_REQUIRE(rccl_comm, "umoe_engine_ep_connect: the RCCL mode needs a communicator");
+        e->ep_comm = rccl_comm;
+        for (int p = 0; p < e->c.ep_size; ++p) e->ep_peers[p] = e->ep_region;
+    } else if (mode == UMOE_EP_LOOPBACK) {
+        for (int p = 0; p < e->c.ep_size; ++p) e->ep_peers[p] = e->ep_region;
+    } else {
+        UMOE_REQUIRE(peers, "umoe_engine_ep_connect: the peer mode needs every rank's region");
+        for (int p = 0; p < e->c.ep_size; ++p) {
+            UMOE_REQUIRE(peers[p], "umoe_engine_ep_connect: region of rank %d is null", p);
+            e->ep_peers[p] = (char*)peers[p];
+        }
+        UMOE_REQUIRE(e->ep_peers[e->c.ep_rank] == e->ep_region, "umoe_engine_ep_connect: peers[ep_rank] must be this engine's own region");
+    }
+    e->ep_mode = mode;
+    e->groups_for_tok = -1;   // the decode group table depends on the mode (where the own rows' outputs go)
+    return 0;
+}
+
+extern "C" int umoe_engine_ep_error(umoe_engine* e, umoe_stream_t stream, int* code_out) {
+    UMOE_REQUIRE(e && code_out, "umoe_engine_ep_error: null argument");
+    uint32_t w[2] = {0, 0};
+    UMOE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    UMOE_HIP(hipMemcpy(w, e->ep_words, sizeof(w), hipMemcpyDeviceToHost));
+    *code_out = (int)w[1];
+    return 0;
+}
+
 // kernel classes reported by umoe_engine_profile_step
 enum { K_QKV = 0, K_ROPE, K_ATTN, K_OPROJ, K_ROUTER, K_DISPATCH, K_GATEUP, K_DOWN, K_COMBINE, K_EMBED, K_HEAD, K_SAMPLE,
        K_DELAY, K_NUM };
@@ -323,6 +433,119 @@ static void prof_mark(umoe_engine* e, int kind, hipStream_t s) {
     (void)hipEventRecord(e->ev[e->ev_used++], s);
 }
 #define PROF(kind) prof_mark(e, kind, s)
+
+// ------------------------------------------------------------------------------------ DCMoE of one layer, expert parallel decode
+// Replaces AudioMOELayer.forward with ep_size > 1 (core.py:446-493: capacity MAX all-reduce :457, all-to-alls :467 / :480) for
+// the decode shape.  Order of launches (one stream, all captured in the step graph):
+//   RMSNorm (own rows -> tile ep_rank of xg) | PUSH rows to every peer | shared experts gate/up (hides the push) | PULL the peers'
+//   rows | local experts gate/up over ep*rows rows (+ the router riders) | down | PUSH outputs to the rows' owners | shared
+//   experts down (hides the push) | PULL | combine (selects by the local routing mask, ascending expert order: bit-identical to
+//   ep_size 1 because every (expert, 16-row tile) product is computed by the same kernel instantiation with the same K split).
+static int run_moe_ep(umoe_engine* e, int l, int n_tok, hipStream_t s) {
+    const umoe_engine_cfg& c = e->c;
+    const int D = c.hidden, G = c.n_real + c.n_fix, GPL = e->groups_per_layer(), E = c.n_dyn + c.n_fix;
+    const int Imax = c.inter_dyn > c.inter_shared ? c.inter_dyn : c.inter_shared;
+    const int ep = c.ep_size, El = e->E_loc, rank = c.ep_rank;
+    const LayerDev& L = e->layers[l];
+    const umoe_group_t* g = e->d_groups + (size_t)l * GPL;
+    const umoe_group_t* gh = e->h_groups.data() + (size_t)l * GPL;
+    UMOE_REQUIRE(e->ep_mode >= 0, "umoe_engine: expert parallel engine is not connected (umoe_engine_ep_connect)");
+    int rc;
+    uint16_t* h2own = e->xg + (size_t)rank * n_tok * D;
+    umoe_router_args ra{};
+    ra.x = e->x1; ra.gate_w = L.w.gate_w; ra.norm_w = L.w.post_norm; ra.h_out = h2own; ra.S = n_tok; ra.D = D;
+    ra.n_dyn = c.n_dyn; ra.n_real = c.n_real; ra.n_fix = c.n_fix; ra.logits_bf16 = 1; ra.top_p = c.top_p;
+    ra.fixed_top_k = c.fixed_top_k; ra.jitter_eps = c.jitter_eps; ra.rms_eps = c.rms_eps;
+    ra.logits_out = e->r_logits; ra.sel = e->r_sel; ra.routing_w = e->r_routing; ra.global_w = e->r_global; ra.moe_w = e->r_moe;
+    ra.expert_mask = e->all_mask + (size_t)l * c.rows * E;
+    ra.top_k = e->all_topk + (size_t)l * c.rows;
+    const bool ride = e->fuse_router && c.n_dyn == 9 && c.n_fix == 2 && (D == 2048 || D == 4096) && n_tok <= 16;
+    if (ride) {              // RMSNorm only; the router body rides in the local experts' gate/up launch (its results feed the combine)
+        umoe_router_args rn = ra;
+        rn.norm_only = 1;
+        rc = umoe_router_fwd(&rn, s);
+        ra.h_out = nullptr;
+    } else {
+        rc = umoe_router_fwd(&ra, s);
+    }
+    if (rc) return rc;
+    PROF(K_ROUTER);
+    const size_t tile = (size_t)n_tok * D * 2, chunk_y = (size_t)El * tile;
+    umoe_ep_xfer x{};
+    for (int p = 0; p < ep; ++p) x.peer_base[p] = e->ep_peers[p];
+    x.rank = rank; x.size = ep; x.loopback = e->ep_mode == UMOE_EP_LOOPBACK; x.step = e->ep_words; x.err = e->ep_words + 1;
+    x.layer = l; x.layers = c.layers;
+    // ---- first exchange: my normalised rows to every peer
+    if (e->ep_mode == UMOE_EP_RCCL) {
+        rc = umoe_ep_rccl_allgather(e->ep_comm, h2own, e->xg, tile, s);
+    } else {
+        x.kind = 0; x.src = (const char*)h2own; x.src_stride = 0; x.chunk = tile; x.data_off = UMOE_EP_FLAG_BYTES;
+        rc = umoe_ep_push(x, s);
+    }
+    if (rc) return rc;
+    PROF(K_DISPATCH);
+    // ---- shared experts gate/up on the own rows while the rows travel.  K split as in the ep_size 1 launch (8 waves, 1-step chunks)
+    if (c.n_fix > 0) {
+        umoe_gemm_args sg{};
+        sg.groups = g + 2 + c.n_real; sg.groups_host = gh + 2 + c.n_real; sg.num_groups = c.n_fix; sg.max_rows = n_tok;
+        sg.max_n_blocks = 2 * c.inter_shared / 16; sg.max_k = D; sg.a = e->xg; sg.lda = D; sg.out = e->hbuf; sg.ldo = Imax; sg.n_valid = Imax;
+        sg.prologue = UMOE_PRO_PLAIN; sg.epilogue = UMOE_EPI_SWIGLU; sg.nt = 2; sg.waves = 8;
+        if ((rc = umoe_grouped_gemm(&sg, s))) return rc;
+        PROF(K_GATEUP);
+    }
+    if (e->ep_mode != UMOE_EP_RCCL) {
+        x.dst = (char*)e->xg;
+        if ((rc = umoe_ep_pull(x, s))) return rc;
+        PROF(K_DISPATCH);
+    }
+    // ---- local experts over every rank's rows
+    umoe_gemm_args gu{};
+    gu.groups = g + 2; gu.groups_host = gh + 2; gu.num_groups = c.n_real; gu.max_rows = n_tok; gu.max_n_blocks = 2 * c.inter_dyn / 16;
+    gu.max_k = D; gu.a = e->xg; gu.lda = D; gu.out = e->hbuf; gu.ldo = Imax; gu.n_valid = Imax;
+    gu.prologue = UMOE_PRO_PLAIN; gu.epilogue = UMOE_EPI_SWIGLU; gu.nt = 14;
+    if (ride) gu.fused_router = &ra;
+    if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
+    PROF(K_GATEUP);
+    umoe_gemm_args dn{};
+    dn.groups = g + 2 + G; dn.groups_host = gh + 2 + G; dn.num_groups = c.n_real; dn.max_rows = n_tok; dn.max_n_blocks = D / 16;
+    dn.max_k = c.inter_dyn; dn.a = e->hbuf; dn.lda = Imax; dn.out = e->ybuf; dn.ldo = D; dn.n_valid = D;
+    dn.prologue = UMOE_PRO_PLAIN; dn.epilogue = UMOE_EPI_BF16; dn.nt = 6; dn.waves = 8;
+    if ((rc = umoe_grouped_gemm(&dn, s))) return rc;
+    PROF(K_DOWN);
+    // ---- second exchange: outputs of my experts to the rows' owners (dense layout row = (global expert)*rows + row there)
+    uint16_t* yloc = e->ybuf + (size_t)G * n_tok * D;
+    if (e->ep_mode == UMOE_EP_RCCL) {
+        rc = umoe_ep_all_to_all(e->ep_comm, yloc, e->ybuf, chunk_y, ep, s);
+    } else {
+        x.kind = 1; x.src = (const char*)yloc; x.src_stride = (long)chunk_y; x.chunk = chunk_y; x.data_off = UMOE_EP_FLAG_BYTES + (size_t)ep * tile;
+        rc = umoe_ep_push(x, s);
+    }
+    if (rc) return rc;
+    PROF(K_DISPATCH);
+    if (c.n_fix > 0) {       // shared experts down while the outputs travel (K split as in the ep_size 1 launch: 8 waves, 2-step chunks)
+        umoe_gemm_args sd{};
+        sd.groups = g + 2 + G + c.n_real; sd.groups_host = gh + 2 + G + c.n_real; sd.num_groups = c.n_fix; sd.max_rows = n_tok;
+        sd.max_n_blocks = D / 16; sd.max_k = c.inter_shared; sd.a = e->hbuf; sd.lda = Imax; sd.out = e->ybuf; sd.ldo = D; sd.n_valid = D;
+        sd.prologue = UMOE_PRO_PLAIN; sd.epilogue = UMOE_EPI_BF16; sd.nt = 2; sd.waves = 8;
+        if ((rc = umoe_grouped_gemm(&sd, s))) return rc;
+        PROF(K_DOWN);
+    }
+    if (e->ep_mode != UMOE_EP_RCCL) {
+        x.dst = (char*)e->ybuf;
+        if ((rc = umoe_ep_pull(x, s))) return rc;
+        PROF(K_DISPATCH);
+    }
+    // ---- combine + residual -> next layer input (as in run_layer)
+    umoe_combine_args cb{};
+    cb.y_slots = e->ybuf; cb.shared_row0 = -1; cb.slot_of = nullptr; cb.moe_w = e->r_moe;
+    cb.expert_mask = ra.expert_mask; cb.mask_ld = E; cb.dense_rows = n_tok;
+    cb.y_shared = c.n_fix ? e->ybuf + (size_t)n_tok * c.n_real * D : nullptr; cb.global_w = e->r_global;
+    cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
+    cb.norm_w = (l + 1 < c.layers) ? e->layers[l + 1].w.in_norm : e->final_norm; cb.norm_out = e->hin; cb.rms_eps = c.rms_eps;
+    rc = umoe_unpermute_combine_fwd(&cb, s);
+    PROF(K_COMBINE);
+    return rc;
+}
 
 // ------------------------------------------------------------------------------------ one layer
 static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStream_t s) {
@@ -395,6 +618,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     }
     if (rc) return rc;
     PROF(K_OPROJ);
+    if (e->ep_decode(n_tok)) return run_moe_ep(e, l, n_tok, s);
     if (e->overlap_shared && c.n_fix > 0) {   // fork: shared experts on s2 (x1 -> RMSNorm -> SwiGLU -> down)
         UMOE_HIP(hipEventRecord(e->ev_fork, s));
         UMOE_HIP(hipStreamWaitEvent(e->s2, e->ev_fork, 0));
@@ -524,6 +748,8 @@ extern "C" int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint
     const umoe_engine_cfg& c = e->c;
     UMOE_REQUIRE(T < c.Lmax, "umoe_engine_prefill: prompt length %d does not fit Lmax %d", T, c.Lmax);
     UMOE_REQUIRE(e->final_norm, "umoe_engine_prefill: globals not set");
+    UMOE_REQUIRE(c.ep_size == 1 || e->ep_mode >= 0, "umoe_engine_prefill: expert parallel engine is not connected (umoe_engine_ep_connect)");
+    UMOE_REQUIRE(c.ep_size == 1 || (c.rows * T >= 64 && e->tiled_prefill), "umoe_engine_prefill: expert parallel prefill runs replicated on the tiled path: needs rows*T >= 64 (got %d)", c.rows * T);
     hipStream_t s = (hipStream_t)stream;
     const int n_tok = c.rows * T;
     int rc;
@@ -569,8 +795,9 @@ extern "C" int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint
 // tokens[b][step] -> tok_in (CFG row doubling, model.py:945), positions / cache slots from device state
 __global__ void step_prep_kernel(const int32_t* __restrict__ tokens, const int32_t* __restrict__ state, int B, int C,
                                  int Tmax, int T_prompt, int Lmax, const int32_t* __restrict__ valid_count,
-                                 int32_t* tok_in, int32_t* pos3, int32_t* kv_pos, int32_t* q_pos0) {
+                                 int32_t* tok_in, int32_t* pos3, int32_t* kv_pos, int32_t* q_pos0, uint32_t* ep_step) {
     const int row = blockIdx.x, b = row >> 1;
+    if (row == 0 && threadIdx.x == 0) ep_step[0] += 1u;   // epoch base of this step's expert-parallel hand-offs (read by later launches)
     const int step = state[4 * B];
     const int n_dec = step - state[4 * B + 4];  // state[4B+4] = dec_step of the first decode call
     const int ts = min(max(step, 0), Tmax - 1);
@@ -593,7 +820,7 @@ static int enqueue_step(umoe_engine* e, const umoe_decode_io* io, hipStream_t s)
     int rc;
     PROF(-1);
     step_prep_kernel<<<dim3((unsigned)c.rows), 64, 0, s>>>(io->tokens, io->state, B, C, c.Tmax, e->T_prompt, c.Lmax,
-                                                           e->valid_count, e->tok_in, e->pos3, e->kv_pos, e->q_pos0);
+                                                           e->valid_count, e->tok_in, e->pos3, e->kv_pos, e->q_pos0, e->ep_words);
     UMOE_LAUNCH_CHECK();
     if ((rc = umoe_codec_embed_sum(e->tok_in, e->codec_emb, c.rows, C, V, c.hidden, e->x, s))) return rc;
     if ((rc = umoe_rmsnorm_residual_fwd(e->x, nullptr, e->layers[0].w.in_norm, c.rms_eps, c.rows, c.hidden, nullptr, e->hin, s)))
@@ -688,6 +915,8 @@ extern "C" const void* umoe_engine_buffer(umoe_engine* e, const char* name, size
         {"k_cache", e->k_cache, (size_t)c.layers * c.rows * c.kv_heads * c.Lmax * c.head_dim * 2},
         {"v_cache", e->v_cache, (size_t)c.layers * c.rows * c.kv_heads * c.Lmax * c.head_dim * 2},
         {"counts", e->counts, (size_t)c.n_real * 4},
+        {"xg", e->xg, (size_t)(c.ep_size > 1 ? c.ep_size : 0) * c.rows * c.hidden * 2},
+        {"ep_words", e->ep_words, 8},
     };
     for (const Item& it : items)
         if (!strcmp(it.n, name)) {

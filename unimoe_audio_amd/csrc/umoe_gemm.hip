@@ -494,6 +494,14 @@ static bool use8(const umoe_gemm_args* a, int nt) {
 // n-blocks per workgroup: more blocks amortise the activation staging, fewer blocks give more workgroups
 template <int PRO, int EPI>
 static int launch_gemm_nt(const umoe_gemm_args* a, int nt, hipStream_t s) {
+    // 8-wave / 2-step-chunk variants of the small tiles: the SAME K split as the 6-block down-projection launch of the dense
+    // decode, so a product computed in a launch of its own (expert parallel: shared experts beside the exchange) is
+    // bit-identical to the one computed inside the big launch
+    if constexpr (PRO == UMOE_PRO_PLAIN && EPI == UMOE_EPI_BF16) {
+        if (a->waves == 8 && nt == 1) return launch_gemm<1, 2, PRO, EPI, 8>(a, s);
+        if (a->waves == 8 && nt == 2) return launch_gemm<2, 2, PRO, EPI, 8>(a, s);
+        if (a->waves == 8 && nt == 4) return launch_gemm<4, 2, PRO, EPI, 8>(a, s);
+    }
     switch (nt) {
         case 1: return launch_gemm<1, 16, PRO, EPI>(a, s);   // 16 k-steps per wave at K=2048: the whole stream is requested up front
         case 2: return launch_gemm<2, 8, PRO, EPI>(a, s);
@@ -570,6 +578,9 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
             }
             const int nt = auto_nt(a, true);
             UMOE_REQUIRE(nt >= 2, "umoe_grouped_gemm: SwiGLU needs nt >= 2");
+            // (8 waves, 1-step chunks: the K split of the 14-block dense decode launch -- see launch_gemm_nt)
+            if (nt == 2 && a->waves == 8) return launch_gemm<2, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s);
+            if (nt == 4 && a->waves == 8) return launch_gemm<4, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s);
             if (nt == 2) return launch_gemm<2, 8, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
             if (nt == 4) return launch_gemm<4, 4, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);
             if (nt == 6) return launch_gemm<6, 2, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU>(a, s);

@@ -131,3 +131,86 @@ def ep_moe(h: torch.Tensor, disp: dict, n_real: int, ep_size: int, group,
     y = expert_fn(recv, recv_cnt)
     back = ep_return(y, group)
     return back.reshape(-1, back.shape[-1]), ep_slot_of(disp["slot_of"], disp["offsets"], S, ep_size)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Expert parallel DECODE: the exchange lives inside the engine's captured step graph (include/umoe.h "Peer exchange").
+class EpLink:
+    """How the decode engines of an expert-parallel job reach each other.
+
+    mode "peer"     one process per GPU: every rank exports its engine's exchange region as a HIP IPC handle, the handles
+                    travel over `group` (any torch.distributed backend; objects, once) and every rank maps its peers'
+                    regions -- afterwards the step graph stores straight into the peers' memory over xGMI.
+         "rccl"     the same exchange as ncclAllGather + grouped ncclSend/ncclRecv on a communicator of the C-ABI
+                    (UmoeEpComm), enqueued by the library on the engine's stream.
+         "loopback" single-GPU emulation of ONE rank of a `size`-rank job (timing only, see umoe_engine_ep_connect).
+    `EpLink.local_mesh(engines)` connects several engines of ONE process (virtual ranks on one GPU: the parity test)."""
+
+    def __init__(self, rank: int = 0, size: int = 1, mode: str = "peer", group=None, device=None):
+        assert mode in ("peer", "rccl", "loopback"), mode
+        self.rank, self.size, self.mode, self.group, self.device = int(rank), int(size), mode, group, device
+        self._opened = []
+        self._comm: Optional[UmoeEpComm] = None
+
+    @classmethod
+    def from_dist(cls, mode: str = "peer", group=None, device=None) -> "EpLink":
+        return cls(dist.get_rank(group), dist.get_world_size(group), mode, group, device)
+
+    def connect(self, engine_handle):
+        """Collective over `group` (every rank calls it with its own freshly created engine)."""
+        import ctypes as C
+        from . import _lib as L
+        lib = L.lib()
+        if self.mode == "loopback":
+            L.check(lib.umoe_engine_ep_connect(engine_handle, None, None, L.EP_LOOPBACK), "umoe_engine_ep_connect")
+            return
+        if self.mode == "rccl":
+            if self._comm is None:
+                self._comm = UmoeEpComm(self.group, self.device)
+            L.check(lib.umoe_engine_ep_connect(engine_handle, None, self._comm.h, L.EP_RCCL), "umoe_engine_ep_connect")
+            return
+        base, nbytes = C.c_void_p(), C.c_size_t()
+        L.check(lib.umoe_engine_ep_region(engine_handle, C.byref(base), C.byref(nbytes)), "umoe_engine_ep_region")
+        raw = (C.c_char * 64)()
+        L.check(lib.umoe_ep_ipc_export(base, C.cast(raw, C.c_void_p)), "umoe_ep_ipc_export")
+        mine = (bytes(raw), int(nbytes.value))
+        every = [None] * self.size
+        dist.all_gather_object(every, mine, group=self.group)
+        peers = (C.c_void_p * L.MAX_EP)()
+        for p, (h, nb) in enumerate(every):
+            if nb != mine[1]:
+                raise L.UmoeError(f"expert-parallel engines disagree on the exchange region size (rank {p}: {nb} != {mine[1]})")
+            if p == self.rank:
+                peers[p] = base.value
+                continue
+            ptr = C.c_void_p()
+            hb = (C.c_char * 64).from_buffer_copy(h)
+            L.check(lib.umoe_ep_ipc_open(C.cast(hb, C.c_void_p), C.byref(ptr)), f"umoe_ep_ipc_open (rank {p})")
+            self._opened.append(ptr)
+            peers[p] = ptr.value
+        L.check(lib.umoe_engine_ep_connect(engine_handle, peers, None, L.EP_PEER), "umoe_engine_ep_connect")
+        dist.barrier(group=self.group)          # nobody steps before every rank has mapped every region
+
+    @staticmethod
+    def local_mesh(engine_handles):
+        """Virtual ranks: engines of one process on one GPU store into each other's regions directly."""
+        import ctypes as C
+        from . import _lib as L
+        lib = L.lib()
+        bases = []
+        for h in engine_handles:
+            base, nbytes = C.c_void_p(), C.c_size_t()
+            L.check(lib.umoe_engine_ep_region(h, C.byref(base), C.byref(nbytes)), "umoe_engine_ep_region")
+            bases.append(base.value)
+        for h in engine_handles:
+            peers = (C.c_void_p * L.MAX_EP)(*bases)
+            L.check(lib.umoe_engine_ep_connect(h, peers, None, L.EP_PEER), "umoe_engine_ep_connect")
+
+    def close(self):
+        from . import _lib as L
+        for ptr in self._opened:
+            L.lib().umoe_ep_ipc_close(ptr)
+        self._opened = []
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None

@@ -273,13 +273,19 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
                                                   all_router_weight=out.all_router_weight, aux_balance_loss=aux_mean)
 
     # ---- engine -----------------------------------------------------------------------------------------
-    def engine(self, batch: int, max_prompt: int, max_tokens: int, attn_splits: int = 8) -> "DecodeEngine":
+    def _pack_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def engine(self, batch: int, max_prompt: int, max_tokens: int, attn_splits: int = 8, ep=None) -> "DecodeEngine":
+        """The decode engine for this shape, rebuilt when the shape, the weights (data pointer / version of any parameter) or the
+        expert-parallel link changed.  `ep`: an unimoe_audio_amd.ep.EpLink (every rank of the link calls this together)."""
         need_L = max_prompt + max_tokens + 8
         e = self._engine
-        if e is None or e.batch != batch or e.Lmax < need_L or e.Tmax < max_tokens + 64:
+        key = self._pack_key()
+        if e is None or e.batch != batch or e.Lmax < need_L or e.Tmax < max_tokens + 64 or e.pack_key != key or e.ep is not ep:
             if e is not None:
                 e.close()
-            self._engine = DecodeEngine(self, batch, Lmax=need_L, Tmax=max_tokens + 64, attn_splits=attn_splits)
+            self._engine = DecodeEngine(self, batch, Lmax=need_L, Tmax=max_tokens + 64, attn_splits=attn_splits, ep=ep)
         return self._engine
 
     @torch.no_grad()
@@ -315,7 +321,7 @@ class DecodeEngine:
     """Python face of umoe_engine_*: packs the weights once, owns the C engine and the decode state."""
 
     def __init__(self, model: UniAudioRVQQwen2_5VLMoEForConditionalGeneration, batch: int, Lmax: int, Tmax: int,
-                 attn_splits: int = 8, max_pos: Optional[int] = None):
+                 attn_splits: int = 8, max_pos: Optional[int] = None, ep=None, ep_connect: bool = True):
         cfg = model.config
         dev = model.device
         if dev.type != "cuda":
@@ -331,12 +337,17 @@ class DecodeEngine:
                         pad=cfg.codec_pad_value, bos=cfg.codec_bos_value, mrope0=sec[0], mrope1=sec[1], mrope2=sec[2],
                         rms_eps=cfg.rms_norm_eps, top_p=float(cfg.mlp_dynamic_top_p), fixed_top_k=int(cfg.mlp_dynamic_top_k),
                         jitter_eps=float(cfg.router_jitter_noise), rows=self.rows, Lmax=self.Lmax, Tmax=self.Tmax,
-                        attn_splits=attn_splits, ep_rank=0, ep_size=1)
+                        attn_splits=attn_splits, ep_rank=0 if ep is None else ep.rank, ep_size=1 if ep is None else ep.size)
+        self.ep = ep
+        self.ep_rank, self.ep_size = (0, 1) if ep is None else (ep.rank, ep.size)
+        self.pack_key = model._pack_key()
         h = C.c_void_p()
         L.check(L.lib().umoe_engine_create(C.byref(c), C.byref(h)), "umoe_engine_create")
         self.h = h
         self.keep: List[torch.Tensor] = []
         self._pack_weights()
+        if ep is not None and ep.size > 1 and ep_connect:
+            ep.connect(self.h)
         self.tokens = None
         self.state = None
         self.io = None
@@ -359,7 +370,12 @@ class DecodeEngine:
             qkv_w, qkv_b, o_w, pk = lp["qkv_w"], lp["qkv_b"], lp["o_w"], lp["moe"]
             n_real, n_fix = cfg.mlp_dynamic_expert_num, cfg.mlp_fixed_expert_num
             arr = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.data_ptr() for t in ts])
-            eg, ed, sg, sd = arr(pk["exp_gu"]), arr(pk["exp_dn"]), arr(pk["sh_gu"]), arr(pk["sh_dn"])
+            # expert parallel: this rank streams its n_real / ep_size local experts (core.py:505) at decode; the prefill runs
+            # replicated on the row-major tensors of all experts
+            e_loc = n_real // self.ep_size
+            lo = self.ep_rank * e_loc
+            eg, ed = arr(pk["exp_gu"][lo:lo + e_loc]), arr(pk["exp_dn"][lo:lo + e_loc])
+            sg, sd = arr(pk["sh_gu"]), arr(pk["sh_dn"])
             # row-major originals (the module's own parameters) for the tiled MFMA kernels of the prefill
             ex = layer.mlp.dynamic_real_moe.deepspeed_moe.experts.deepspeed_experts
             sh = layer.mlp.fixed_real_moe
@@ -444,7 +460,23 @@ class DecodeEngine:
         return {k: (ms[i] / max(cnt[i], 1), cnt[i] // n) for i, k in enumerate(self.KINDS)}
 
     def all_done(self) -> bool:
-        return bool(int(self.state[4 * self.batch + 2].item()))
+        done = bool(int(self.state[4 * self.batch + 2].item()))
+        if self.ep is not None and self.ep.size > 1 and self.ep.mode != "loopback" and self.ep.group is not False:
+            # expert parallel: every rank keeps stepping until ALL are done (a rank that stopped would starve its peers' receives)
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                t = torch.tensor([1 if done else 0], dtype=torch.int32)
+                if dist.get_backend(self.ep.group) == "nccl":
+                    t = t.to(self.dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.ep.group)
+                done = bool(int(t.item()))
+        return done
+
+    def ep_error(self) -> int:
+        """0, or 1 when a receive of the expert-parallel exchange timed out (sticky); synchronises the current stream."""
+        code = C.c_int()
+        L.check(L.lib().umoe_engine_ep_error(self.h, self._stream(), C.byref(code)), "umoe_engine_ep_error")
+        return int(code.value)
 
     def run(self, use_graph: bool = True, poll_every: int = 16, max_steps: Optional[int] = None):
         """Decode until every sequence finished (reference loop head, model.py:1149-1151).  The device decides;

@@ -198,6 +198,7 @@ def forward_train(model, input_ids, codec_input_ids, attention_mask, codec_label
     codec_loss = CodecCEFn.apply(sl, lab)
     aux_mean = torch.stack([a_.float() for a_ in auxes]).mean()
     loss = codec_loss + model.cur_aux_weight * aux_mean
+    model.training_steps = getattr(model, "training_steps", 0) + 1      # model.py:827 (weight read before the increment)
     return (loss, codec_loss, aux_mean, routing) if return_routing else (loss, codec_loss, aux_mean)
 
 
