@@ -39,48 +39,68 @@ def parse():
     ap.add_argument("--layers", type=int, default=0, help="debug only: override num_hidden_layers (0 = 36)")
     ap.add_argument("--codec-channels", type=int, default=0,
                     help="0 = the reference's 12 channels (16 kHz DAC, 50 frames/s); 9 = the 44.1 kHz reading of BASELINE (SURVEY 8d: delay [0,8..15], 86.1 frames/s)")
-    ap.add_argument("--parallel", default="auto", choices=["auto", "ep", "replica"])
+    ap.add_argument("--parallel", default="auto", choices=["auto", "ep", "replica"],
+                    help="N > 1: ep = expert-parallel decode (BASELINE configs[3] layout: batch-sharded rows, n_real/N routed experts per "
+                         "GPU, exchange inside the step graph); replica = N independent full models; auto = ep")
+    ap.add_argument("--ep-backend", default=os.environ.get("UMOE_EP_BACKEND", "peer"), choices=["peer", "rccl"],
+                    help="exchange of the expert-parallel step: xGMI peer stores (default) or RCCL calls captured in the graph")
+    ap.add_argument("--ep-emulate", type=int, default=0,
+                    help="single GPU only: time ONE rank of an N-rank expert-parallel job in loopback (no peers; a kernel-time proxy, "
+                         "reported as a secondary field, never as `value`)")
+    ap.add_argument("--no-replica-check", action="store_true", help="N > 1, ep: skip the replica leg (secondary number + bit check)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[0] (single prompt) legs")
     ap.add_argument("--cpu-steps", type=int, default=5)
     return ap.parse_args()
 
 
-def synth_prompt(cfg, B, T, device):
-    g = torch.Generator().manual_seed(11)
+def synth_prompt(cfg, B, T, device, rank=0):
+    g = torch.Generator().manual_seed(11 + 1000 * rank)
     ids = torch.randint(0, 151643, (2 * B, T), generator=g)
     am = torch.ones(2 * B, T, dtype=torch.long)
     n_codec = min(245, T - 8)
     ids[:, -n_codec - 3:-3] = cfg.codec_placeholder_value
     am[0::2, :17] = 0                                  # negative prompts are shorter: left padding on uncond rows
-    g.manual_seed(7)
+    g.manual_seed(7 + 1000 * rank)
     codec = torch.randint(0, 1024, (2 * B * n_codec, cfg.codec_channels), generator=g)
     return ids.to(device), am.to(device), codec.to(device)
 
 
-def gpu_run(args, rank, world, device):
-    from unimoe_audio_amd.codec_utils import prepare_audio_prompt
+def make_cfg(args):
     from unimoe_audio_amd.config import UniMoEAudioConfig
-    from unimoe_audio_amd.model import UniAudioRVQQwen2_5VLMoEForConditionalGeneration
-
     cfg = UniMoEAudioConfig()
     if args.layers:
         cfg.num_hidden_layers = args.layers
     if args.codec_channels:
         cfg.codec_channels = args.codec_channels
         cfg.codec_delay_pattern = [0] + list(range(8, 8 + args.codec_channels - 1))
-    B, T, K, W = args.batch, args.prompt, args.steps, args.warmup
+    return cfg
+
+
+def build_model(cfg, device):
+    from unimoe_audio_amd.model import UniAudioRVQQwen2_5VLMoEForConditionalGeneration
     t0 = time.time()
     torch.set_default_dtype(torch.bfloat16)
     with torch.device(device):
         model = UniAudioRVQQwen2_5VLMoEForConditionalGeneration(cfg)
     torch.set_default_dtype(torch.float32)
-    model.init_synthetic(1234).eval()
+    model.init_synthetic(1234).eval()          # same seed on every rank: expert-parallel ranks hold slices of ONE model
     torch.cuda.synchronize()
-    t_build = time.time() - t0
+    return model, time.time() - t0
+
+
+def decode_leg(model, cfg, args, device, rank, B, ep=None, profile=True, steps=None, warmup=None):
+    """prefill + W warm-up steps + K timed steps of one engine; the timed region is bracketed by barrier + synchronize."""
+    from unimoe_audio_amd.codec_utils import prepare_audio_prompt
+    from unimoe_audio_amd.model import DecodeEngine
+    T = args.prompt
+    K = args.steps if steps is None else steps
+    W = args.warmup if warmup is None else warmup
     max_tokens = K + W + 64
-    eng = model.engine(B, T, max_tokens, attn_splits=int(os.environ.get("UMOE_ATTN_SPLITS", "8")))   # (experiment knob; 8 measured best)
-    ids, am, codec = synth_prompt(cfg, B, T, device)
+    eng = DecodeEngine(model, B, Lmax=T + max_tokens + 8, Tmax=max_tokens + 64,
+                       attn_splits=int(os.environ.get("UMOE_ATTN_SPLITS", "8")), ep=ep)     # (experiment knob; 8 measured best)
+    ids, am, codec = synth_prompt(cfg, B, T, device, rank)
     x = model.calculate_input_embedding(ids, codec)
     torch.cuda.synchronize()
     t1 = time.time()
@@ -94,71 +114,118 @@ def gpu_run(args, rank, world, device):
     use_graph = not args.no_graph
     for _ in range(W):
         eng.step(use_graph)
-    barrier(world)
+    torch.cuda.synchronize()
+    barrier()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     for _ in range(K):
         eng.step(use_graph)
     torch.cuda.synchronize()
-    barrier(world)
+    barrier()
     dt = time.perf_counter() - t2
-    # which experts were hit (last step, every layer) -> algorithmic bytes of the dominant kernel
     E = cfg.num_experts
     masks = eng.copy_buffer("all_mask", torch.int32, (cfg.num_hidden_layers, 2 * B, E)).cpu()
-    hit = (masks[:, :, : cfg.mlp_dynamic_expert_num].sum(1) > 0).sum(1).float()          # |U_l| per layer
+    hit = (masks[:, :, : cfg.mlp_dynamic_expert_num].sum(1) > 0).sum(1).float()          # |U_l| per layer (last step)
     topk = eng.copy_buffer("all_topk", torch.int64, (cfg.num_hidden_layers, 2 * B)).cpu().float()
-    prof = eng.profile_steps(4)
-    info = dict(t_build=t_build, t_prefill=t_prefill, mean_experts_hit=float(hit.mean()), mean_top_k=float(topk.mean()),
-                prof=prof, cfg=cfg, kv_len_end=T + W + K + 4)
-    return dt, info
+    tokens = eng.tokens[:, : K + W + 2].cpu().clone()
+    prof = eng.profile_steps(4) if profile else None
+    err = eng.ep_error() if ep is not None else 0
+    if ep is not None:
+        barrier()                     # peers may still be reading this rank's exchange region
+    info = dict(dt=dt, t_prefill=t_prefill, mean_experts_hit=float(hit.mean()), mean_top_k=float(topk.mean()), prof=prof,
+                kv_len_first=T + W, kv_len_end=T + W + K, tokens=tokens, ep_error=err, steps=K)
+    eng.close()
+    return info
 
 
-def barrier(world):
+def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
 
 
-def roofline(info):
-    cfg = info["cfg"]
+def max_over_ranks(v: float) -> float:
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return v
+    t = torch.tensor([v], dtype=torch.float64)          # CPU tensor: the control plane runs on gloo
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def step_bytes(cfg, rows, kv_mean, experts_hit, ep=1):
+    """Algorithmic HBM bytes of ONE decode step of ONE GPU: per layer attention + shared experts + gate + norms
+    (52.75 MB at the reference sizes) + 33.82 MB per routed expert streamed (|U_l| of them; expert parallel: the n_real/ep local
+    ones), the KV read 1 KiB per cached token per row per layer, the codec head; activations left out (< 0.1 %)."""
+    D, H, KV, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    Id, Is, E = cfg.dynamic_intermediate_size, cfg.shared_intermediate_size, cfg.num_experts
+    attn = (H * hd + 2 * KV * hd) * D + (H * hd + 2 * KV * hd) + D * H * hd
+    per_layer = 2.0 * (attn + cfg.mlp_fixed_expert_num * 3 * Is * D + E * D + 2 * D)
+    routed = 2.0 * 3 * Id * D * (experts_hit if ep == 1 else cfg.mlp_dynamic_expert_num / ep)
+    kv = 2.0 * 2 * KV * hd * kv_mean * rows
+    head = 2.0 * cfg.codec_channels * cfg.codec_vocab_size * D
+    return cfg.num_hidden_layers * (per_layer + routed + kv) + head
+
+
+PROFILE_REF = os.path.join(ROOT, "profiles", "bench_roofline_ref.json")   # rocprofv3 figures of this same command (committed)
+
+
+def roofline(cfg, info, args, ep=1):
+    """Dominant kernel = the grouped gate/up SwiGLU launch (HBM-bound weight streaming).  achieved = algorithmic bytes per launch
+    / its average HIP-event interval on the launch stream, measured live in this run (eager pass right after the timed region)."""
     D, Id, Is = cfg.hidden_size, cfg.dynamic_intermediate_size, cfg.shared_intermediate_size
     U = info["mean_experts_hit"]
-    # algorithmic bytes of ONE launch of the grouped gate/up SwiGLU kernel: gate+up weights of every
-    # routed expert hit + of the shared experts, bf16; activations (16 x 2048) and outputs are < 0.3 % and left out
-    bytes_per_launch = (U * 2 * Id * D + cfg.mlp_fixed_expert_num * 2 * Is * D) * 2.0
+    n_fix, n_real = cfg.mlp_fixed_expert_num, cfg.mlp_dynamic_expert_num
     ms, n = info["prof"]["gateup"]
+    if ep == 1:
+        # gate+up weights of every routed expert hit + of the shared experts, bf16 (SURVEY.md 8d); activations / outputs < 0.3 %
+        bytes_per_launch = (U * 2 * Id * D + n_fix * 2 * Is * D) * 2.0
+        kname = "wstream_gemm<14, 1, 0, 2, 8, true>"
+        what = " (grouped gate/up SwiGLU, 8 routed + 2 shared experts in one launch; 16 of its tile-less workgroups run the Top-P router)"
+    else:
+        # expert parallel: two gate/up launches per layer (shared experts beside the exchange, then the local experts over the
+        # ep*16 gathered rows); algorithmic bytes = each weight once
+        bytes_per_launch = ((n_real / ep) * 2 * Id * D + n_fix * 2 * Is * D) * 2.0 / 2
+        kname = "wstream_gemm<14, 1, 0, 2, 8, true> + wstream_gemm<2, 1, 0, 2, 8, false>"
+        what = f" (expert parallel x{ep}: local experts' and shared experts' gate/up launches, averaged)"
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    kname = "wstream_gemm<14, 1, 0, 2, 8, true>"
-    traffic = None
-    try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/)
-        with open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")) as f:
-            traffic = json.load(f)["kernels"][kname]["traffic_bytes"]
-    except Exception:
-        pass
-    return {"bound": "hbm", "kernel": kname + " (grouped gate/up SwiGLU, 8 routed + 2 shared experts in one launch; 16 of its tile-less workgroups run the Top-P router)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(ms * 1e3, 2),
-            "launches_per_step": n, "experts_hit_per_layer": round(U, 2),
-            "note": "achieved = algorithmic bytes / HIP-event interval on the launch stream (eager profiling pass right after the "
-                    "timed region; the interval includes the launch gap, rocprofv3 durations are in profiles/r01h_decode_kernels.md); "
-                    "traffic = FETCH_SIZE*2 + WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r01h_pmc_traffic.md)"}
+    K = info["steps"]
+    kv_mean = (info["kv_len_first"] + info["kv_len_end"] + 1) / 2.0
+    sb = step_bytes(cfg, 2 * args.batch, kv_mean, U, ep)
+    step_gbs = sb / (info["dt"] / K) / 1e9
+    out = {"bound": "hbm", "kernel": kname + what, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+           "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(ms * 1e3, 2), "launches_per_step": n,
+           "experts_hit_per_layer": round(U, 2),
+           "step_bytes": int(sb), "step_achieved": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+           "note": "achieved = algorithmic bytes / HIP-event interval on the launch stream (live, eager pass after the timed region; "
+                   "the interval includes the launch gap); step_* = SURVEY 8d bytes of a whole decode step (measured |U_l|, mean KV "
+                   "length of the timed steps) / ms_per_step; traffic / rocprof_kernel_us are NOT measured by this run: they are "
+                   "read from the committed rocprofv3 passes named in traffic_source"}
+    if ep == 1:
+        try:
+            with open(PROFILE_REF) as f:
+                ref = json.load(f)
+            out["traffic"] = ref["traffic_bytes"]
+            out["traffic_source"] = ref["source"]
+            out["rocprof_kernel_us"] = ref["kernel_us"]
+        except Exception:
+            pass
+    return out
 
 
-def cpu_baseline(args):
+_CPU_W = {}
+
+
+def cpu_baseline(args, batch=None, steps=None):
     """The CPU oracle (oracle/decode.py, reference-like torch-CPU path) on a bounded sample: `cpu_steps` decode steps of
     the full 36-layer model at batch 8 (16 rows) with a synthetic 300-token KV cache, greedy sampling."""
     from oracle import decode as OD
-    from unimoe_audio_amd.config import UniMoEAudioConfig
-    cfg = UniMoEAudioConfig()
-    if args.layers:
-        cfg.num_hidden_layers = args.layers
-    if args.codec_channels:
-        cfg.codec_channels = args.codec_channels
-        cfg.codec_delay_pattern = [0] + list(range(8, 8 + args.codec_channels - 1))
+    cfg = make_cfg(args)
     torch.manual_seed(0)
     bf = torch.bfloat16
     D, H, KV, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-    w = {}
+    w = _CPU_W          # (the second call -- BASELINE configs[0], batch 1 -- reuses the 14 GB of synthetic weights)
 
     proto = {}
 
@@ -169,7 +236,7 @@ def cpu_baseline(args):
             proto[shape] = (torch.randn(*shape) * 0.02).to(bf)
             return proto[shape]
         return proto[shape].clone()
-    for l in range(cfg.num_hidden_layers):
+    for l in range(cfg.num_hidden_layers if not w else 0):
         p = f"language_model.layers.{l}."
         w[p + "input_layernorm.weight"] = torch.ones(D, dtype=bf)
         w[p + "post_attention_layernorm.weight"] = torch.ones(D, dtype=bf)
@@ -186,11 +253,13 @@ def cpu_baseline(args):
             q = p + f"mlp.fixed_real_moe.{i}."
             w[q + "gate_proj.weight"], w[q + "up_proj.weight"] = rnd(cfg.shared_intermediate_size, D), rnd(cfg.shared_intermediate_size, D)
             w[q + "down_proj.weight"] = rnd(D, cfg.shared_intermediate_size)
-    w["language_model.norm.weight"] = torch.ones(D, dtype=bf)
-    for c in range(cfg.codec_channels):
-        w[f"codec_embed_tokens.{c}.weight"] = rnd(cfg.codec_vocab_size, D)
-    w["codec_head.weight"] = rnd(cfg.codec_channels * cfg.codec_vocab_size, D)
-    B, L = args.batch, args.prompt
+    if "codec_head.weight" not in w:
+        w["language_model.norm.weight"] = torch.ones(D, dtype=bf)
+        for c in range(cfg.codec_channels):
+            w[f"codec_embed_tokens.{c}.weight"] = rnd(cfg.codec_vocab_size, D)
+        w["codec_head.weight"] = rnd(cfg.codec_channels * cfg.codec_vocab_size, D)
+    B, L = (args.batch if batch is None else batch), args.prompt
+    n_steps = args.cpu_steps if steps is None else steps
     rows = 2 * B
     tm = OD.TextModelOracle(cfg, w)
     cache = [(torch.randn(rows, KV, L, hd).to(bf), torch.randn(rows, KV, L, hd).to(bf)) for _ in range(cfg.num_hidden_layers)]
@@ -198,7 +267,7 @@ def cpu_baseline(args):
     tok = torch.randint(0, 1024, (B, 1, cfg.codec_channels))
     times = []
     with torch.no_grad():
-        for s in range(args.cpu_steps + 1):
+        for s in range(n_steps + 1):
             t0 = time.perf_counter()
             key_valid = torch.cat([key_valid, torch.ones(rows, 1, dtype=torch.bool)], -1)
             pos = (key_valid.long().cumsum(-1) - 1)[:, -1:]
@@ -212,75 +281,159 @@ def cpu_baseline(args):
     sec = steady[len(steady) // 2]                       # median
     return {"value": round(B / sec, 3), "unit": "audio-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"median of {len(steady)} decode steps (after 1 warm-up) of the full {cfg.num_hidden_layers}-layer model, batch {B} "
-                      f"(16 CFG rows), synthetic KV cache of {L} tokens, torch-CPU bf16 oracle (oracle/decode.py), "
+                      f"({2 * B} CFG rows), synthetic KV cache of {L} tokens, torch-CPU bf16 oracle (oracle/decode.py), "
                       f"{sec * 1e3:.0f} ms/step"}
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks (one per GPU) BEFORE anything here touches the GPU, as child
+        # processes of this one (a process that initialised the GPU must never be replaced by another program)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()                   # (does not initialise the GPU)
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    shared_gpu = world > ndev                          # rehearsal of N ranks on fewer GPUs: ranks share cards, no RCCL
+    torch.cuda.set_device(local % ndev)
+    device = torch.device("cuda", local % ndev)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    mode = args.parallel
-    dist_on = world > 1 or "RANK" in os.environ
-    if dist_on:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    rccl_ranks = 0
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        try:
-            dist.init_process_group("nccl", device_id=device)          # "nccl" is RCCL on ROCm
-            probe = torch.ones(1, device=device)
-            dist.all_reduce(probe)
-            torch.cuda.synchronize()
-        except Exception as e:  # keep the scaling run alive: the replica mode only needs a barrier and a MAX of one scalar
-            print(f"[bench] RCCL init failed ({e!r}); falling back to gloo for the barrier/reduce", file=sys.stderr)
-            if dist.is_initialized():
-                dist.destroy_process_group()
+        # control plane (barriers, MAX of the wall time, IPC handles) on gloo; RCCL ("nccl" on ROCm) for device collectives
+        if shared_gpu:
             dist.init_process_group("gloo")
-    if world > 1:
-        if mode in ("auto", "ep"):
-            # the in-engine RCCL exchange is the next step: this round every rank runs a full replica
-            mode = "replica"
-    else:
-        mode = "single"
-    dt, info = gpu_run(args, rank, world, device)
-    if dist_on:
-        import torch.distributed as dist
-        on_gpu = dist.get_backend() == "nccl"
-        t = torch.tensor([dt], device=device if on_gpu else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)                        # the slowest rank defines the step time
-        dt = float(t.item())
+        else:
+            dist.init_process_group("cpu:gloo,cuda:nccl", device_id=device)
+            try:
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)                   # RCCL over xGMI is up: every rank contributed
+                torch.cuda.synchronize()
+                rccl_ranks = int(probe.item())
+            except Exception as e:
+                print(f"[bench] rank {rank}: RCCL all-reduce failed ({e!r})", file=sys.stderr)
+    mode = "single" if world == 1 else ("replica" if args.parallel == "replica" else "ep")
+    cfg = make_cfg(args)
     B, K, W = args.batch, args.steps, args.warmup
-    if rank == 0:
+    model, t_build = build_model(cfg, device)
+    notes = {}
+    ep_info = None
+    if mode == "ep":
+        from unimoe_audio_amd.ep import EpLink
+        backends = [args.ep_backend] + [b for b in ("peer", "rccl") if b != args.ep_backend and not (b == "rccl" and shared_gpu)]
+        for be in backends:
+            # a backend that cannot be set up, or whose exchange times out in a short rehearsal, is skipped by ALL ranks together
+            ok, why = 1, ""
+            link = None
+            try:
+                link = EpLink.from_dist(be, None, device)
+                trial = decode_leg(model, cfg, args, device, rank, B, ep=link, profile=False, steps=4, warmup=2)
+                if trial["ep_error"]:
+                    ok, why = 0, "receive timed out"
+            except Exception as e:
+                ok, why = 0, repr(e)
+            ok_all = -max_over_ranks(-float(ok))
+            if ok_all >= 1.0:
+                ep_info = decode_leg(model, cfg, args, device, rank, B, ep=link)
+                ep_info["backend"] = be
+                if max_over_ranks(float(ep_info["ep_error"])) == 0.0:
+                    break
+                why = "receive timed out in the timed run"
+                ep_info = None
+            notes[f"ep_backend_{be}"] = f"not used: {why or 'another rank failed'}"
+            if rank == 0:
+                print(f"[bench] expert-parallel backend {be!r} not usable: {why or 'another rank failed'}", file=sys.stderr)
+        if ep_info is None:
+            mode = "replica"
+            notes["ep"] = "no expert-parallel backend worked on this node: `value` is the replica number"
+    rep_info = None
+    if mode != "ep" or not args.no_replica_check:
+        rep_info = decode_leg(model, cfg, args, device, rank, B, profile=(mode != "ep"))
+    info = ep_info if mode == "ep" else rep_info
+    dt = max_over_ranks(info["dt"])                                     # the slowest rank defines the step time
+    out = None
+    if rank == 0 or mode == "ep":
         value = world * B * K / dt
-        cfg = info["cfg"]
+    if mode == "ep" and rep_info is not None:
+        # secondary: N independent replicas on the same prompts and seeds; the expert-parallel tokens must equal them bit for bit
+        same = float(torch.equal(ep_info["tokens"], rep_info["tokens"]))
+        notes["ep_tokens_equal_replica"] = bool(-max_over_ranks(-same) >= 1.0)
+        notes["replica_value"] = round(world * B * K / max_over_ranks(rep_info["dt"]), 2)
+        notes["replica_ms_per_step"] = round(max_over_ranks(rep_info["dt"]) / K * 1e3, 4)
+    if rank == 0:
+        ep = world if mode == "ep" else 1
+        info_dt = dict(info)
+        info_dt["dt"] = dt
         out = {
             "metric": "audio-tokens/sec/node (TTS decode, bs=8 per GPU)", "value": round(value, 2), "unit": "audio-tokens/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: TTS decode batch 8 (16 CFG rows) per GPU, 300-token prompt, "
                                    f"{cfg.num_hidden_layers}-layer DCMoE (8+1 routed, 2 shared), 12x1027 codec head, "
-                                   "CFG 3.0 + top-k 45 + top-p 0.95 sampling, 16 kHz DAC 50 frames/s",
-                       "global_batch": world * B, "prompt_len": args.prompt, "kv_len_end": info["kv_len_end"],
-                       "parallelism": mode + (str(world) if world > 1 else ""), "graph": not args.no_graph,
-                       "codes_per_s": round(value * cfg.codec_channels, 1), "prefill_s": round(info["t_prefill"], 3),
-                       "mean_top_k": round(info["mean_top_k"], 2)},
-            "roofline": roofline(info),
+                                   "CFG 3.0 + top-k 45 + top-p 0.95 sampling, 16 kHz DAC 50 frames/s"
+                                   + ("; N GPUs = BASELINE configs[3] layout (rows batch-sharded, routed experts sharded n_real/N per GPU)"
+                                      if mode == "ep" else ""),
+                       "global_batch": world * B, "prompt_len": args.prompt, "kv_len_end": info["kv_len_end"] + 4,
+                       "parallelism": {"single": "single", "ep": f"ep{world}", "replica": f"replica{world}"}[mode],
+                       "graph": not args.no_graph, "codes_per_s": round(value * cfg.codec_channels, 1),
+                       "prefill_s": round(info["t_prefill"], 3), "mean_top_k": round(info["mean_top_k"], 2)},
+            "roofline": roofline(cfg, info_dt, args, ep),
             "kernel_ms_per_step": {k: round(v[0] * v[1], 4) for k, v in info["prof"].items()},
         }
+        if world > 1:
+            out["config"]["rccl_ranks"] = rccl_ranks
+            out["config"]["ranks_share_gpus"] = shared_gpu
+            if mode == "ep":
+                out["config"]["ep_exchange"] = {"peer": "xGMI peer stores in the step graph (HIP IPC regions)",
+                                                "rccl": "ncclAllGather + grouped ncclSend/ncclRecv captured in the step graph"}[info["backend"]]
+            out["config"].update(notes)
+    if world == 1 and args.ep_emulate > 1:
+        from unimoe_audio_amd.ep import EpLink
+        emu = decode_leg(model, cfg, args, device, 0, B, ep=EpLink(0, args.ep_emulate, "loopback"))
+        out["ep_emulation"] = {"ep_size": args.ep_emulate, "ms_per_step": round(emu["dt"] / K * 1e3, 4),
+                               "audio_tokens_per_s_per_gpu": round(B * K / emu["dt"], 2), "ep_error": emu["ep_error"],
+                               "kernel_ms_per_step": {k: round(v[0] * v[1], 4) for k, v in emu["prof"].items()},
+                               "note": "ONE rank of an expert-parallel job in loopback on one GPU (its own rows stand in for the "
+                                       "peers'): kernel time of the sharded step without xGMI latency; not the model's outputs"}
+    if world == 1 and not args.no_config1:
+        # BASELINE configs[0]: the reference's own CPU-runnable case, one prompt (2 CFG rows: ragged dispatch path), GPU side
+        try:
+            c1 = decode_leg(model, cfg, args, device, 0, 1, profile=False, steps=min(K, 200), warmup=W)
+            out["config1"] = {"workload": "BASELINE configs[0]: single prompt (batch 1 = 2 CFG rows), same model and sampling",
+                              "value": round(c1["steps"] / c1["dt"], 2), "unit": "audio-tokens/s",
+                              "ms_per_step": round(c1["dt"] / c1["steps"] * 1e3, 4), "steps": c1["steps"]}
+        except Exception as e:
+            out["config1"] = {"error": repr(e)}
+    del model
+    torch.cuda.empty_cache()
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
-                out["config"]["gpu_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+                out["config"]["gpu_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+                if "config1" in out and "value" in out["config1"]:
+                    out["config1"]["cpu_baseline"] = cpu_baseline(args, batch=1, steps=3)
             except Exception as e:  # the GPU number must not be lost to a host-side problem
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
-    if dist_on:
-        import torch.distributed as dist
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 

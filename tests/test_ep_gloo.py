@@ -78,6 +78,20 @@ def _worker(rank, world, port, S, out_q):
         ref_moe = one.moe_layer(h, r["expert_mask"][:, :n_real], r["global_weight"][:, :n_real])
         ok = torch.allclose(moe_out.float(), ref_moe.float(), rtol=2 ** -6, atol=2 ** -9)
         out_q.put((rank, bool(ok), float((moe_out.float() - ref_moe.float()).abs().max())))
+        # the DENSE exchange of the decode engine (every row visits every expert, the owner selects by its mask):
+        # layout contract of csrc/umoe_engine.hip run_moe_ep, restated in ep.dense_ep_moe
+        def one_expert(e, xx):
+            return swiglu_mlp(xx, w[EXPERT_FMT.format(e=e, p="gate")], w[EXPERT_FMT.format(e=e, p="up")], w[EXPERT_FMT.format(e=e, p="down")])
+        y_dense = EP.dense_ep_moe(h, one_expert, rank, world, n_real, dist.group.WORLD)      # [n_real, S, D]
+        acc2 = torch.zeros(S, 64)
+        for e in range(n_real):
+            sel = r["expert_mask"][:, e] != 0
+            acc2[sel] += moe_w[sel, e:e + 1] * y_dense[e][sel].float()
+        ok2 = torch.allclose(acc2.to(torch.bfloat16).float(), ref_moe.float(), rtol=2 ** -6, atol=2 ** -9)
+        # and every (expert, row) product is the single-process product, bit for bit (what makes ep == 1 and ep > 1 identical)
+        for e in range(n_real):
+            ok2 = ok2 and torch.equal(y_dense[e], one_expert(e, h))
+        out_q.put((rank + 10, bool(ok2), 0.0))
         # bench.py aggregation: MAX over ranks of the timed region
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -95,12 +109,14 @@ def test_ep_exchange_world2_gloo(S):
     ps = [ctx.Process(target=_worker, args=(r, 2, port, S, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = [q.get(timeout=120) for _ in range(4)]
+    res = [q.get(timeout=120) for _ in range(6)]
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
     oks = [r for r in res if r[0] in (0, 1)]
     assert len(oks) == 2 and all(r[1] for r in oks), oks
+    dense = [r for r in res if r[0] in (10, 11)]
+    assert len(dense) == 2 and all(r[1] for r in dense), dense
     assert all(r[1] == 2.0 for r in res if r[0] == "max")
 
 

@@ -134,6 +134,32 @@ def ep_moe(h: torch.Tensor, disp: dict, n_real: int, ep_size: int, group,
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def dense_ep_moe(h: torch.Tensor, expert_fn: Callable[[int, torch.Tensor], torch.Tensor], rank: int, size: int, n_real: int,
+                 group=None) -> torch.Tensor:
+    """The DENSE exchange of the expert-parallel decode engine (csrc/umoe_engine.hip run_moe_ep), restated with
+    torch.distributed collectives for any backend -- the layout contract the engine's slabs follow:
+      gather   xg[t] = rows of rank t                                  (every rank's `rows` normalised rows visit every expert)
+      local    y_loc[t][x] = expert (rank*E_loc + x) applied to xg[t]  (E_loc = n_real / size local experts, core.py:505)
+      return   rank t receives y_loc[t] of every rank src -> dense layout row (src*E_loc + x)*rows + s = (global expert, row)
+    h [rows, D]; expert_fn(global expert id, x [n, D]) -> [n, D].  Returns y [n_real, rows, D]; the caller combines by its own
+    routing mask in ascending expert order, exactly like ep_size 1."""
+    rows, D = h.shape
+    E_loc = n_real // size
+    if size == 1:
+        xg = h[None]
+    else:
+        parts = [torch.empty_like(h) for _ in range(size)]
+        dist.all_gather(parts, h.contiguous(), group=group)
+        xg = torch.stack(parts, 0)
+    y_loc = torch.empty((size, E_loc, rows, D), dtype=h.dtype, device=h.device)
+    for x in range(E_loc):
+        y_loc[:, x] = expert_fn(rank * E_loc + x, xg.reshape(size * rows, D)).reshape(size, rows, D)
+    y_ret = torch.empty_like(y_loc)
+    _a2a(y_ret, y_loc.contiguous(), group if size > 1 else None)
+    return y_ret.reshape(n_real, rows, D)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # Expert parallel DECODE: the exchange lives inside the engine's captured step graph (include/umoe.h "Peer exchange").
 class EpLink:
     """How the decode engines of an expert-parallel job reach each other.
@@ -170,26 +196,40 @@ class EpLink:
             L.check(lib.umoe_engine_ep_connect(engine_handle, None, self._comm.h, L.EP_RCCL), "umoe_engine_ep_connect")
             return
         base, nbytes = C.c_void_p(), C.c_size_t()
-        L.check(lib.umoe_engine_ep_region(engine_handle, C.byref(base), C.byref(nbytes)), "umoe_engine_ep_region")
-        raw = (C.c_char * 64)()
-        L.check(lib.umoe_ep_ipc_export(base, C.cast(raw, C.c_void_p)), "umoe_ep_ipc_export")
-        mine = (bytes(raw), int(nbytes.value))
+        try:
+            L.check(lib.umoe_engine_ep_region(engine_handle, C.byref(base), C.byref(nbytes)), "umoe_engine_ep_region")
+            raw = (C.c_char * 64)()
+            L.check(lib.umoe_ep_ipc_export(base, C.cast(raw, C.c_void_p)), "umoe_ep_ipc_export")
+            mine = (bytes(raw), int(nbytes.value), "")
+        except Exception as e:
+            mine = (b"", 0, f"rank {self.rank}: {e!r}")
         every = [None] * self.size
         dist.all_gather_object(every, mine, group=self.group)
+        bad = [m[2] for m in every if m[2]]
+        if bad:
+            raise L.UmoeError("expert-parallel connect failed: " + "; ".join(bad))
         peers = (C.c_void_p * L.MAX_EP)()
-        for p, (h, nb) in enumerate(every):
-            if nb != mine[1]:
-                raise L.UmoeError(f"expert-parallel engines disagree on the exchange region size (rank {p}: {nb} != {mine[1]})")
-            if p == self.rank:
-                peers[p] = base.value
-                continue
-            ptr = C.c_void_p()
-            hb = (C.c_char * 64).from_buffer_copy(h)
-            L.check(lib.umoe_ep_ipc_open(C.cast(hb, C.c_void_p), C.byref(ptr)), f"umoe_ep_ipc_open (rank {p})")
-            self._opened.append(ptr)
-            peers[p] = ptr.value
-        L.check(lib.umoe_engine_ep_connect(engine_handle, peers, None, L.EP_PEER), "umoe_engine_ep_connect")
-        dist.barrier(group=self.group)          # nobody steps before every rank has mapped every region
+        problem = ""
+        try:
+            for p, (h, nb, _) in enumerate(every):
+                if nb != mine[1]:
+                    raise L.UmoeError(f"expert-parallel engines disagree on the exchange region size (rank {p}: {nb} != {mine[1]})")
+                if p == self.rank:
+                    peers[p] = base.value
+                    continue
+                ptr = C.c_void_p()
+                hb = (C.c_char * 64).from_buffer_copy(h)
+                L.check(lib.umoe_ep_ipc_open(C.cast(hb, C.c_void_p), C.byref(ptr)), f"umoe_ep_ipc_open (rank {p})")
+                self._opened.append(ptr)
+                peers[p] = ptr.value
+            L.check(lib.umoe_engine_ep_connect(engine_handle, peers, None, L.EP_PEER), "umoe_engine_ep_connect")
+        except Exception as e:           # agree on the outcome together: a rank that raised alone would leave its peers waiting
+            problem = f"rank {self.rank}: {e!r}"
+        outcomes = [None] * self.size
+        dist.all_gather_object(outcomes, problem, group=self.group)   # (also the barrier: nobody steps before every rank has mapped every region)
+        bad = [o for o in outcomes if o]
+        if bad:
+            raise L.UmoeError("expert-parallel connect failed: " + "; ".join(bad))
 
     @staticmethod
     def local_mesh(engine_handles):
