@@ -238,6 +238,8 @@ typedef struct {
     float rms_eps;
     const int32_t* expert_mask; /* dense-expert layout (slot_of == NULL): expert e's output row of token s is e*dense_rows + s, */
     int mask_ld, dense_rows;    /* used iff expert_mask[s*mask_ld + e] != 0 (every expert computed all rows; decode, S <= 16) */
+    const void* ep_xfer;        /* decode engine only (NULL otherwise): HOST pointer to the exchange descriptor of an expert-parallel
+                                 * step -- y_slots is then this rank's return slab and the kernel waits for the peers' rows itself */
 } umoe_combine_args;
 int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_stream_t stream);
 

@@ -78,7 +78,7 @@ class CombineArgs(C.Structure):
     _fields_ = [("y_slots", vp), ("slot_of", vp), ("moe_w", vp), ("y_shared", vp), ("global_w", vp), ("resid", vp),
                 ("out", vp), ("S", i32), ("D", i32), ("n_real", i32), ("n_dyn", i32), ("n_fix", i32), ("y_parts", vp), ("n_parts", i32), ("part_stride", C.c_long),
                 ("shared_row0", i32), ("norm_w", vp),
-                ("norm_out", vp), ("rms_eps", f32), ("expert_mask", vp), ("mask_ld", i32), ("dense_rows", i32)]
+                ("norm_out", vp), ("rms_eps", f32), ("expert_mask", vp), ("mask_ld", i32), ("dense_rows", i32), ("ep_xfer", vp)]
 
 
 class RopeArgs(C.Structure):

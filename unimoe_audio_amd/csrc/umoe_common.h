@@ -170,21 +170,75 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // ---- expert-parallel peer exchange (umoe_ep.hip; used by the decode engine) -----------------------------------------
 // Region of one rank (uncached device memory, mapped by every peer through HIP IPC):
 //   [flag block: 2 kinds x UMOE_MAX_EP tiles x UMOE_EP_PARTS words, one 64-byte line each][dispatch slab][return slab]
-#define UMOE_EP_PARTS 4
+// A hand-off unit ("part") is ONE token row: part s of tile t carries row s of rank t (dispatch: one row of D; return: row s
+// of each of the n_sub local experts' outputs), published by one flag word.
+#define UMOE_EP_PARTS 16
 #define UMOE_EP_FLAG_BYTES (2 * UMOE_MAX_EP * UMOE_EP_PARTS * 64)
 struct umoe_ep_xfer {          // one push (local rows -> every peer's slab) or pull (own slab -> local buffer); by value
     char* peer_base[UMOE_MAX_EP];  // region base of every rank as mapped in this process
-    const char* src;           // push: local source of the chunk for peer p = src + p * src_stride
+    const char* src;           // push: local source; the chunk for peer p starts at src + p * src_stride
     long src_stride;
-    char* dst;                 // pull: local destination of tile p = dst + p * chunk
-    size_t chunk;              // bytes per tile (multiple of UMOE_EP_PARTS * 16)
+    char* dst;                 // pull: local destination of tile p = dst + p * chunk (row-major), or the packed tiles (pull_pack)
+    size_t chunk;              // bytes per tile = n_sub * rows * row_bytes
     size_t data_off;           // slab offset inside a region
     int kind;                  // 0 dispatch, 1 return: selects the flag block half
     int rank, size, loopback;
+    int rows, row_bytes, n_sub;    // rows per tile (<= UMOE_EP_PARTS), bytes per row (multiple of 16), sub-blocks [n_sub][rows][row_bytes]
     const uint32_t* step;      // device word: decode steps taken so far
     int layer, layers;         // epoch = *step * layers + layer + 1
     uint32_t* err;             // device word, sticky: 1 = a receive timed out
 };
 int umoe_ep_push(const umoe_ep_xfer& x, hipStream_t s);
 int umoe_ep_pull(const umoe_ep_xfer& x, hipStream_t s);
+// pull of the dispatch slab that also re-lays every 16-row tile (the own one from `own_rows`, row-major) into MFMA operand order
+// (WP16 of a [16][K = row_bytes / 2] matrix, include/umoe.h): x.dst = packed tiles [size][K * 16]
+int umoe_ep_pull_pack(const umoe_ep_xfer& x, const uint16_t* own_rows, hipStream_t s);
+// RMSNorm-only router launch (umoe_router_args.norm_only) that also pushes each normalised row to every peer (umoe_router.hip)
+int umoe_router_norm_push(const umoe_router_args* a, const umoe_ep_xfer& x, hipStream_t s);
 int umoe_ep_rccl_allgather(void* comm, const void* send, void* recv, size_t bytes, hipStream_t s);
+
+// ---- weight-streaming GEMM over several 16-row tiles per weight pass (umoe_gemm_mt.hip; expert parallel decode) --------
+#define UMOE_MT_MAXG 4
+#define UMOE_MT_MAXT UMOE_MAX_EP
+struct umoe_mt_args {
+    const uint16_t* w[UMOE_MT_MAXG];   // WP16 weights of group g = local expert (gate/up blocks interleaved for SwiGLU)
+    int num_groups, n_blocks, k;       // 16-feature blocks per group (SwiGLU: 2*I/16), contraction length (k % 32 == 0)
+    int tiles, n_rows;                 // row tiles per group (= ep_size: one per source rank), valid rows per tile (<= 16)
+    const uint16_t* b;                 // activation tiles in MFMA operand order (WP16 of a [16][k] matrix): tile (g, t) at
+    int b_group_tiles;                 //   b + (g * b_group_tiles + t) * 16 * k; 0 = every group reads the same tiles (gate/up)
+    uint16_t* h_out;                   // UMOE_EPI_SWIGLU: tile (g, t) of silu(g)*u in operand order for the down projection,
+                                       //   h_out + (g * tiles + t) * 16 * I, I = n_blocks * 8
+    uint16_t* y_out[UMOE_MT_MAXG][UMOE_MT_MAXT];   // UMOE_EPI_BF16: row-major [16][ldo] output of tile (g, t)
+    int ldo;
+    int epilogue;
+    const umoe_router_args* fused_router;   // optional HOST pointer: S router workgroups ride as an extra z-slice (see umoe_gemm_args)
+};
+int umoe_gemm_mt(const umoe_mt_args* a, hipStream_t s);
+
+// device side of the hand-off (shared by umoe_ep.hip, umoe_router.hip, umoe_misc.hip)
+#if defined(__HIPCC__)
+typedef __attribute__((address_space(1))) uint32_t umoe_gu32;
+#define UMOE_SYS_AUX 17   // raw buffer aux bits on gfx950: sc0 (1) | sc1 (16) = system scope
+__device__ __forceinline__ umoe_gu32* umoe_ep_flag(char* base, int kind, int tile, int part) {
+    return reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(base + ((size_t)(kind * UMOE_MAX_EP + tile) * UMOE_EP_PARTS + part) * 64));
+}
+__device__ __forceinline__ uint32_t umoe_ep_epoch(const umoe_ep_xfer& x) { return *x.step * (uint32_t)x.layers + (uint32_t)x.layer + 1u; }
+// ONE lane: bounded wait until `flag` carries `epoch` (or a later one).  A peer that never arrives, or a timeout anywhere
+// earlier (sticky error word), ends the wait: every wave reaches its exit.
+__device__ __forceinline__ void umoe_ep_wait(umoe_gu32* flag, uint32_t epoch, uint32_t* err_word) {
+    umoe_gu32* err = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(err_word));
+    const unsigned long long t0 = wall_clock64();        // 100 MHz
+    for (unsigned spins = 0;; ++spins) {
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - epoch) >= 0) break;
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 255u) == 255u) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (wall_clock64() - t0 > 1000000000ull) {    // 10 s
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+}
+#endif

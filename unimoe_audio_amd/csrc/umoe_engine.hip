@@ -97,7 +97,8 @@ struct umoe_engine {
     void* ep_comm = nullptr;
     int ep_mode = -1;                     // -1 = not connected
     uint32_t* ep_words = nullptr;         // [0] decode steps taken (epoch base), [1] sticky error word; own allocation: survives workspace growth
-    uint16_t* xg = nullptr;               // [ep][rows][D] normalised rows of every rank (tile ep_rank is written locally)
+    uint16_t* xg = nullptr;               // RCCL mode: [ep][rows][D] normalised rows of every rank (tile ep_rank is written locally)
+    uint16_t *xgp = nullptr, *hpk = nullptr;   // peer modes: operand-order tiles (see carve)
     bool ep_decode(int n_tok) const { return c.ep_size > 1 && n_tok == c.rows; }
     int groups_per_layer() const { return 2 + 2 * (c.n_real + c.n_fix); }
 };
@@ -123,6 +124,9 @@ static size_t carve(umoe_engine* e, int n_tok, char* base) {
     // the LOCAL experts for every rank's rows, [dest rank][local expert][row], which the return exchange ships
     e->ybuf = k.take<uint16_t>(slots * D + (c.ep_size > 1 ? (size_t)c.n_real * c.rows * D : 0));
     e->xg = k.take<uint16_t>(c.ep_size > 1 ? (size_t)c.ep_size * c.rows * D : 0);
+    // peer modes: 16-row tiles in MFMA operand order -- the gathered rows [ep][16*D] and silu(g)*u of every (local expert, rank) [n_real][16*I]
+    e->xgp = k.take<uint16_t>(c.ep_size > 1 ? (size_t)c.ep_size * 16 * D : 0);
+    e->hpk = k.take<uint16_t>(c.ep_size > 1 ? (size_t)c.n_real * 16 * c.inter_dyn : 0);
     e->part_o = k.take<float>((size_t)n_tok * c.heads * splits * c.head_dim);
     e->part_ml = k.take<float>((size_t)n_tok * c.heads * splits * 2);
     e->logits = k.take<float>((size_t)c.rows * c.codec_channels * c.codec_vocab);
@@ -210,7 +214,8 @@ static int build_groups(umoe_engine* e, int n_tok, hipStream_t s) {
                 }
             for (int i = 0; i < c.n_fix; ++i) {
                 const int x = c.n_real + i;
-                gu[x].w = L.sh_gu[i]; gu[x].static_count = n_tok; gu[x].a_row_base = c.ep_rank * n_tok;   // own tile of xg
+                gu[x].w = L.sh_gu[i]; gu[x].static_count = n_tok;
+                gu[x].a_row_base = own_direct ? 0 : c.ep_rank * n_tok;   // peer modes: the row-major h2; RCCL mode: own tile of xg
                 gu[x].out_row_base = slots_routed + i * n_tok; gu[x].n_blocks = 2 * c.inter_shared / 16; gu[x].k = c.hidden;
                 dn[x].w = L.sh_dn[i]; dn[x].static_count = n_tok; dn[x].a_row_base = slots_routed + i * n_tok;
                 dn[x].out_row_base = slots_routed + i * n_tok; dn[x].n_blocks = c.hidden / 16; dn[x].k = c.inter_shared;
@@ -441,7 +446,7 @@ static void prof_mark(umoe_engine* e, int kind, hipStream_t s) {
 //   rows | local experts gate/up over ep*rows rows (+ the router riders) | down | PUSH outputs to the rows' owners | shared
 //   experts down (hides the push) | PULL | combine (selects by the local routing mask, ascending expert order: bit-identical to
 //   ep_size 1 because every (expert, 16-row tile) product is computed by the same kernel instantiation with the same K split).
-static int run_moe_ep(umoe_engine* e, int l, int n_tok, hipStream_t s) {
+static int run_moe_ep_rccl(umoe_engine* e, int l, int n_tok, hipStream_t s) {
     const umoe_engine_cfg& c = e->c;
     const int D = c.hidden, G = c.n_real + c.n_fix, GPL = e->groups_per_layer(), E = c.n_dyn + c.n_fix;
     const int Imax = c.inter_dyn > c.inter_shared ? c.inter_dyn : c.inter_shared;
@@ -542,6 +547,103 @@ static int run_moe_ep(umoe_engine* e, int l, int n_tok, hipStream_t s) {
     cb.y_shared = c.n_fix ? e->ybuf + (size_t)n_tok * c.n_real * D : nullptr; cb.global_w = e->r_global;
     cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
     cb.norm_w = (l + 1 < c.layers) ? e->layers[l + 1].w.in_norm : e->final_norm; cb.norm_out = e->hin; cb.rms_eps = c.rms_eps;
+    rc = umoe_unpermute_combine_fwd(&cb, s);
+    PROF(K_COMBINE);
+    return rc;
+}
+
+// Peer modes (xGMI stores / loopback): 6 launches beside the two shared-expert GEMMs --
+//   RMSNorm + PUSH of the rows (one launch) | shared gate/up | PULL + re-lay into operand order | local experts gate/up over
+//   all ep*16 rows, weights streamed ONCE (umoe_gemm_mt.hip; + the router riders) | down, own rows' outputs straight into the own
+//   return slab | PUSH outputs | shared down | combine, which waits for the peers' rows itself and reads the slab in place.
+static int run_moe_ep(umoe_engine* e, int l, int n_tok, hipStream_t s) {
+    if (e->ep_mode == UMOE_EP_RCCL) return run_moe_ep_rccl(e, l, n_tok, s);
+    const umoe_engine_cfg& c = e->c;
+    const int D = c.hidden, G = c.n_real + c.n_fix, GPL = e->groups_per_layer(), E = c.n_dyn + c.n_fix;
+    const int Imax = c.inter_dyn > c.inter_shared ? c.inter_dyn : c.inter_shared;
+    const int ep = c.ep_size, El = e->E_loc, rank = c.ep_rank;
+    const LayerDev& L = e->layers[l];
+    const umoe_group_t* g = e->d_groups + (size_t)l * GPL;
+    const umoe_group_t* gh = e->h_groups.data() + (size_t)l * GPL;
+    UMOE_REQUIRE(e->ep_mode >= 0, "umoe_engine: expert parallel engine is not connected (umoe_engine_ep_connect)");
+    UMOE_REQUIRE(c.n_dyn == 9 && c.n_fix == 2 && (D == 2048 || D == 4096) && El <= UMOE_MT_MAXG,
+                 "umoe_engine: the expert parallel peer path is built for n_dyn 9 / n_fix 2, D 2048 / 4096");
+    int rc;
+    umoe_router_args ra{};
+    ra.x = e->x1; ra.gate_w = L.w.gate_w; ra.norm_w = L.w.post_norm; ra.h_out = e->h2; ra.S = n_tok; ra.D = D;
+    ra.n_dyn = c.n_dyn; ra.n_real = c.n_real; ra.n_fix = c.n_fix; ra.logits_bf16 = 1; ra.top_p = c.top_p;
+    ra.fixed_top_k = c.fixed_top_k; ra.jitter_eps = c.jitter_eps; ra.rms_eps = c.rms_eps;
+    ra.logits_out = e->r_logits; ra.sel = e->r_sel; ra.routing_w = e->r_routing; ra.global_w = e->r_global; ra.moe_w = e->r_moe;
+    ra.expert_mask = e->all_mask + (size_t)l * c.rows * E;
+    ra.top_k = e->all_topk + (size_t)l * c.rows;
+    const size_t tile = (size_t)n_tok * D * 2, chunk_y = (size_t)El * tile;
+    umoe_ep_xfer x{};
+    for (int p = 0; p < ep; ++p) x.peer_base[p] = e->ep_peers[p];
+    x.rank = rank; x.size = ep; x.loopback = e->ep_mode == UMOE_EP_LOOPBACK; x.step = e->ep_words; x.err = e->ep_words + 1;
+    x.layer = l; x.layers = c.layers; x.rows = n_tok; x.row_bytes = D * 2;
+    // ---- RMSNorm of the own rows (-> h2) + first exchange
+    x.kind = 0; x.n_sub = 1; x.chunk = tile; x.data_off = UMOE_EP_FLAG_BYTES;
+    umoe_router_args rn = ra;
+    rn.norm_only = 1;
+    if ((rc = umoe_router_norm_push(&rn, x, s))) return rc;
+    ra.h_out = nullptr;
+    PROF(K_ROUTER);
+    // ---- shared experts gate/up on the own rows while the rows travel (K split of the ep_size 1 launch: 8 waves, 1-step chunks)
+    umoe_gemm_args sg{};
+    sg.groups = g + 2 + c.n_real; sg.groups_host = gh + 2 + c.n_real; sg.num_groups = c.n_fix; sg.max_rows = n_tok;
+    sg.max_n_blocks = 2 * c.inter_shared / 16; sg.max_k = D; sg.a = e->h2; sg.lda = D; sg.out = e->hbuf; sg.ldo = Imax; sg.n_valid = Imax;
+    sg.prologue = UMOE_PRO_PLAIN; sg.epilogue = UMOE_EPI_SWIGLU; sg.nt = 2; sg.waves = 8;
+    if ((rc = umoe_grouped_gemm(&sg, s))) return rc;
+    PROF(K_GATEUP);
+    // ---- the peers' rows (and the own ones) into operand-order tiles
+    x.dst = (char*)e->xgp; x.chunk = tile;
+    {
+        umoe_ep_xfer xp = x;
+        // (the packed tiles are 16 rows apart whatever n_tok is; the slab tiles n_tok rows)
+        if ((rc = umoe_ep_pull_pack(xp, e->h2, s))) return rc;
+    }
+    PROF(K_DISPATCH);
+    // ---- local experts over every rank's rows: one pass over each expert's weights
+    umoe_mt_args gu{};
+    for (int q = 0; q < El; ++q) gu.w[q] = L.exp_gu[q];
+    gu.num_groups = El; gu.n_blocks = 2 * c.inter_dyn / 16; gu.k = D; gu.tiles = ep; gu.n_rows = n_tok;
+    gu.b = e->xgp; gu.b_group_tiles = 0; gu.h_out = e->hpk; gu.epilogue = UMOE_EPI_SWIGLU;
+    gu.fused_router = e->fuse_router ? &ra : nullptr;
+    if ((rc = umoe_gemm_mt(&gu, s))) return rc;
+    if (!e->fuse_router) {
+        if ((rc = umoe_router_fwd(&ra, s))) return rc;
+    }
+    PROF(K_GATEUP);
+    uint16_t* yloc = e->ybuf + (size_t)G * n_tok * D;                        // [dest rank][local expert][row][D]
+    uint16_t* slab_ret = reinterpret_cast<uint16_t*>(e->ep_region + UMOE_EP_FLAG_BYTES + (size_t)ep * tile);   // [global expert][row][D]
+    umoe_mt_args dn{};
+    for (int q = 0; q < El; ++q) dn.w[q] = L.exp_dn[q];
+    dn.num_groups = El; dn.n_blocks = D / 16; dn.k = c.inter_dyn; dn.tiles = ep; dn.n_rows = n_tok;
+    dn.b = e->hpk; dn.b_group_tiles = ep; dn.ldo = D; dn.epilogue = UMOE_EPI_BF16;
+    for (int q = 0; q < El; ++q)
+        for (int t = 0; t < ep; ++t)
+            dn.y_out[q][t] = (t == rank) ? slab_ret + (size_t)(rank * El + q) * n_tok * D : yloc + (size_t)(t * El + q) * n_tok * D;
+    if ((rc = umoe_gemm_mt(&dn, s))) return rc;
+    PROF(K_DOWN);
+    // ---- second exchange: my experts' outputs to the rows' owners
+    x.kind = 1; x.n_sub = El; x.chunk = chunk_y; x.data_off = UMOE_EP_FLAG_BYTES + (size_t)ep * tile;
+    x.src = (const char*)yloc; x.src_stride = (long)chunk_y;
+    if ((rc = umoe_ep_push(x, s))) return rc;
+    PROF(K_DISPATCH);
+    umoe_gemm_args sd{};     // shared experts down while the outputs travel (K split of the ep_size 1 launch: 8 waves, 2-step chunks)
+    sd.groups = g + 2 + G + c.n_real; sd.groups_host = gh + 2 + G + c.n_real; sd.num_groups = c.n_fix; sd.max_rows = n_tok;
+    sd.max_n_blocks = D / 16; sd.max_k = c.inter_shared; sd.a = e->hbuf; sd.lda = Imax; sd.out = e->ybuf; sd.ldo = D; sd.n_valid = D;
+    sd.prologue = UMOE_PRO_PLAIN; sd.epilogue = UMOE_EPI_BF16; sd.nt = 2; sd.waves = 8;
+    if ((rc = umoe_grouped_gemm(&sd, s))) return rc;
+    PROF(K_DOWN);
+    // ---- combine + residual -> next layer input; waits for the peers' rows itself, reads the return slab in place
+    umoe_combine_args cb{};
+    cb.y_slots = slab_ret; cb.shared_row0 = -1; cb.slot_of = nullptr; cb.moe_w = e->r_moe;
+    cb.expert_mask = ra.expert_mask; cb.mask_ld = E; cb.dense_rows = n_tok;
+    cb.y_shared = e->ybuf + (size_t)n_tok * c.n_real * D; cb.global_w = e->r_global;
+    cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
+    cb.norm_w = (l + 1 < c.layers) ? e->layers[l + 1].w.in_norm : e->final_norm; cb.norm_out = e->hin; cb.rms_eps = c.rms_eps;
+    cb.ep_xfer = &x;
     rc = umoe_unpermute_combine_fwd(&cb, s);
     PROF(K_COMBINE);
     return rc;

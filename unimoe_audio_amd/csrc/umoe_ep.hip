@@ -141,79 +141,100 @@ extern "C" int umoe_ep_ipc_close(void* dev_ptr) {
 // barrier, ONE lane publishes the epoch with a system-scope store; the consumer polls that word with a system-scope load (one
 // lane, bounded), the other waves wait at the barrier, and EVERY load of the payload is an sc0 sc1 load -- no stale line of any
 // cache level can be read, whatever the memory type of the region turns out to be on the peer.
-typedef __attribute__((address_space(1))) uint32_t gu32;
-#define UMOE_SYS_AUX 17   // raw buffer aux bits on gfx950: sc0 (1) | sc1 (16) = system scope
-
-__device__ __forceinline__ gu32* ep_flag(char* base, int kind, int tile, int part) {
-    return reinterpret_cast<gu32*>(reinterpret_cast<uintptr_t>(base + ((size_t)(kind * UMOE_MAX_EP + tile) * UMOE_EP_PARTS + part) * 64));
-}
+// One workgroup moves one part = row s of every sub-block of one tile; all of a thread's loads are in flight before its stores.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define EP_MAXC 8   // 16-byte chunks per thread: n_sub * row_bytes / 16 / 256 <= 8 (4 local experts x D 4096)
 
 __global__ __launch_bounds__(256) void ep_push_kernel(const umoe_ep_xfer x) {
-    const int part = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const int srow = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
     const int p = (x.rank + 1 + j) % x.size;                 // destination rank
     const int tile = x.loopback ? p : x.rank;                // where my rows live in its slab
-    const uint32_t epoch = *x.step * (uint32_t)x.layers + (uint32_t)x.layer + 1u;
-    const size_t per = x.chunk / UMOE_EP_PARTS;
-    const char* src = x.src + (long)p * x.src_stride + (size_t)part * per;
-    char* dst = x.peer_base[p] + x.data_off + (size_t)tile * x.chunk + (size_t)part * per;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)per, 0x00020000);
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    for (size_t i = (size_t)tid * 16; i < per; i += 256 * 16) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(src + i);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)i, 0, UMOE_SYS_AUX);
+    const uint32_t epoch = umoe_ep_epoch(x);
+    const int cpr = x.row_bytes >> 4, total = x.n_sub * cpr; // chunks per row, chunks of this part
+    const char* src = x.src + (long)p * x.src_stride;
+    char* dst = x.peer_base[p] + x.data_off + (size_t)tile * x.chunk;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)x.chunk, 0x00020000);
+    u32x4 v[EP_MAXC];
+#pragma unroll
+    for (int k = 0; k < EP_MAXC; ++k) {
+        const int c = tid + k * 256;
+        if (c < total) v[k] = *reinterpret_cast<const u32x4*>(src + ((size_t)(c / cpr) * x.rows + srow) * x.row_bytes + (size_t)(c % cpr) * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < EP_MAXC; ++k) {
+        const int c = tid + k * 256;
+        if (c < total)
+            __builtin_amdgcn_raw_buffer_store_b128(v[k], rsrc, (int)(((size_t)(c / cpr) * x.rows + srow) * x.row_bytes + (size_t)(c % cpr) * 16), 0, UMOE_SYS_AUX);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its write-through stores
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(ep_flag(x.peer_base[p], x.kind, tile, part), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) __hip_atomic_store(umoe_ep_flag(x.peer_base[p], x.kind, tile, srow), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(256) void ep_pull_kernel(const umoe_ep_xfer x) {
-    const int part = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
-    const int p = (x.rank + 1 + j) % x.size;                 // source rank = tile index in my slabs
-    const uint32_t epoch = *x.step * (uint32_t)x.layers + (uint32_t)x.layer + 1u;
-    char* own = x.peer_base[x.rank];
-    if (tid == 0) {
-        gu32* f = ep_flag(own, x.kind, p, part);
-        gu32* err = reinterpret_cast<gu32*>(reinterpret_cast<uintptr_t>(x.err));
-        const unsigned long long t0 = wall_clock64();        // 100 MHz
-        for (unsigned spins = 0;; ++spins) {
-            const uint32_t v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((int32_t)(v - epoch) >= 0) break;
-            __builtin_amdgcn_s_sleep(8);
-            if ((spins & 255u) == 255u) {
-                // exit condition every wave reaches: a peer that never arrives (or an earlier timeout anywhere) ends the wait
-                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                if (wall_clock64() - t0 > 1000000000ull) {    // 10 s
-                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
+// PACK: the destination tile is written in MFMA operand order (dispatch slab only: n_sub 1); blockIdx.y == size - 1 packs the own rows
+template <bool PACK>
+__global__ __launch_bounds__(256) void ep_pull_kernel(const umoe_ep_xfer x, const uint16_t* own_rows) {
+    const int srow = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const bool own = PACK && j == x.size - 1;
+    const int p = own ? x.rank : (x.rank + 1 + j) % x.size;  // source rank = tile index in my slabs
+    char* region = x.peer_base[x.rank];
+    if (!own) {
+        if (tid == 0) umoe_ep_wait(umoe_ep_flag(region, x.kind, p, srow), umoe_ep_epoch(x), x.err);
+        __syncthreads();
+    }
+    const int cpr = x.row_bytes >> 4, total = x.n_sub * cpr;
+    char* src = region + x.data_off + (size_t)p * x.chunk;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(src, 0, (int)x.chunk, 0x00020000);
+    u32x4 v[EP_MAXC];
+#pragma unroll
+    for (int k = 0; k < EP_MAXC; ++k) {
+        const int c = tid + k * 256;
+        if (c < total) {
+            const size_t off = ((size_t)(c / cpr) * x.rows + srow) * x.row_bytes + (size_t)(c % cpr) * 16;
+            if (own) v[k] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(own_rows) + off);
+            else v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, UMOE_SYS_AUX);
         }
     }
-    __syncthreads();
-    const size_t per = x.chunk / UMOE_EP_PARTS;
-    char* src = own + x.data_off + (size_t)p * x.chunk + (size_t)part * per;
-    char* dst = x.dst + (size_t)p * x.chunk + (size_t)part * per;
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(src, 0, (int)per, 0x00020000);
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    for (size_t i = (size_t)tid * 16; i < per; i += 256 * 16) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)i, 0, UMOE_SYS_AUX);
-        *reinterpret_cast<u32x4*>(dst + i) = v;
+#pragma unroll
+    for (int k = 0; k < EP_MAXC; ++k) {
+        const int c = tid + k * 256;
+        if (c < total) {
+            size_t off = ((size_t)(c / cpr) * x.rows + srow) * x.row_bytes + (size_t)(c % cpr) * 16;
+            if (PACK) {   // chunk c of row srow: K-quarter q, k-step i  ->  fragment (i, lane = q*16 + row)
+                const int q4 = cpr >> 2, q = c / q4, i = c % q4;
+                off = ((size_t)i * 64 + q * 16 + srow) * 16;
+            }
+            // (operand-order tiles are 16 rows apart whatever the row count is)
+            *reinterpret_cast<u32x4*>(x.dst + (size_t)p * (PACK ? (size_t)16 * x.row_bytes : x.chunk) + off) = v[k];
+        }
     }
+}
+
+static int xfer_check(const umoe_ep_xfer& x, const char* who) {
+    UMOE_REQUIRE(x.size >= 2 && x.size <= UMOE_MAX_EP && x.rows >= 1 && x.rows <= UMOE_EP_PARTS && x.row_bytes % 16 == 0 && x.n_sub >= 1 &&
+                     x.n_sub * (x.row_bytes / 16) <= 256 * EP_MAXC && x.chunk == (size_t)x.n_sub * x.rows * x.row_bytes && x.chunk < (1u << 30),
+                 "%s: bad geometry (size %d rows %d row_bytes %d n_sub %d chunk %zu)", who, x.size, x.rows, x.row_bytes, x.n_sub, x.chunk);
+    return 0;
 }
 
 int umoe_ep_push(const umoe_ep_xfer& x, hipStream_t s) {
-    UMOE_REQUIRE(x.size >= 2 && x.size <= UMOE_MAX_EP && x.chunk % (UMOE_EP_PARTS * 16) == 0 && x.chunk / UMOE_EP_PARTS < (1u << 30),
-                 "umoe_ep_push: bad geometry (size %d, chunk %zu)", x.size, x.chunk);
-    ep_push_kernel<<<dim3(UMOE_EP_PARTS, (unsigned)(x.size - 1)), 256, 0, s>>>(x);
+    if (int rc = xfer_check(x, "umoe_ep_push")) return rc;
+    ep_push_kernel<<<dim3((unsigned)x.rows, (unsigned)(x.size - 1)), 256, 0, s>>>(x);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
 
 int umoe_ep_pull(const umoe_ep_xfer& x, hipStream_t s) {
-    UMOE_REQUIRE(x.size >= 2 && x.size <= UMOE_MAX_EP && x.chunk % (UMOE_EP_PARTS * 16) == 0 && x.chunk / UMOE_EP_PARTS < (1u << 30),
-                 "umoe_ep_pull: bad geometry (size %d, chunk %zu)", x.size, x.chunk);
-    ep_pull_kernel<<<dim3(UMOE_EP_PARTS, (unsigned)(x.size - 1)), 256, 0, s>>>(x);
+    if (int rc = xfer_check(x, "umoe_ep_pull")) return rc;
+    ep_pull_kernel<false><<<dim3((unsigned)x.rows, (unsigned)(x.size - 1)), 256, 0, s>>>(x, nullptr);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+int umoe_ep_pull_pack(const umoe_ep_xfer& x, const uint16_t* own_rows, hipStream_t s) {
+    if (int rc = xfer_check(x, "umoe_ep_pull_pack")) return rc;
+    UMOE_REQUIRE(x.n_sub == 1 && own_rows && (x.row_bytes / 16) % 4 == 0, "umoe_ep_pull_pack: one sub-block, K %% 32 == 0");
+    ep_pull_kernel<true><<<dim3((unsigned)x.rows, (unsigned)x.size), 256, 0, s>>>(x, own_rows);
     UMOE_LAUNCH_CHECK();
     return 0;
 }

@@ -3,6 +3,7 @@
 // All are HBM/latency-bound elementwise or row-reduction kernels: 16-byte vector accesses, one
 // workgroup per row, no atomics, fixed summation orders.
 #include "umoe_common.h"
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 void umoe_set_error(const char* fmt, ...) {
@@ -66,7 +67,11 @@ extern "C" int umoe_rmsnorm_residual_fwd(const uint16_t* x, const uint16_t* r, c
 // ------------------------------------------------------------------------------------ combine
 // reference: einsum("se,sem->sm") core.py:488 (fp32 accumulate, one rounding), `final + current`
 // core.py:342, shared experts `expert(x) * w` then add core.py:349-351, residual model.py:242.
-__global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a) {
+// EP (expert parallel decode, dense layout): y_slots is this rank's RETURN slab (uncached region memory); the rows of expert e
+// arrive from rank e / E_loc (second all-to-all, core.py:480): lane e of wave 0 waits for that rank's flag of THIS token row,
+// the workgroup meets at its barrier, and every load of the slab is a system-scope (sc0 sc1) load (hand-off form: umoe_common.h).
+template <bool EP>
+__global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a, const umoe_ep_xfer x) {
     __shared__ float sh[4];
     TL_ENTER(9);
     const int s = blockIdx.x;
@@ -117,6 +122,13 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) swgt[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sw_l), i));
     }
+    if constexpr (EP) {
+        if (threadIdx.x < (unsigned)a.n_real) {
+            const int src = (int)threadIdx.x / (a.n_real / x.size);
+            if (src != x.rank) umoe_ep_wait(umoe_ep_flag(x.peer_base[x.rank], 1, src, s), umoe_ep_epoch(x), x.err);
+        }
+        __syncthreads();
+    }
     TL_MARK(9, 5);
     for (int c = threadIdx.x; c < (a.D >> 3); c += 256) {
         float acc[8];
@@ -126,8 +138,16 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a)
             uint4 yv[UMOE_MAXE], sv[4], rv = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < UMOE_MAXE; ++e)   // unselected experts re-read row 0 (valid memory, value never used): no
-                if (e < a.n_real)                  // data-dependent branch between the loads, all of them in flight at once
-                    yv[e] = ld16(a.y_slots + (size_t)(slot[e] >= 0 ? slot[e] : 0) * a.D + c * 8);
+                if (e < a.n_real) {                // data-dependent branch between the loads, all of them in flight at once
+                    if constexpr (EP) {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.y_slots), 0, a.n_real * a.dense_rows * a.D * 2, 0x00020000);
+                        const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((slot[e] >= 0 ? slot[e] : 0) * a.D + c * 8) * 2, 0, UMOE_SYS_AUX);
+                        yv[e] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                    } else {
+                        yv[e] = ld16(a.y_slots + (size_t)(slot[e] >= 0 ? slot[e] : 0) * a.D + c * 8);
+                    }
+                }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (a.y_shared && i < a.n_fix) sv[i] = ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8);
@@ -220,7 +240,17 @@ extern "C" int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_strea
     UMOE_REQUIRE(!(a->y_shared || (a->y_parts && a->shared_row0 >= 0)) || a->global_w,
                  "umoe_unpermute_combine_fwd: shared experts need global_w");
     if (a->S == 0) return 0;
-    combine_kernel<<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(*a);
+    umoe_ep_xfer x;
+    memset(&x, 0, sizeof(x));
+    if (a->ep_xfer) {
+        x = *reinterpret_cast<const umoe_ep_xfer*>(a->ep_xfer);
+        UMOE_REQUIRE(!a->slot_of && !a->y_parts && a->expert_mask && a->n_real <= UMOE_MAXE && a->n_fix <= 4 && x.size >= 2 && a->n_real % x.size == 0 &&
+                         a->S <= UMOE_EP_PARTS && a->dense_rows == a->S,
+                     "umoe_unpermute_combine_fwd: the expert-parallel form needs the dense layout over <= %d rows", UMOE_EP_PARTS);
+        combine_kernel<true><<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(*a, x);
+    } else {
+        combine_kernel<false><<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(*a, x);
+    }
     UMOE_LAUNCH_CHECK();
     return 0;
 }

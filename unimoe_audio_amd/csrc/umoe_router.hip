@@ -49,6 +49,47 @@ __global__ __launch_bounds__(256) void router_norm_kernel(const umoe_router_args
     TL_EXIT(5);
 }
 
+// Expert parallel decode: the RMSNorm-only launch also PUSHES its row to every peer's dispatch slab (first exchange of
+// AudioMOELayer.forward, core.py:467, in its dense form) -- each thread re-reads the 16 bytes it just stored and writes them
+// through to the peers (sc0 sc1), every wave drains, lanes 0..size-2 publish the row's epoch, one peer each (umoe_common.h).
+__global__ __launch_bounds__(256) void router_norm_push_kernel(const umoe_router_args a, const umoe_ep_xfer x) {
+    __shared__ float lds[4 + 4 * UMOE_MAXE];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    router4_body<9, 2, 1, true>(a, s, tid, lds);
+    const int nch = a.D >> 11;
+    const uint32_t epoch = umoe_ep_epoch(x);
+    u32x4 v[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+        if (n < nch) v[n] = *reinterpret_cast<const u32x4*>(a.h_out + (size_t)s * a.D + ((n * 4 + wave) * 64 + lane) * 8);   // own stores
+    for (int j = 0; j + 1 < x.size; ++j) {
+        const int p = (x.rank + 1 + j) % x.size;
+        const int tile = x.loopback ? p : x.rank;
+        char* dst = x.peer_base[p] + x.data_off + (size_t)tile * x.chunk + (size_t)s * x.row_bytes;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, x.row_bytes, 0x00020000);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            if (n < nch) __builtin_amdgcn_raw_buffer_store_b128(v[n], rsrc, ((n * 4 + wave) * 64 + lane) * 16, 0, UMOE_SYS_AUX);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid + 1 < x.size) {
+        const int p = (x.rank + 1 + tid) % x.size;
+        __hip_atomic_store(umoe_ep_flag(x.peer_base[p], x.kind, x.loopback ? p : x.rank, s), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int umoe_router_norm_push(const umoe_router_args* a, const umoe_ep_xfer& x, hipStream_t s) {
+    UMOE_REQUIRE(a && a->x && a->norm_w && a->h_out && (a->D == 2048 || a->D == 4096) && a->S >= 1 && a->S <= UMOE_EP_PARTS,
+                 "umoe_router_norm_push: needs x, norm_w, h_out, D 2048 / 4096, S <= %d", UMOE_EP_PARTS);
+    UMOE_REQUIRE(x.size >= 2 && x.size <= UMOE_MAX_EP && x.rows == a->S && x.row_bytes == a->D * 2 && x.n_sub == 1 && x.kind == 0,
+                 "umoe_router_norm_push: exchange geometry does not match the rows");
+    router_norm_push_kernel<<<dim3((unsigned)a->S), 256, 0, s>>>(*a, x);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 extern "C" int umoe_dispatch_build(const int32_t*, int, int, int, int32_t*, int32_t*, int32_t*, int32_t*, umoe_stream_t);
 
