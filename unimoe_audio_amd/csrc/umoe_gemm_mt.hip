@@ -18,7 +18,7 @@
 #include "umoe_router_dev.h"
 #include <string.h>
 
-template <int NT, int MT, int U, int EPI, bool FR>
+template <int NT, int MT, int U, int EPI, bool FR, int RW, int RB, bool WREFILL>
 __global__ __launch_bounds__(512, 1) void wstream_mt(const umoe_mt_args p, const umoe_router_args ra) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WV = 8;
@@ -34,6 +34,7 @@ __global__ __launch_bounds__(512, 1) void wstream_mt(const umoe_mt_args p, const
         }
     }
     const int g = blockIdx.z, nb0 = blockIdx.x * NT;
+    const int tile0 = blockIdx.y * MT;          // a workgroup serves MT of the group's row tiles (grid.y covers the rest)
     if (nb0 >= p.n_blocks) return;
     const int K = p.k, KB = K >> 5;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(512, 1) void wstream_mt(const umoe_mt_args p, const
     const u32x4_t* bp[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int mm = min(m, p.tiles - 1);
+        const int mm = min(tile0 + m, p.tiles - 1);
         bp[m] = reinterpret_cast<const u32x4_t*>(p.b) + ((size_t)(g * p.b_group_tiles + mm) * KB) * 64 + lane;
     }
     f32x4_t acc[MT][NT];
@@ -67,37 +68,47 @@ __global__ __launch_bounds__(512, 1) void wstream_mt(const umoe_mt_args p, const
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    u32x4_t w0[NT][U], w1[NT][U], b0[MT][U], b1[MT][U];
-    auto load_chunk = [&](u32x4_t (&dw)[NT][U], u32x4_t (&db)[MT][U], int ibase) {
+    // Register rings, one k-step per slot.  A workgroup streams so few bytes (2 blocks x K = 128 KiB of weights at ep_size 8) that
+    // the launch is bound by memory LATENCY, not bandwidth: with the double-buffered chunks of wstream_gemm every second k-step
+    // waited a full HBM round trip (8 k-steps per wave: ~4 round trips, 12-15 us per launch measured).  So the weight ring holds
+    // RW k-steps (the wave's whole K slice where it fits: every weight load is in flight before the first MFMA) and the
+    // fragment ring RB k-steps of L2-resident activations; within an iteration the fragment refill is issued BEFORE the weight
+    // refill (loads return in issue order: a wait for fragments must not drag in the younger weight loads).
+    u32x4_t wr[RW][NT], br[RB][MT];
+    auto load_w = [&](u32x4_t (&d)[NT], int ii) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ii = min(ibase + u, i1 - 1);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) dw[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)ii * 64);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) db[m][u] = bp[m][(size_t)ii * 64];
-        }
+        for (int t = 0; t < NT; ++t) d[t] = __builtin_nontemporal_load(wp[t] + (size_t)ii * 64);
     };
-    auto compute_chunk = [&](const u32x4_t (&sw)[NT][U], const u32x4_t (&sb)[MT][U], int ibase) {
+    auto load_b = [&](u32x4_t (&d)[MT], int ii) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (ibase + u < i1) {
+        for (int m = 0; m < MT; ++m) d[m] = bp[m][(size_t)ii * 64];
+    };
+    // every load is UNCONDITIONAL (index clamped to the slice; a refill past the end re-reads the last k-step, at most RW - 1 + RB - 1
+    // L2-resident fragments): a branch around a load makes hipcc wait for vmcnt(0) at the join, which serialises the rings
+    const int il = i1 - 1;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) load_b(br[r], min(i0 + r, il));
+#pragma unroll
+    for (int r = 0; r < RW; ++r) load_w(wr[r], min(i0 + r, il));
+    __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks the loads next to their first use: one round trip per fragment)
+    for (int base = i0; base < i1; base += RW) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int ii = base + r;
+            if (ii < i1) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, sb[m][u]);
+                    const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, br[r % RB][m]);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, sw[t][u]), bfrag, acc[m][t], 0, 0, 0);
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wr[r][t]), bfrag, acc[m][t], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(br[r % RB], min(ii + RB, il));
+            if constexpr (WREFILL) load_w(wr[r], min(ii + RW, il));   // (WREFILL false: the whole K slice of a wave fits the ring)
+            __builtin_amdgcn_sched_barrier(0);
         }
-    };
-    if (i0 < i1) load_chunk(w0, b0, i0);
-    for (int i = i0; i < i1; i += 2 * U) {
-        if (i + U < i1) load_chunk(w1, b1, i + U);
-        compute_chunk(w0, b0, i);
-        if (i + 2 * U < i1) load_chunk(w0, b0, i + 2 * U);
-        if (i + U < i1) compute_chunk(w1, b1, i + U);
     }
     // ---- fixed-order cross-wave reduction (wave 0 first, as in wstream_gemm) --------------------------------------------
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(512, 1) void wstream_mt(const umoe_mt_args p, const
         const int I = p.n_blocks * 8, Q = I >> 2;           // intermediate size and its K-quarter for the down projection
         for (int q = wave; q < MT * (NT / 2); q += WV) {
             const int m = q / (NT / 2), pq = q % (NT / 2);
-            if (m >= p.tiles || nb0 + 2 * pq >= p.n_blocks) continue;
+            if (tile0 + m >= p.tiles || nb0 + 2 * pq >= p.n_blocks) continue;
             const f32x4_t ga = reduced(m, 2 * pq), ua = reduced(m, 2 * pq + 1);
             uint16_t y[4];
 #pragma unroll
@@ -133,35 +144,35 @@ __global__ __launch_bounds__(512, 1) void wstream_mt(const umoe_mt_args p, const
             // feature f..f+3 of row mm -> operand order of the [16][I] tile: fragment (k-step i, lane = quarter*16 + row), element j
             const int f = (nb0 / 2 + pq) * 16 + 4 * h;
             const int qq = f / Q, r = f % Q;
-            uint16_t* o = p.h_out + (size_t)(g * p.tiles + m) * 16 * I + ((size_t)(r >> 3) * 64 + qq * 16 + mm) * 8 + (r & 7);
+            uint16_t* o = p.h_out + (size_t)(g * p.tiles + tile0 + m) * 16 * I + ((size_t)(r >> 3) * 64 + qq * 16 + mm) * 8 + (r & 7);
             *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
         }
         return;
     }
     for (int q = wave; q < MT * NT; q += WV) {
         const int m = q / NT, t = q % NT;
-        if (m >= p.tiles || nb0 + t >= p.n_blocks || mm >= p.n_rows) continue;
+        if (tile0 + m >= p.tiles || nb0 + t >= p.n_blocks || mm >= p.n_rows) continue;
         const f32x4_t a4 = reduced(m, t);
         const int n = (nb0 + t) * 16 + 4 * h;
         uint16_t y[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = f2bf(a4[j]);
-        uint16_t* o = p.y_out[g][m] + (size_t)mm * p.ldo + n;
+        uint16_t* o = p.y_out[g][tile0 + m] + (size_t)mm * p.ldo + n;
         *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
     }
 }
 
-template <int NT, int MT, int U, int EPI, bool FR>
-static int launch_mt(const umoe_mt_args* a, hipStream_t s) {
+template <int NT, int MT, int U, int EPI, bool FR, int RW, int RB, bool WREFILL>
+static int launch_mt_v(const umoe_mt_args* a, hipStream_t s) {
     const size_t lds = (size_t)8 * MT * NT * 64 * 16;
     static bool configured = false;
     if (!configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_mt<NT, MT, U, EPI, FR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_mt<NT, MT, U, EPI, FR, RW, RB, WREFILL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = true;
     }
     umoe_router_args ra;
     memset(&ra, 0, sizeof(ra));
-    dim3 grid((unsigned)ceil_div(a->n_blocks, NT), 1, (unsigned)a->num_groups);
+    dim3 grid((unsigned)ceil_div(a->n_blocks, NT), (unsigned)ceil_div(a->tiles, MT), (unsigned)a->num_groups);
     if (FR) {
         ra = *a->fused_router;
         UMOE_REQUIRE(ra.S <= (int)grid.x && ra.n_dyn == 9 && ra.n_fix == 2 && (ra.D == 2048 || ra.D == 4096) && ra.x && ra.gate_w && ra.expert_mask &&
@@ -169,9 +180,18 @@ static int launch_mt(const umoe_mt_args* a, hipStream_t s) {
                      "umoe_gemm_mt: fused_router needs n_dyn 9 / n_fix 2, D 2048 / 4096, S <= %u", grid.x);
         grid.z += 1;
     }
-    wstream_mt<NT, MT, U, EPI, FR><<<grid, 512, lds, s>>>(*a, ra);
+    wstream_mt<NT, MT, U, EPI, FR, RW, RB, WREFILL><<<grid, 512, lds, s>>>(*a, ra);
     UMOE_LAUNCH_CHECK();
     return 0;
+}
+
+template <int NT, int MT, int U, int EPI, bool FR, int RW, int RB>
+static int launch_mt(const umoe_mt_args* a, hipStream_t s) {
+    // k-steps of the longest wave slice (U-step chunks dealt to 8 waves): no weight refill when the ring holds them all
+    const int KB = a->k >> 5;
+    const int longest = (KB % U == 0) ? U * ceil_div(KB / U, 8) : ceil_div(KB, 8);
+    if (longest <= RW) return launch_mt_v<NT, MT, U, EPI, FR, RW, RB, false>(a, s);
+    return launch_mt_v<NT, MT, U, EPI, FR, RW, RB, true>(a, s);
 }
 
 int umoe_gemm_mt(const umoe_mt_args* a, hipStream_t s) {
@@ -184,15 +204,16 @@ int umoe_gemm_mt(const umoe_mt_args* a, hipStream_t s) {
         // the K split of the dense decode gate/up launch: 8 waves, 1-step chunks
         UMOE_REQUIRE(a->h_out && a->n_blocks % 2 == 0 && (a->n_blocks * 8) % 32 == 0, "umoe_gemm_mt: SwiGLU needs h_out and gate/up block pairs, I %% 32 == 0");
         const bool fr = a->fused_router != nullptr;
-        if (a->tiles == 2) return fr ? launch_mt<8, 2, 1, UMOE_EPI_SWIGLU, true>(a, s) : launch_mt<8, 2, 1, UMOE_EPI_SWIGLU, false>(a, s);
-        if (a->tiles == 4) return fr ? launch_mt<4, 4, 1, UMOE_EPI_SWIGLU, true>(a, s) : launch_mt<4, 4, 1, UMOE_EPI_SWIGLU, false>(a, s);
-        return fr ? launch_mt<2, 8, 1, UMOE_EPI_SWIGLU, true>(a, s) : launch_mt<2, 8, 1, UMOE_EPI_SWIGLU, false>(a, s);
+        if (a->tiles == 2) return fr ? launch_mt<8, 2, 1, UMOE_EPI_SWIGLU, true, 4, 2>(a, s) : launch_mt<8, 2, 1, UMOE_EPI_SWIGLU, false, 4, 2>(a, s);
+        if (a->tiles == 4) return fr ? launch_mt<4, 4, 1, UMOE_EPI_SWIGLU, true, 8, 2>(a, s) : launch_mt<4, 4, 1, UMOE_EPI_SWIGLU, false, 8, 2>(a, s);
+        return fr ? launch_mt<2, 8, 1, UMOE_EPI_SWIGLU, true, 8, 2>(a, s) : launch_mt<2, 8, 1, UMOE_EPI_SWIGLU, false, 8, 2>(a, s);
     }
     UMOE_REQUIRE(a->epilogue == UMOE_EPI_BF16 && !a->fused_router && a->ldo % 4 == 0, "umoe_gemm_mt: epilogue must be SwiGLU or bf16 (ldo %% 4 == 0)");
     for (int g = 0; g < a->num_groups; ++g)
         for (int t = 0; t < a->tiles; ++t) UMOE_REQUIRE(a->y_out[g][t], "umoe_gemm_mt: tile (%d, %d) has no output", g, t);
-    // the K split of the dense decode down launch: 8 waves, 2-step chunks
-    if (a->tiles == 2) return launch_mt<4, 2, 2, UMOE_EPI_BF16, false>(a, s);
-    if (a->tiles == 4) return launch_mt<2, 4, 2, UMOE_EPI_BF16, false>(a, s);
-    return launch_mt<1, 8, 2, UMOE_EPI_BF16, false>(a, s);
+    // the K split of the dense decode down launch: 8 waves, 2-step chunks.  Shapes: a workgroup takes in its weight blocks AND
+    // the fragments of its row tiles through the vector memory path at ~50 GB/s per CU (measured: 128 workgroups of 1 block x 8
+    // tiles = 792 KB each took 18 us), so the launch is cut into 256 workgroups of <= 4 tiles
+    if (a->tiles == 2) return launch_mt<2, 2, 2, UMOE_EPI_BF16, false, 8, 4>(a, s);
+    return launch_mt<1, 4, 2, UMOE_EPI_BF16, false, 8, 4>(a, s);
 }
