@@ -84,6 +84,17 @@ int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 int umoe_aux_loss_fwd(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S, int E,
                       int n_dyn, float* out, umoe_stream_t stream);
 
+/* Token drop (core.py:302-329; `capacity` = _audio_expert_capacity, core.py:170-175, computed by the host in the reference's
+ * float32 arithmetic).  policy 0 "probs": per dynamic column keep the `capacity` selected tokens with the largest logits (the
+ * reference's topk(dim=0) over the column, :305-314; shared columns untouched); policy 1 "position": keep the first `capacity`
+ * selected tokens of EVERY column in token order (:321-323; the reference's cumsum runs over the shared columns too).  Dropped
+ * entries leave routing_w, which is renormalised (:328-329); global_w / moe_w are recomputed over the kept columns (:178-193) with
+ * the router's arithmetic.  Ties at the capacity boundary keep the lowest token indices (torch.topk leaves them unspecified).
+ * Integer outputs are bit-exact w.r.t. the reference wherever the boundary is not tied. */
+int umoe_token_drop(const void* logits, int logits_bf16, const int32_t* expert_mask_in, const float* routing_w_in, int S, int n_dyn,
+                    int n_real, int n_fix, int capacity, int policy, int32_t* expert_mask_out, float* routing_w_out, float* global_w,
+                    float* moe_w, umoe_stream_t stream);
+
 /* Ragged dispatch tables from the 0/1 mask: the build's replacement for the dense
  * compress_matrix / decompress_matrix pair (utils/UniMoE_Audio_utils.py:436-523) and the
  * capacity MAX of core.py:455-457.  Wavefront ballot + prefix sums, token order preserved.
@@ -302,6 +313,11 @@ int umoe_permute_bwd(const uint16_t* dxe, const int32_t* slot_of, int n_real, co
 int umoe_router_bwd(const void* logits, int logits_bf16, const int32_t* sel, const int64_t* top_k, const int32_t* expert_mask,
                     const float* d_moe_w, const float* d_gw_shared, const float* d_logits_in, int S, int n_dyn, int n_real,
                     int n_fix, double jitter_eps, float* d_logits, umoe_stream_t stream);
+/* the same with the token-drop branch in the graph (core.py:328-329): `expert_mask` is then the mask AFTER the drop and the routing
+ * weights pass through r2 = (r * mask) / (sum(r * mask) + 1e-6) before the global weights */
+int umoe_router_bwd_drop(const void* logits, int logits_bf16, const int32_t* sel, const int64_t* top_k, const int32_t* expert_mask,
+                         const float* d_moe_w, const float* d_gw_shared, const float* d_logits_in, int S, int n_dyn, int n_real,
+                         int n_fix, double jitter_eps, float* d_logits, umoe_stream_t stream);
 
 /* Backward of the expert MLPs down(silu(gate x) * up x), core.py:16-49,406-416, over up to 12 groups per call:
  *   dH = dY Wd ; (dG | dU) = SwiGLU'(G, U, dH) ; dX_slots = dG Wg + dU Wu ; dWd = dY^T H ; dWg = dG^T X ; dWu = dU^T X.

@@ -60,6 +60,33 @@ def capacity_of(num_tokens: int, num_experts: int, capacity_factor: float, min_c
     return max(c, int(min_capacity))
 
 
+def drop_keep_mask(logits: torch.Tensor, expert_mask: torch.Tensor, n_dyn: int, cap: int, policy: str) -> torch.Tensor:
+    """Token-drop selection (core.py:305-323) with a DEFINED order among equal logits: "probs" keeps, per dynamic column, the
+    `cap` selected tokens with the largest logits, lowest token index first among equals (the reference's torch.topk leaves
+    that order unspecified; tests/test_oracle_golden.py checks that this equals the reference wherever the boundary is not
+    tied); "position" keeps the first `cap` selected tokens of every column (cumsum over ALL columns, shared ones included)."""
+    dt = expert_mask.dtype
+    if policy == "position":
+        loc = torch.cumsum(expert_mask, dim=0) - 1
+        return (expert_mask * torch.lt(loc, cap)).to(dt)
+    if policy != "probs":
+        raise ValueError(f"Invalid drop_policy: {policy}")
+    S = logits.shape[0]
+    cap = min(cap, S)
+    keep = torch.zeros_like(expert_mask)
+    keep[:, n_dyn:] = 1
+    idx = torch.arange(S)
+    for e in range(n_dyn):
+        sel = idx[expert_mask[:, e] != 0]
+        if sel.numel() <= cap:
+            keep[sel, e] = 1
+            continue
+        v = logits[sel, e].float()
+        order = sorted(range(sel.numel()), key=lambda i: (-float(v[i]), int(sel[i])))
+        keep[sel[torch.tensor(order[:cap])], e] = 1
+    return torch.logical_and(expert_mask, keep).to(dt)
+
+
 class DCMoEOracle:
     def __init__(self, cfg, weights: Dict[str, torch.Tensor], prefix: str = ""):
         self.cfg = cfg

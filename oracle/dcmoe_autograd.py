@@ -79,7 +79,7 @@ def aux_loss(mask: torch.Tensor, n_dyn: int, logits: torch.Tensor, aux_balance_w
 def forward(cfg, weights: Dict[str, torch.Tensor], hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
             aux_balance_weight: Optional[torch.Tensor] = None, training: bool = True, forced=None):
     """-> (out [B,T,D], logits, top_k, expert_mask, global_weight, aux); differentiable in hidden_states and weights."""
-    assert cfg.ignore_differentiable_router and not cfg.token_drop
+    assert cfg.ignore_differentiable_router
     B, T, D = hidden_states.shape
     n_real, n_fix = cfg.mlp_dynamic_expert_num, cfg.mlp_fixed_expert_num
     n_dyn = n_real + cfg.mlp_dynamic_null_expert_num
@@ -106,6 +106,12 @@ def forward(cfg, weights: Dict[str, torch.Tensor], hidden_states: torch.Tensor, 
     if n_fix:
         mask[:, n_dyn:] = 1
     aux = aux_loss(mask, n_dyn, logits, aux_balance_weight)
+    if cfg.token_drop:                                         # core.py:302-329 (capacity :170-175)
+        from .dcmoe import capacity_of, drop_keep_mask
+        cap = capacity_of(x.shape[0], n_dyn, cfg.capacity_factor, cfg.min_capacity)
+        mask = drop_keep_mask(logits.detach(), mask, n_dyn, cap, cfg.drop_policy)
+        rw = rw.masked_fill(~(mask[:, :n_dyn].bool()), 0.0)
+        rw = rw / (rw.sum(dim=-1, keepdim=True) + 1e-6)        # :328-329
     if n_fix:
         g = torch.softmax(logits.masked_fill(mask == 0, float("-inf")), dim=-1)
         gw = torch.cat([rw * g[:, :n_dyn].sum(-1, keepdim=True), g[:, n_dyn:]], dim=-1)

@@ -202,6 +202,9 @@ def gen_dcmoe_bwd(ref, out):
         eval_bf16gate=dict(_train=False),
         train_pad_auxw=dict(_train=True, _pad=True, _auxw=True),
         train_topk2=dict(_train=True, mlp_dynamic_top_p=0.0, mlp_dynamic_top_k=2),
+        # token-drop branch in the graph (core.py:302-329): capacity = ceil(72 / 9 * 1.0) = 8 rows per column
+        train_drop_probs=dict(_train=True, token_drop=True, drop_policy="probs", capacity_factor=1.0, min_capacity=2),
+        train_drop_pos=dict(_train=True, token_drop=True, drop_policy="position", capacity_factor=1.0, min_capacity=2),
     )
     for vi, (name, over) in enumerate(variants.items()):
         over = dict(over)
@@ -231,6 +234,13 @@ def gen_dcmoe_bwd(ref, out):
             o = blk(x, am, aw)
         loss = (o[0].float() * G.float()).sum() + aux_coef * o[5].float()
         loss.backward()
+        if c.token_drop and c.drop_policy == "probs":
+            # the fixture must not hinge on torch.topk's unspecified order among equal values: the capacity-th and the next
+            # selected logit of every column differ
+            lg = o[1].detach().float()
+            n_dyn = c.mlp_dynamic_expert_num + c.mlp_dynamic_null_expert_num
+            cap = max(int(np.ceil(np.float32(B * T / n_dyn) * np.float32(c.capacity_factor))), c.min_capacity)
+            assert int(o[3][:, :n_dyn].sum(0).max()) == cap, "no column is at capacity: nothing was dropped"
         d = {"in_x": x.detach(), "in_G": G, "aux_coef": np.array(aux_coef, dtype=np.float32), "out_hidden": o[0].detach(),
              "out_logits": o[1].detach(), "out_top_k": o[2], "out_mask": o[3], "out_weight": o[4].detach(), "out_aux": o[5].detach(),
              "out_sel": rec.selection(o[2].long(), c.mlp_dynamic_expert_num + c.mlp_dynamic_null_expert_num),

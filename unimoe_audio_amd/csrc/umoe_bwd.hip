@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void router_bwd_kernel(const void* __restrict_
                                                          const int64_t* __restrict__ top_k, const int32_t* __restrict__ mask,
                                                          const float* __restrict__ d_moe_w, const float* __restrict__ d_gw_shared,
                                                          const float* __restrict__ d_logits_in, int S, int n_dyn, int n_real, int n_fix,
-                                                         float jitter_eps, float* __restrict__ d_logits) {
+                                                         float jitter_eps, float* __restrict__ d_logits, int drop) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= S) return;
     const int E = n_dyn + n_fix;
@@ -326,6 +326,30 @@ __global__ __launch_bounds__(256) void router_bwd_kernel(const void* __restrict_
             dGd += dgw * rw[e] * Rinv;
         }
     }
+    float Q = 0.f;       // token drop (core.py:328-329): r2 = q / (Q + 1e-6), q = r * mask_after_drop; gw = r2 * Gd
+    if (drop) {
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < n_dyn && m[e] != 0) Q += rw[e] * Rinv;
+        const float Qinv = 1.f / (Q + 1e-6f);
+        dGd = 0.f;
+        float qdot = 0.f;   // sum_j dr2[j] * q[j]
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < n_real && m[e] != 0) {
+                const float dgw = d_moe_w[(size_t)s * n_real + e];
+                const float q = rw[e] * Rinv;
+                dGd += dgw * q * Qinv;
+                qdot += dgw * Gd * q;
+            }
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e) {
+            // dr2[e] = dgw[e] * Gd on kept real experts; dq = dr2 * Qinv - qdot * Qinv^2 on every kept dynamic column; dr = dq * mask
+            float dq = 0.f;
+            if (e < n_dyn && m[e] != 0) dq = (e < n_real ? d_moe_w[(size_t)s * n_real + e] * Gd : 0.f) * Qinv - qdot * Qinv * Qinv;
+            dr[e] = dq;
+        }
+    }
 #pragma unroll
     for (int e = 0; e < UMOE_MAXE; ++e) {
         if (e < n_dyn) dG[e] = dGd;
@@ -396,7 +420,21 @@ extern "C" int umoe_router_bwd(const void* logits, int logits_bf16, const int32_
     if (S == 0) return 0;
     router_bwd_kernel<<<dim3((unsigned)ceil_div(S, 256)), 256, 0, (hipStream_t)stream>>>(
         logits, logits_bf16, sel, top_k, expert_mask, d_moe_w, d_gw_shared, d_logits_in, S, n_dyn, n_real, n_fix, (float)jitter_eps,
-        d_logits);
+        d_logits, 0);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int umoe_router_bwd_drop(const void* logits, int logits_bf16, const int32_t* sel, const int64_t* top_k, const int32_t* expert_mask,
+                                    const float* d_moe_w, const float* d_gw_shared, const float* d_logits_in, int S, int n_dyn, int n_real,
+                                    int n_fix, double jitter_eps, float* d_logits, umoe_stream_t stream) {
+    UMOE_REQUIRE(logits && sel && top_k && expert_mask && d_moe_w && d_logits, "umoe_router_bwd_drop: null argument");
+    UMOE_REQUIRE(n_dyn >= 1 && n_dyn + n_fix <= UMOE_MAXE && n_real <= n_dyn && (n_fix == 0 || d_gw_shared),
+                 "umoe_router_bwd_drop: bad sizes n_dyn=%d n_real=%d n_fix=%d", n_dyn, n_real, n_fix);
+    if (S == 0) return 0;
+    router_bwd_kernel<<<dim3((unsigned)ceil_div(S, 256)), 256, 0, (hipStream_t)stream>>>(
+        logits, logits_bf16, sel, top_k, expert_mask, d_moe_w, d_gw_shared, d_logits_in, S, n_dyn, n_real, n_fix, (float)jitter_eps,
+        d_logits, 1);
     UMOE_LAUNCH_CHECK();
     return 0;
 }

@@ -923,7 +923,10 @@ __global__ __launch_bounds__(256) void aux_loss_kernel(const void* __restrict__ 
     for (int e = 0; e < UMOE_MAXE; ++e)
         if (e < n_dyn) {
             const float a = block_sum_256(fm[e], sh), b = block_sum_256(fp[e], sh);
-            total += (a / wsum) * (b / wsum);
+            // torch.mean of the bf16 probabilities returns bf16 (fp32 accumulate, ONE rounding, core.py:378); the token-weighted
+            // branch multiplies by the fp32 weights first and stays in fp32 (core.py:384-385)
+            const float pm = (!tok_w && logits_bf16) ? rbf(b / wsum) : b / wsum;
+            total += (a / wsum) * pm;
         }
     if (threadIdx.x == 0) *out = total * (float)n_dyn;
 }

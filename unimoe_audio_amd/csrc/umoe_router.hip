@@ -277,3 +277,169 @@ extern "C" int umoe_permute_fwd(const uint16_t* x, int D, const int32_t* slot_to
     UMOE_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------ token drop
+// Replaces the token-drop branch of UniMoEAudioSparseMoeBlock.forward (core.py:302-329; capacity :170-175):
+//   "probs"    per dynamic column keep the `capacity` selected tokens with the largest logits (reference: topk(dim=0) over the
+//              column with unselected entries filled with finfo.min, :305-314);
+//   "position" per column -- ALL E columns, the shared ones too, as the reference's cumsum over the whole mask does -- keep the
+//              first `capacity` selected tokens in token order (:321-323);
+// then routing weights are zeroed on dropped entries and renormalised (:328-329) and the global weights recomputed over the
+// kept columns (:178-193).  Two launches: one workgroup per column selects (radix select on the order-preserving integer image
+// of the logit + index-ordered tie break, or a prefix count), one wave per token finishes with the router's lane-per-column
+// arithmetic.  torch.topk leaves the order among EQUAL values unspecified; here ties at the capacity boundary keep the lowest
+// token indices (identical to the reference whenever the capacity-th and the next logit of a column differ).
+__device__ __forceinline__ uint32_t drop_key(const void* logits, int is_bf16, size_t idx) {
+    if (is_bf16) {
+        const uint32_t u = reinterpret_cast<const uint16_t*>(logits)[idx];
+        return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);          // 16-bit key, larger logit = larger key
+    }
+    const uint32_t u = __float_as_uint(reinterpret_cast<const float*>(logits)[idx]);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void token_drop_select_kernel(const void* __restrict__ logits, int is_bf16, const int32_t* __restrict__ mask_in,
+                                                                int S, int E, int n_dyn, int capacity, int policy,
+                                                                int32_t* __restrict__ mask_out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned scan[256];
+    __shared__ unsigned bcast[2];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int per = (S + 255) / 256, t0 = tid * per, t1 = min(t0 + per, S);   // contiguous token range per thread: index order
+    if (policy == 0 && e >= n_dyn) {       // shared columns are never dropped by "probs" (keep[:, n_dyn:] = 1)
+        for (int s = tid; s < S; s += 256) mask_out[(size_t)s * E + e] = mask_in[(size_t)s * E + e];
+        return;
+    }
+    unsigned thr_key = 0;      // probs: kept = key > thr_key, plus the first `need_eq` tokens with key == thr_key
+    unsigned need_eq = 0;
+    bool keep_all = false;
+    if (policy == 0) {
+        unsigned cnt = 0;
+        for (int s = t0; s < t1; ++s) cnt += mask_in[(size_t)s * E + e] != 0;
+        scan[tid] = cnt;
+        __syncthreads();
+        unsigned total = 0;
+        for (int i = 0; i < 256; ++i) total += scan[i];
+        __syncthreads();
+        if ((int)total <= capacity) {
+            keep_all = true;
+        } else {
+            // radix select, most significant byte first: find the key of the capacity-th largest selected logit
+            const int bits = is_bf16 ? 16 : 32;
+            unsigned prefix = 0, want = (unsigned)capacity;     // `want` largest remain to be found among keys matching `prefix`
+            for (int shift = bits - 8; shift >= 0; shift -= 8) {
+                hist[tid] = 0;
+                __syncthreads();
+                const unsigned hi_mask = (shift + 8 >= 32) ? 0u : (0xffffffffu << (shift + 8));
+                for (int s = t0; s < t1; ++s)
+                    if (mask_in[(size_t)s * E + e] != 0) {
+                        const unsigned k = drop_key(logits, is_bf16, (size_t)s * E + e);
+                        if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+                    }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned acc = 0;
+                    int b = 255;
+                    for (; b > 0; --b) {
+                        if (acc + hist[b] >= want) break;
+                        acc += hist[b];
+                    }
+                    bcast[0] = (unsigned)b;
+                    bcast[1] = want - acc;           // still to take inside bin b
+                }
+                __syncthreads();
+                prefix |= bcast[0] << shift;
+                want = bcast[1];
+                __syncthreads();
+            }
+            thr_key = prefix;
+            need_eq = want;
+        }
+    }
+    // index-ordered prefix over the candidates of the tie break (probs) or over the selected tokens (position)
+    unsigned mine = 0;
+    for (int s = t0; s < t1; ++s) {
+        const bool sel = mask_in[(size_t)s * E + e] != 0;
+        if (policy == 1) mine += sel;
+        else if (!keep_all) mine += sel && drop_key(logits, is_bf16, (size_t)s * E + e) == thr_key;
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    unsigned before = 0;
+    for (int i = 0; i < tid; ++i) before += scan[i];
+    for (int s = t0; s < t1; ++s) {
+        const int m = mask_in[(size_t)s * E + e];
+        int out = m;
+        if (m != 0) {
+            if (policy == 1) {
+                out = before < (unsigned)capacity ? m : 0;
+                before += 1;
+            } else if (!keep_all) {
+                const unsigned k = drop_key(logits, is_bf16, (size_t)s * E + e);
+                if (k > thr_key) out = m;
+                else if (k == thr_key) { out = before < need_eq ? m : 0; before += 1; }
+                else out = 0;
+            }
+        }
+        mask_out[(size_t)s * E + e] = out;
+    }
+}
+
+template <int TB>
+__global__ __launch_bounds__(256) void token_drop_finish_kernel(const void* __restrict__ logits, const int32_t* __restrict__ mask, const float* __restrict__ routing_in,
+                                                                int S, int n_dyn, int n_real, int n_fix, float* __restrict__ routing_out,
+                                                                float* __restrict__ global_w, float* __restrict__ moe_w) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= S) return;
+    const int E = n_dyn + n_fix;
+    float full = -INFINITY;
+    int m = 0;
+    if (lane < E) {
+        full = TB ? bf2f(reinterpret_cast<const uint16_t*>(logits)[(size_t)s * E + lane]) : reinterpret_cast<const float*>(logits)[(size_t)s * E + lane];
+        m = mask[(size_t)s * E + lane];
+    }
+    float w = (lane < n_dyn && m != 0) ? routing_in[(size_t)s * n_dyn + lane] : 0.f;      // masked_fill(~mask, 0)
+    float ws[UMOE_MAXE];
+    gather16<0>(w, n_dyn, 0.f, ws);
+    float sum = ws[0];
+#pragma unroll
+    for (int j = 1; j < UMOE_MAXE; ++j)
+        if (j < n_dyn) sum = sum + ws[j];
+    sum = round_t(sum, TB);
+    const float den = round_t(sum + 1e-6f, TB);
+    w = (lane < n_dyn) ? round_t(w / den, TB) : 0.f;                                        // core.py:328-329
+    float gw = w;
+    {
+        const float gl = (lane < E && m) ? full : -INFINITY;                                 // core.py:188
+        gw = lane_softmax<0, TB>(gl, E, lane);
+        float gs[UMOE_MAXE];
+        gather16<0>(gw, n_dyn, 0.f, gs);
+        float ds = gs[0];
+#pragma unroll
+        for (int j = 1; j < UMOE_MAXE; ++j)
+            if (j < n_dyn) ds = ds + gs[j];
+        ds = round_t(ds, TB);
+        if (lane < n_dyn) gw = round_t(w * ds, TB);
+    }
+    if (lane < E && global_w) global_w[(size_t)s * E + lane] = gw;
+    if (lane < n_dyn && routing_out) routing_out[(size_t)s * n_dyn + lane] = w;
+    if (lane < n_real && moe_w) moe_w[(size_t)s * n_real + lane] = gw * (float)(m != 0);
+}
+
+extern "C" int umoe_token_drop(const void* logits, int logits_bf16, const int32_t* expert_mask_in, const float* routing_w_in, int S,
+                               int n_dyn, int n_real, int n_fix, int capacity, int policy, int32_t* expert_mask_out,
+                               float* routing_w_out, float* global_w, float* moe_w, umoe_stream_t stream) {
+    UMOE_REQUIRE(logits && expert_mask_in && routing_w_in && expert_mask_out && expert_mask_out != expert_mask_in,
+                 "umoe_token_drop: null argument (the mask is not updated in place)");
+    UMOE_REQUIRE(policy == 0 || policy == 1, "umoe_token_drop: policy must be 0 (probs) or 1 (position)");     // core.py:325 raises ValueError
+    UMOE_REQUIRE(n_dyn >= 1 && n_dyn + n_fix <= UMOE_MAXE && n_real <= n_dyn && capacity >= 0, "umoe_token_drop: bad sizes");
+    if (S == 0) return 0;
+    const int E = n_dyn + n_fix;
+    hipStream_t st = (hipStream_t)stream;
+    token_drop_select_kernel<<<dim3((unsigned)E), 256, 0, st>>>(logits, logits_bf16, expert_mask_in, S, E, n_dyn, policy == 0 ? min(capacity, S) : capacity, policy, expert_mask_out);
+    UMOE_LAUNCH_CHECK();
+    if (logits_bf16) token_drop_finish_kernel<1><<<dim3((unsigned)ceil_div(S, 4)), 256, 0, st>>>(logits, expert_mask_out, routing_w_in, S, n_dyn, n_real, n_fix, routing_w_out, global_w, moe_w);
+    else token_drop_finish_kernel<0><<<dim3((unsigned)ceil_div(S, 4)), 256, 0, st>>>(logits, expert_mask_out, routing_w_in, S, n_dyn, n_real, n_fix, routing_w_out, global_w, moe_w);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}

@@ -165,9 +165,8 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         n_dyn, n_real, n_fix = self.mlp_dynamic_expert_num, self.mlp_dynamic_real_expert_num, self.mlp_fixed_expert_num
         if torch.is_grad_enabled() and (hidden_states.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training: forward + backward on the HIP kernels (shipped configuration)
-            if self.token_drop or int(self.dynamic_real_moe.ep_size) > 1 or not self.ignore_differentiable_router:
-                raise NotImplementedError("HIP backward covers the shipped configuration: ignore_differentiable_router=True, "
-                                          "token_drop=False, ep_size=1")
+            if int(self.dynamic_real_moe.ep_size) > 1 or not self.ignore_differentiable_router:
+                raise NotImplementedError("HIP backward covers ignore_differentiable_router=True (the shipped setting) at ep_size=1")
             for p_ in self.parameters():
                 if p_.dtype != torch.bfloat16 or not p_.is_contiguous():
                     raise L.UmoeError("training needs contiguous bfloat16 parameters")
@@ -187,8 +186,10 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         top_k = r["top_k"] if self.mlp_dynamic_top_p != 0 else r["top_k"].to(torch.int32)
         aux = aux_loss(expert_mask, n_dyn, logits, aux_balance_weight)         # core.py:293
         global_w, moe_w = r["global_weight"], r["moe_weight"]
-        if self.token_drop:
-            expert_mask, global_w, moe_w = self._token_drop(logits, expert_mask, r["routing_weights"], S)
+        if self.token_drop:                                                    # core.py:302-329
+            td = ops.token_drop(logits, expert_mask, r["routing_weights"], n_dyn=n_dyn, n_real=n_real, n_fix=n_fix,
+                                capacity=ops.expert_capacity(S, n_dyn, self.capacity_factor, self.min_capacity), policy=self.drop_policy)
+            expert_mask, global_w, moe_w = td["expert_mask"], td["global_weight"], td["moe_weight"]
         disp = ops.dispatch_build(expert_mask, n_real)
         I_d, I_s = self.dynamic_intermediate_size, self.shared_intermediate_size
         ep = int(self.dynamic_real_moe.ep_size)
@@ -276,33 +277,6 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         ops.grouped_gemm(ops.GroupTable(dn, x.device), hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D)
         return ybuf
 
-    # ---- rarely used branch, device torch ops (shipped config: token_drop = false) ------------------------
-    def _token_drop(self, logits, expert_mask, routing_w, num_tokens):
-        n_dyn = self.mlp_dynamic_expert_num
-        dt = logits.dtype
-        cap = int(torch.ceil(torch.tensor(num_tokens / n_dyn) * torch.tensor(self.capacity_factor)).to(torch.int64))
-        cap = max(cap, int(self.min_capacity))
-        dyn_logits = logits[:, :n_dyn]
-        mdt = expert_mask.dtype
-        if self.drop_policy == "probs":
-            cap = min(cap, dyn_logits.shape[0])
-            dm = expert_mask[:, :n_dyn].bool()
-            filled = dyn_logits.masked_fill(~dm, torch.finfo(dt).min)
-            _, idx = torch.topk(filled, k=cap, dim=0, sorted=False)
-            keep = torch.zeros_like(expert_mask).scatter(0, idx, 1)
-            keep[:, n_dyn:] = 1
-            expert_mask = torch.logical_and(expert_mask, keep).to(mdt)
-        else:
-            loc = torch.cumsum(expert_mask, dim=0) - 1
-            expert_mask = (expert_mask * torch.lt(loc, cap)).to(mdt)
-        rw = routing_w.to(dt).masked_fill(~(expert_mask[:, :n_dyn].bool()), 0.0)
-        rw = rw / (rw.sum(dim=-1, keepdim=True) + 1e-6)
-        gw = torch.softmax(logits.masked_fill(expert_mask == 0, float("-inf")), dim=-1)
-        gdyn = rw * gw[:, :n_dyn].sum(-1, keepdim=True)
-        global_w = torch.cat((gdyn, gw[:, n_dyn:]), dim=-1).float()
-        moe_w = (global_w[:, : self.mlp_dynamic_real_expert_num] * expert_mask[:, : self.mlp_dynamic_real_expert_num]).contiguous()
-        return expert_mask.contiguous(), global_w.contiguous(), moe_w
-
 
 def aux_loss(expert_mask, n_dyn, full_logits, aux_balance_weight=None):
     """reference audio_load_balancing_loss_func, core.py:361-389 (one HIP launch, fixed-order reductions)."""
@@ -347,7 +321,12 @@ class _DCMoETrainFn(torch.autograd.Function):
         if aux_balance_weight is not None:
             b, t = aux_balance_weight.shape
             tw = aux_balance_weight.reshape(1, b * t).expand(S // (b * t), -1).reshape(-1).to(x.device).float().contiguous()
-        aux = ops.aux_loss(logits, mask, n_dyn, tw)
+        aux = ops.aux_loss(logits, mask, n_dyn, tw)                     # on the mask BEFORE the drop (core.py:293)
+        mask0 = mask
+        if blk.token_drop:                                              # core.py:302-329
+            td = ops.token_drop(logits, mask, r["routing_weights"], n_dyn=n_dyn, n_real=n_real, n_fix=n_fix,
+                                capacity=ops.expert_capacity(S, n_dyn, blk.capacity_factor, blk.min_capacity), policy=blk.drop_policy)
+            mask, moe_w, global_w = td["expert_mask"], td["moe_weight"], td["global_weight"]
         disp = ops.dispatch_build_aligned(mask, n_real, 8)
         cap = ops._r8(disp["cap"])                       # routed slot rows [0, cap); shared expert i at cap + i*S
         rows_total = cap + n_fix * S
@@ -368,7 +347,7 @@ class _DCMoETrainFn(torch.autograd.Function):
         y_sh = ybuf[cap:] if n_fix else None
         out = ops.combine(ybuf, disp["slot_of"], moe_w, y_sh, global_w, None, n_dyn, n_fix)
         ctx.blk, ctx.dims = blk, (S, D, n_dyn, n_real, n_fix, I_d, I_s, Imax, cap, rows_total)
-        ctx.disp, ctx.tw, ctx.noise = disp, tw, noise
+        ctx.disp, ctx.tw, ctx.noise, ctx.mask0 = disp, tw, noise, mask0
         ctx.save_for_backward(x, logits, r["sel"], r["top_k"], mask, moe_w, global_w, hbuf, gu, ybuf, *params)
         top_k = r["top_k"] if blk.mlp_dynamic_top_p != 0 else r["top_k"].to(torch.int32)
         gw_out = global_w.to(x.dtype)
@@ -411,8 +390,9 @@ class _DCMoETrainFn(torch.autograd.Function):
         # 6. router: d(moe_w), d(shared weights), d(aux) -> d(logits) -> gate weight and input gradients
         d_lg_aux = None
         if d_aux is not None:
-            d_lg_aux = ops.aux_loss_bwd(logits, mask, n_dyn, ctx.tw, d_aux)
-        d_lg = ops.router_bwd(logits, sel, top_k, mask, d_mw, d_gs, d_lg_aux, n_dyn, n_real, n_fix, float(blk.router_jitter_noise))
+            d_lg_aux = ops.aux_loss_bwd(logits, ctx.mask0, n_dyn, ctx.tw, d_aux)
+        d_lg = ops.router_bwd(logits, sel, top_k, mask, d_mw, d_gs, d_lg_aux, n_dyn, n_real, n_fix, float(blk.router_jitter_noise),
+                              token_drop=bool(blk.token_drop))
         E = n_dyn + n_fix
         dl16 = torch.zeros((S, 16), dtype=bf, device=dev)
         dl16[:, :E] = d_lg.to(bf)

@@ -139,6 +139,31 @@ def aux_loss(logits: torch.Tensor, expert_mask: torch.Tensor, n_dyn: int, token_
     return out[0]
 
 
+def expert_capacity(num_tokens: int, num_experts: int, capacity_factor: float, min_capacity: int) -> int:
+    """reference _audio_expert_capacity (core.py:170-175) in its float32 tensor arithmetic: max(ceil(S / E * cf), min_capacity)."""
+    import numpy as np
+    c = int(np.ceil(np.float32(num_tokens / num_experts) * np.float32(capacity_factor)))
+    return max(c, int(min_capacity))
+
+
+def token_drop(logits: torch.Tensor, expert_mask: torch.Tensor, routing_w: torch.Tensor, *, n_dyn: int, n_real: int, n_fix: int,
+               capacity: int, policy: str) -> dict:
+    """Token-drop branch of the block (core.py:302-329) as two HIP launches; returns the post-drop expert_mask, the renormalised
+    routing weights and the recomputed global / MoE weights."""
+    if policy not in ("probs", "position"):
+        raise ValueError(f"Invalid drop_policy: {policy}")                 # core.py:325
+    S, E = logits.shape
+    dev = logits.device
+    o = dict(expert_mask=torch.empty((S, E), dtype=torch.int32, device=dev),
+             routing_weights=torch.empty((S, n_dyn), dtype=torch.float32, device=dev),
+             global_weight=torch.empty((S, E), dtype=torch.float32, device=dev),
+             moe_weight=torch.empty((S, n_real), dtype=torch.float32, device=dev))
+    L.check(L.lib().umoe_token_drop(_p(logits.contiguous()), int(logits.dtype == torch.bfloat16), _p(expert_mask), _p(routing_w), S, n_dyn, n_real,
+                                    n_fix, int(capacity), 0 if policy == "probs" else 1, _p(o["expert_mask"]), _p(o["routing_weights"]),
+                                    _p(o["global_weight"]), _p(o["moe_weight"]), _stream()), "umoe_token_drop")
+    return o
+
+
 def dispatch_build(expert_mask: torch.Tensor, n_real: int) -> dict:
     S, ld = expert_mask.shape
     dev = expert_mask.device
@@ -450,10 +475,12 @@ def permute_bwd(dxe, slot_of, dx_shared, n_fix: int, extra=None):
 
 
 def router_bwd(logits, sel, top_k, expert_mask, d_moe_w, d_gw_shared, d_logits_in, n_dyn: int, n_real: int, n_fix: int,
-               jitter_eps: float) -> torch.Tensor:
+               jitter_eps: float, token_drop: bool = False) -> torch.Tensor:
+    """token_drop: `expert_mask` is the mask AFTER the drop and the extra renormalisation of core.py:328-329 is in the graph."""
     S, E = logits.shape
     out = torch.empty((S, E), dtype=torch.float32, device=logits.device)
-    L.check(L.lib().umoe_router_bwd(_p(logits), int(logits.dtype == torch.bfloat16), _p(sel), _p(top_k), _p(expert_mask), _p(d_moe_w),
+    fn = L.lib().umoe_router_bwd_drop if token_drop else L.lib().umoe_router_bwd
+    L.check(fn(_p(logits), int(logits.dtype == torch.bfloat16), _p(sel), _p(top_k), _p(expert_mask), _p(d_moe_w),
                                     _p(d_gw_shared), _p(d_logits_in), S, n_dyn, n_real, n_fix, float(jitter_eps), _p(out), _stream()),
             "umoe_router_bwd")
     return out
