@@ -76,6 +76,14 @@ typedef struct {
     int norm_only;            /* 1: only h_out = RMSNorm(x) with the router's own arithmetic (x, norm_w, h_out; S <= 256, D 2048 / 4096):
                                * the launch the decode engine puts in front of the expert GEMM when the router itself rides inside
                                * that GEMM's launch (umoe_gemm_args.fused_router) */
+    /* training branch of the mixer (core.py:111-137; `training and not ignore_differentiable_router`), taken when `gumbel` is set:
+     * round j selects arg-max(masked_gates + gumbel[s][j][:]) instead of the arg-max, and its weight is the softmax multiplier times
+     * mask_for_one = 1 if (selected == arg-max of the softmaxed gates or rand_u[s][j] > 0.75) else 0.3333.  The noise is an INPUT
+     * (the reference draws gumbel_rsample / torch.rand_like per call): the host supplies it, tests inject the reference's draws. */
+    const float* gumbel;      /* optional [S][n_dyn][n_dyn] fp32 Gumbel(0,1) noise, round-major per token */
+    const float* rand_u;      /* [S][n_dyn] fp32 uniform [0,1) draws, one per (token, round); required with gumbel */
+    float* round_factor;      /* optional out [S][n_dyn]: mask_for_one of round j as 1 / 0.3333 (T-rounded), 0 beyond k; kept for
+                               * umoe_router_bwd_ex (AudioMoERoutingFunction.backward, core.py:64-91) */
 } umoe_router_args;
 int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 
@@ -313,6 +321,12 @@ int umoe_permute_bwd(const uint16_t* dxe, const int32_t* slot_of, int n_real, co
 int umoe_router_bwd(const void* logits, int logits_bf16, const int32_t* sel, const int64_t* top_k, const int32_t* expert_mask,
                     const float* d_moe_w, const float* d_gw_shared, const float* d_logits_in, int S, int n_dyn, int n_real,
                     int n_fix, double jitter_eps, float* d_logits, umoe_stream_t stream);
+/* general form: token_drop as in umoe_router_bwd_drop; round_factor (optional [S][n_dyn], umoe_router_args.round_factor) = the
+ * differentiable-router training branch: the forward weights carry mask_for_one, the gradient is AudioMoERoutingFunction.backward
+ * (core.py:64-91: grad * multiplier * (onehot(selected) - masked_gates), mask_for_one not differentiated) */
+int umoe_router_bwd_ex(const void* logits, int logits_bf16, const int32_t* sel, const int64_t* top_k, const int32_t* expert_mask,
+                       const float* d_moe_w, const float* d_gw_shared, const float* d_logits_in, int S, int n_dyn, int n_real,
+                       int n_fix, double jitter_eps, int token_drop, const float* round_factor, float* d_logits, umoe_stream_t stream);
 /* the same with the token-drop branch in the graph (core.py:328-329): `expert_mask` is then the mask AFTER the drop and the routing
  * weights pass through r2 = (r * mask) / (sum(r * mask) + 1e-6) before the global weights */
 int umoe_router_bwd_drop(const void* logits, int logits_bf16, const int32_t* sel, const int64_t* top_k, const int32_t* expert_mask,

@@ -38,6 +38,55 @@ def _top_p_count(dyn_logits: torch.Tensor, top_p: float) -> torch.Tensor:
         return (~(ps.cumsum(dim=-1) >= top_p)).sum(dim=-1) + 1
 
 
+class _RoutingFn(torch.autograd.Function):
+    """AudioMoERoutingFunction (core.py:64-91): forward multiplier * mask_for_one; backward hands `scores` the gradient
+    grad * multiplier * (onehot(selected) - masked_gates) and nothing to the other inputs."""
+
+    @staticmethod
+    def forward(ctx, scores, multiplier, selected, gates, mask_for_one):
+        ctx.save_for_backward(multiplier, selected, gates)
+        return multiplier * mask_for_one
+
+    @staticmethod
+    def backward(ctx, g):
+        multiplier, selected, gates = ctx.saved_tensors
+        g = g * multiplier
+        out = gates * g.mul(-1)
+        out.scatter_add_(dim=-1, index=selected, src=g)
+        return out, None, None, None, None
+
+
+def routing_weights_train(dyn_logits: torch.Tensor, k: torch.Tensor, jitter_eps: float, gumbel: torch.Tensor, rand: torch.Tensor):
+    """The mixer's TRAINING branch (core.py:111-137) with its noise as inputs (gumbel [S, n_dyn, n_dyn], rand [S, n_dyn], one slice
+    per round): round j selects arg-max(masked_gates + gumbel_j), weighs it by the softmax multiplier * mask_for_one, where
+    mask_for_one = 1 if (selected == arg-max of the softmaxed gates or rand_j > 0.75) else 0.3333; gradient by _RoutingFn.
+    -> (weights [S, n_dyn], selection mask [S, n_dyn] int, selection order [S, n_dyn] int32 (-1 beyond k))."""
+    S, n = dyn_logits.shape
+    taken = torch.zeros((S, n), dtype=torch.bool)
+    w = torch.zeros_like(dyn_logits)
+    order = torch.full((S, n), -1, dtype=torch.int32)
+    for j in range(int(k.max()) if S else 0):
+        live = (k > j).unsqueeze(-1)
+        masked = dyn_logits.masked_fill(taken, float("-inf"))
+        with torch.no_grad():
+            mx, _ = masked.max(dim=-1, keepdim=True)
+            factor = dyn_logits.abs().clamp(min=mx.abs())
+            far = ((mx - dyn_logits) / factor) > (2 * jitter_eps)
+        gates = masked.masked_fill(far, float("-inf"))
+        sel = (gates + gumbel[:, j]).max(dim=-1)[1].unsqueeze(-1)
+        gates = torch.softmax(gates, dim=-1)
+        mo = gates.gather(dim=-1, index=sel)
+        _, mi = gates.max(dim=-1, keepdim=True)
+        one = torch.logical_or(sel == mi, rand[:, j:j + 1] > 0.75)
+        one = torch.add(0.3333, one, alpha=0.6667).type_as(gates)
+        mult = _RoutingFn.apply(dyn_logits, mo, sel, gates, one)
+        pick = torch.zeros((S, n), dtype=torch.bool).scatter(1, sel, True) & live
+        w = w + torch.where(pick, torch.zeros_like(w).scatter(1, sel, mult), torch.zeros_like(w))
+        order[:, j] = torch.where(live.squeeze(-1), sel.squeeze(-1).to(torch.int32), order[:, j])
+        taken = taken | pick
+    return w, taken.to(torch.int32), order
+
+
 def routing_weights(dyn_logits: torch.Tensor, k: torch.Tensor, jitter_eps: float, forced_set: Optional[torch.Tensor] = None):
     """-> (weights [S, n_dyn] differentiable, selection mask [S, n_dyn] int): round j acts on the tokens with k > j.
     forced_set [S, n_dyn] bool (tests only): rows whose set has exactly k members pick inside that set -- teacher forcing of
@@ -77,9 +126,9 @@ def aux_loss(mask: torch.Tensor, n_dyn: int, logits: torch.Tensor, aux_balance_w
 
 
 def forward(cfg, weights: Dict[str, torch.Tensor], hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-            aux_balance_weight: Optional[torch.Tensor] = None, training: bool = True, forced=None):
-    """-> (out [B,T,D], logits, top_k, expert_mask, global_weight, aux); differentiable in hidden_states and weights."""
-    assert cfg.ignore_differentiable_router
+            aux_balance_weight: Optional[torch.Tensor] = None, training: bool = True, forced=None, noise=None):
+    """-> (out [B,T,D], logits, top_k, expert_mask, global_weight, aux); differentiable in hidden_states and weights.
+    noise = (gumbel, rand): required when the mixer's training branch runs (training and not ignore_differentiable_router)."""
     B, T, D = hidden_states.shape
     n_real, n_fix = cfg.mlp_dynamic_expert_num, cfg.mlp_fixed_expert_num
     n_dyn = n_real + cfg.mlp_dynamic_null_expert_num
@@ -98,7 +147,11 @@ def forward(cfg, weights: Dict[str, torch.Tensor], hidden_states: torch.Tensor, 
     if forced is not None:                                     # (top_k [S], expert_mask [S, E]) of another run: teacher forcing
         k = forced[0].long()
         forced_set = forced[1][:, :n_dyn] != 0
-    rw, sel = routing_weights(dyn, k, float(cfg.router_jitter_noise), forced_set)
+    if training and not cfg.ignore_differentiable_router:
+        assert noise is not None and forced is None
+        rw, sel, _ = routing_weights_train(dyn, k, float(cfg.router_jitter_noise), noise[0], noise[1])
+    else:
+        rw, sel = routing_weights(dyn, k, float(cfg.router_jitter_noise), forced_set)
     rw = rw / (rw.sum(dim=-1, keepdim=True) + 1e-6)
     mask = torch.cat([sel, torch.zeros((sel.shape[0], n_fix), dtype=torch.int32)], dim=-1)
     if attention_mask is not None:

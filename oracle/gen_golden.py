@@ -92,6 +92,52 @@ class MixerRecorder:
         return sel
 
 
+class NoiseInjector:
+    """Replaces the random draws of the reference mixer's training branch (core.py:111-126) by slices of fixed per-token tensors:
+    `gumbel_rsample(shape)` -> gumbel[group rows, round], `torch.rand_like(max_scores)` -> rand[group rows, round].  The group of a
+    mixer call = the tokens whose Top-P count equals the call's top_k (core.py:262-266), recovered from the captured counts."""
+
+    def __init__(self, core, gumbel, rand):
+        self.core, self.gumbel, self.rand = core, gumbel, rand
+        self.rounds_served = 0
+
+    def __enter__(self):
+        core = self.core
+        self.o_sel, self.o_mix, self.o_gum, self.o_rand = (core.audio_dynamic_expert_selection, core.audio_sparse_expert_mixer,
+                                                           core.gumbel_rsample, torch.rand_like)
+        st = {}
+
+        def sel(logits, p):
+            k = self.o_sel(logits, p)
+            st["k"] = k.clone()
+            return k
+
+        def mix(scores, top_k, jitter_eps, training):
+            st["idx"] = torch.nonzero(st["k"] == top_k, as_tuple=True)[0]
+            st["round"] = 0
+            assert st["idx"].numel() == scores.shape[0]
+            return self.o_mix(scores, top_k, jitter_eps, training)
+
+        def gum(shape, device):
+            out = self.gumbel[st["idx"], st["round"]]
+            assert tuple(out.shape) == tuple(shape)
+            return out
+
+        def rnd(t, *a, **k):
+            out = self.rand[st["idx"], st["round"]].reshape(t.shape).to(t.dtype)
+            st["round"] += 1
+            self.rounds_served += 1
+            return out
+
+        core.audio_dynamic_expert_selection, core.audio_sparse_expert_mixer, core.gumbel_rsample, torch.rand_like = sel, mix, gum, rnd
+        return self
+
+    def __exit__(self, *a):
+        core = self.core
+        core.audio_dynamic_expert_selection, core.audio_sparse_expert_mixer, core.gumbel_rsample, torch.rand_like = (
+            self.o_sel, self.o_mix, self.o_gum, self.o_rand)
+
+
 def gen_router_ids(ref, out):
     core = ref.core
     torch.manual_seed(100)
@@ -205,12 +251,18 @@ def gen_dcmoe_bwd(ref, out):
         # token-drop branch in the graph (core.py:302-329): capacity = ceil(72 / 9 * 1.0) = 8 rows per column
         train_drop_probs=dict(_train=True, token_drop=True, drop_policy="probs", capacity_factor=1.0, min_capacity=2),
         train_drop_pos=dict(_train=True, token_drop=True, drop_policy="position", capacity_factor=1.0, min_capacity=2),
+        # the mixer's training branch + AudioMoERoutingFunction (core.py:64-91,111-137): `ignore_differentiable_router=False`.
+        # Its noise (gumbel_rsample per k-group call, torch.rand_like per round) is replaced by slices of two fixed per-token
+        # tensors, saved in the fixture: in_gumbel [S, n_dyn(round), n_dyn], in_rand [S, n_dyn(round)]
+        train_diffrouter=dict(_train=True, _noise=True, ignore_differentiable_router=False),
+        train_diffrouter_bf16gate=dict(_train=True, _noise=True, ignore_differentiable_router=False, fp32_gate=False),
     )
     for vi, (name, over) in enumerate(variants.items()):
         over = dict(over)
         train = over.pop("_train")
         pad = over.pop("_pad", False)
         auxw = over.pop("_auxw", False)
+        noise = over.pop("_noise", False)
         c = block_cfg(**over)
         torch.manual_seed(900 + vi)
         blk = core.UniMoEAudioSparseMoeBlock(c)
@@ -230,8 +282,17 @@ def gen_dcmoe_bwd(ref, out):
         if auxw:
             aw = torch.rand(B, T)
         aux_coef = 0.3
+        inj = None
+        if noise:
+            n_dyn_ = c.mlp_dynamic_expert_num + c.mlp_dynamic_null_expert_num
+            gn = torch.Generator().manual_seed(4000 + vi)
+            u = torch.rand((B * T, n_dyn_, n_dyn_), generator=gn).clamp_(1e-20, 1.0 - 1e-7)
+            inj = NoiseInjector(core, -torch.log(-torch.log(u)), torch.rand((B * T, n_dyn_), generator=gn))
+            inj.__enter__()
         with MixerRecorder(core) as rec:
             o = blk(x, am, aw)
+        if inj is not None:
+            inj.__exit__()
         loss = (o[0].float() * G.float()).sum() + aux_coef * o[5].float()
         loss.backward()
         if c.token_drop and c.drop_policy == "probs":
@@ -249,6 +310,9 @@ def gen_dcmoe_bwd(ref, out):
             d["in_attention_mask"] = am
         if aw is not None:
             d["in_aux_balance_weight"] = aw
+        if inj is not None:
+            d["in_gumbel"], d["in_rand"] = inj.gumbel, inj.rand
+            assert inj.rounds_served > 0
         for n, p in blk.named_parameters():
             d["w." + n] = p.detach()
             d["g." + n] = p.grad if p.grad is not None else torch.zeros_like(p)

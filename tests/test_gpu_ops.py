@@ -334,6 +334,8 @@ def test_dcmoe_block_backward_vs_reference_autograd(dev, path):
     w = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
     blk = _mk_block(cfgd, w, dev)
     blk.train(bool(int(g["train"])))
+    if "in_gumbel" in g:          # the mixer's training branch (core.py:111-137): the reference's own noise draws, injected
+        blk._router_noise = (g["in_gumbel"], g["in_rand"])
     for p_ in blk.parameters():
         p_.requires_grad_(True)
     am, aw = g.get("in_attention_mask"), g.get("in_aux_balance_weight")

@@ -36,7 +36,7 @@ class RouterArgs(C.Structure):
                 ("S", i32), ("D", i32), ("n_dyn", i32), ("n_real", i32), ("n_fix", i32), ("logits_bf16", i32),
                 ("top_p", f32), ("fixed_top_k", i32), ("jitter_eps", f64), ("rms_eps", f32),
                 ("logits_out", vp), ("top_k", vp), ("sel", vp), ("expert_mask", vp), ("routing_w", vp),
-                ("global_w", vp), ("moe_w", vp), ("norm_only", i32)]
+                ("global_w", vp), ("moe_w", vp), ("norm_only", i32), ("gumbel", vp), ("rand_u", vp), ("round_factor", vp)]
 
 
 class Group(C.Structure):
@@ -135,7 +135,7 @@ EXPORTS = [
     "umoe_attn_prefill_bwd_workspace_bytes", "umoe_attn_prefill_bwd",
     "umoe_ep_unique_id", "umoe_ep_comm_create", "umoe_ep_comm_destroy", "umoe_ep_all_to_all",
     "umoe_ep_ipc_export", "umoe_ep_ipc_open", "umoe_ep_ipc_close", "umoe_engine_ep_region", "umoe_engine_ep_connect",
-    "umoe_engine_ep_error", "umoe_token_drop", "umoe_router_bwd_drop",
+    "umoe_engine_ep_error", "umoe_token_drop", "umoe_router_bwd_drop", "umoe_router_bwd_ex",
 ]
 
 EP_PEER, EP_LOOPBACK, EP_RCCL = 0, 1, 2
@@ -170,6 +170,7 @@ def lib():
         L.umoe_permute_bwd.argtypes = [vp, vp, i32, vp, i32, i32, i32, vp, vp, vp]
         L.umoe_router_bwd.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp]
         L.umoe_router_bwd_drop.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, vp, vp]
+        L.umoe_router_bwd_ex.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f64, i32, vp, vp, vp]
         L.umoe_token_drop.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
         L.umoe_rmsnorm_residual_bwd.argtypes = [vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, C.c_size_t, vp]
         L.umoe_dispatch_build_aligned.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256) void router_bwd_kernel(const void* __restrict_
                                                          const int64_t* __restrict__ top_k, const int32_t* __restrict__ mask,
                                                          const float* __restrict__ d_moe_w, const float* __restrict__ d_gw_shared,
                                                          const float* __restrict__ d_logits_in, int S, int n_dyn, int n_real, int n_fix,
-                                                         float jitter_eps, float* __restrict__ d_logits, int drop) {
+                                                         float jitter_eps, float* __restrict__ d_logits, int drop,
+                                                         const float* __restrict__ round_factor) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= S) return;
     const int E = n_dyn + n_fix;
@@ -285,7 +286,10 @@ __global__ __launch_bounds__(256) void router_bwd_kernel(const void* __restrict_
 #pragma unroll
             for (int e = 0; e < UMOE_MAXE; ++e)
                 if (e == ej) {
-                    rw[e] = expf(z[e] - mx) / den;
+                    // differentiable router (training branch of the mixer, core.py:111-137): the forward multiplies the softmax
+                    // multiplier by mask_for_one (1 or 0.3333); AudioMoERoutingFunction.backward (core.py:64-91) ignores that factor
+                    // and is otherwise the softmax gradient used below
+                    rw[e] = expf(z[e] - mx) / den * (round_factor ? round_factor[(size_t)s * n_dyn + j] : 1.f);
                     taken[e] = true;
                 }
         }
@@ -420,7 +424,7 @@ extern "C" int umoe_router_bwd(const void* logits, int logits_bf16, const int32_
     if (S == 0) return 0;
     router_bwd_kernel<<<dim3((unsigned)ceil_div(S, 256)), 256, 0, (hipStream_t)stream>>>(
         logits, logits_bf16, sel, top_k, expert_mask, d_moe_w, d_gw_shared, d_logits_in, S, n_dyn, n_real, n_fix, (float)jitter_eps,
-        d_logits, 0);
+        d_logits, 0, nullptr);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -434,7 +438,22 @@ extern "C" int umoe_router_bwd_drop(const void* logits, int logits_bf16, const i
     if (S == 0) return 0;
     router_bwd_kernel<<<dim3((unsigned)ceil_div(S, 256)), 256, 0, (hipStream_t)stream>>>(
         logits, logits_bf16, sel, top_k, expert_mask, d_moe_w, d_gw_shared, d_logits_in, S, n_dyn, n_real, n_fix, (float)jitter_eps,
-        d_logits, 1);
+        d_logits, 1, nullptr);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int umoe_router_bwd_ex(const void* logits, int logits_bf16, const int32_t* sel, const int64_t* top_k, const int32_t* expert_mask,
+                                  const float* d_moe_w, const float* d_gw_shared, const float* d_logits_in, int S, int n_dyn, int n_real,
+                                  int n_fix, double jitter_eps, int token_drop, const float* round_factor, float* d_logits,
+                                  umoe_stream_t stream) {
+    UMOE_REQUIRE(logits && sel && top_k && expert_mask && d_moe_w && d_logits, "umoe_router_bwd_ex: null argument");
+    UMOE_REQUIRE(n_dyn >= 1 && n_dyn + n_fix <= UMOE_MAXE && n_real <= n_dyn && (n_fix == 0 || d_gw_shared),
+                 "umoe_router_bwd_ex: bad sizes n_dyn=%d n_real=%d n_fix=%d", n_dyn, n_real, n_fix);
+    if (S == 0) return 0;
+    router_bwd_kernel<<<dim3((unsigned)ceil_div(S, 256)), 256, 0, (hipStream_t)stream>>>(
+        logits, logits_bf16, sel, top_k, expert_mask, d_moe_w, d_gw_shared, d_logits_in, S, n_dyn, n_real, n_fix, (float)jitter_eps,
+        d_logits, token_drop ? 1 : 0, round_factor);
     UMOE_LAUNCH_CHECK();
     return 0;
 }

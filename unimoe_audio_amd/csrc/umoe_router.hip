@@ -117,6 +117,7 @@ static int router_check(const umoe_router_args* a) {
                  a->n_fix, UMOE_MAXE);
     UMOE_REQUIRE(a->logits_in || (a->x && a->gate_w && a->D > 0 && a->D % 8 == 0),
                  "umoe_router_fwd: need logits_in or (x, gate_w, D %% 8 == 0)");
+    UMOE_REQUIRE(!a->gumbel || a->rand_u, "umoe_router_fwd: the training branch of the mixer needs both noise tensors (gumbel, rand_u)");
     return 0;
 }
 

@@ -288,6 +288,38 @@ __device__ __forceinline__ int route_from_logits(const umoe_router_args& a, cons
         const float q = round_t(d / factor, T);
         const float gate = (q > two_eps) ? -INFINITY : masked;
         const float gsm = lane_softmax<ND, TB>(gate, n_dyn, lane);
+        if (a.gumbel) {
+            // training branch (core.py:111-137): selected = arg-max(masked_gates + Gumbel noise) -- the sum is fp32 (fp32 noise) --,
+            // weight = softmax multiplier of the SELECTED column * mask_for_one; lowest index on ties, like torch.max
+            const float noisy = (lane < n_dyn) ? gate + a.gumbel[((size_t)s * n_dyn + j) * n_dyn + lane] : -INFINITY;
+            float ns[UMOE_MAXE], ps[UMOE_MAXE];
+            gather16<ND>(noisy, n_dyn, -INFINITY, ns);
+            gather16<ND>(gsm, n_dyn, -INFINITY, ps);
+            float nb = ns[0], pb = ps[0];
+            int sel_j = 0, mi = 0;
+#pragma unroll
+            for (int e = 1; e < UMOE_MAXE; ++e)
+                if (ND == 0 || e < ND) {
+                    if (ns[e] > nb) { nb = ns[e]; sel_j = e; }
+                    if (ps[e] > pb) { pb = ps[e]; mi = e; }
+                }
+            float mo = 0.f;
+#pragma unroll
+            for (int e = 0; e < UMOE_MAXE; ++e)
+                if (e == sel_j) mo = ps[e];
+            const bool one = (sel_j == mi) || (a.rand_u[(size_t)s * n_dyn + j] > 0.75f);
+            const float factor = round_t(one ? (0.3333f + 0.6667f) : 0.3333f, T);     // torch.add(0.3333, mask, alpha=0.6667).type_as(gates)
+            if (lane == sel_j) {
+                w = round_t(mo * factor, T);
+                m += 1;
+                masked = -INFINITY;
+            }
+            if (lane == 0) {
+                if (a.sel) a.sel[(size_t)s * n_dyn + j] = sel_j;
+                if (a.round_factor) a.round_factor[(size_t)s * n_dyn + j] = factor;
+            }
+            continue;
+        }
         if (lane == ind) {
             w = gsm;
             m += 1;
@@ -295,6 +327,7 @@ __device__ __forceinline__ int route_from_logits(const umoe_router_args& a, cons
         }
         if (a.sel && lane == 0) a.sel[(size_t)s * n_dyn + j] = ind;
     }
+    if (a.gumbel && a.round_factor && lane >= k && lane < n_dyn) a.round_factor[(size_t)s * n_dyn + lane] = 0.f;
     if (a.sel && lane >= k && lane < n_dyn) a.sel[(size_t)s * n_dyn + lane] = -1;
     TL_MARK(5, 8);
 

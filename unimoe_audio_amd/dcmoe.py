@@ -151,6 +151,19 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         self._packed, self._packed_key = pk, key
         return pk
 
+    def _mixer_noise(self, S: int, device):
+        """Noise of the mixer's training branch (core.py:111-126, `training and not ignore_differentiable_router`): Gumbel(0,1)
+        [S, n_dyn, n_dyn] (one row per token and round; the reference draws gumbel_rsample per k-group call) and uniform [S, n_dyn].
+        `self._router_noise = (gumbel, uniform)` overrides the draw (tests inject the reference's own samples)."""
+        if not (self.training and not self.ignore_differentiable_router):
+            return None, None
+        inj = getattr(self, "_router_noise", None)
+        if inj is not None:
+            return inj[0].to(device=device, dtype=torch.float32), inj[1].to(device=device, dtype=torch.float32)
+        n = self.mlp_dynamic_expert_num
+        u = torch.rand((S, n, n), device=device).clamp_(1e-20, 1.0 - 1e-7)
+        return -torch.log(-torch.log(u)), torch.rand((S, n), device=device)
+
     # ---- forward ------------------------------------------------------------------------------------------
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 aux_balance_weight: Optional[torch.Tensor] = None):
@@ -165,8 +178,8 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         n_dyn, n_real, n_fix = self.mlp_dynamic_expert_num, self.mlp_dynamic_real_expert_num, self.mlp_fixed_expert_num
         if torch.is_grad_enabled() and (hidden_states.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training: forward + backward on the HIP kernels (shipped configuration)
-            if int(self.dynamic_real_moe.ep_size) > 1 or not self.ignore_differentiable_router:
-                raise NotImplementedError("HIP backward covers ignore_differentiable_router=True (the shipped setting) at ep_size=1")
+            if int(self.dynamic_real_moe.ep_size) > 1:
+                raise NotImplementedError("the HIP backward runs at ep_size=1")
             for p_ in self.parameters():
                 if p_.dtype != torch.bfloat16 or not p_.is_contiguous():
                     raise L.UmoeError("training needs contiguous bfloat16 parameters")
@@ -178,10 +191,11 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         if self.training and self.input_jitter_noise > 0:                      # core.py:243-244: the gate's copy only
             xg = (x.float() * torch.empty((S, D), dtype=torch.float32, device=x.device).uniform_(
                 1.0 - self.input_jitter_noise, 1.0 + self.input_jitter_noise)).to(torch.bfloat16)
+        gmb, ru = self._mixer_noise(S, x.device)
         r = ops.router_fwd(xg, self.gate.weight.data, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix,
                            top_p=float(self.mlp_dynamic_top_p), fixed_top_k=int(self.mlp_dynamic_top_k),
                            jitter_eps=float(self.router_jitter_noise), attn_mask=attention_mask,
-                           logits_bf16=not fp32_gate)
+                           logits_bf16=not fp32_gate, gumbel=gmb, rand_u=ru)
         logits, expert_mask = r["logits"], r["expert_mask"]
         top_k = r["top_k"] if self.mlp_dynamic_top_p != 0 else r["top_k"].to(torch.int32)
         aux = aux_loss(expert_mask, n_dyn, logits, aux_balance_weight)         # core.py:293
@@ -313,9 +327,10 @@ class _DCMoETrainFn(torch.autograd.Function):
             noise = torch.empty((S, D), dtype=torch.float32, device=x.device).uniform_(1.0 - blk.input_jitter_noise,
                                                                                        1.0 + blk.input_jitter_noise)
             xg = (x.float() * noise).to(torch.bfloat16)
+        gmb, ru = blk._mixer_noise(S, x.device)
         r = ops.router_fwd(xg, gate_w, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, top_p=float(blk.mlp_dynamic_top_p),
                            fixed_top_k=int(blk.mlp_dynamic_top_k), jitter_eps=float(blk.router_jitter_noise),
-                           attn_mask=attention_mask, logits_bf16=not fp32_gate)
+                           attn_mask=attention_mask, logits_bf16=not fp32_gate, gumbel=gmb, rand_u=ru)
         logits, mask, moe_w, global_w = r["logits"], r["expert_mask"], r["moe_weight"], r["global_weight"]
         tw = None
         if aux_balance_weight is not None:
@@ -348,6 +363,7 @@ class _DCMoETrainFn(torch.autograd.Function):
         out = ops.combine(ybuf, disp["slot_of"], moe_w, y_sh, global_w, None, n_dyn, n_fix)
         ctx.blk, ctx.dims = blk, (S, D, n_dyn, n_real, n_fix, I_d, I_s, Imax, cap, rows_total)
         ctx.disp, ctx.tw, ctx.noise, ctx.mask0 = disp, tw, noise, mask0
+        ctx.round_factor = r.get("round_factor")
         ctx.save_for_backward(x, logits, r["sel"], r["top_k"], mask, moe_w, global_w, hbuf, gu, ybuf, *params)
         top_k = r["top_k"] if blk.mlp_dynamic_top_p != 0 else r["top_k"].to(torch.int32)
         gw_out = global_w.to(x.dtype)
@@ -392,7 +408,7 @@ class _DCMoETrainFn(torch.autograd.Function):
         if d_aux is not None:
             d_lg_aux = ops.aux_loss_bwd(logits, ctx.mask0, n_dyn, ctx.tw, d_aux)
         d_lg = ops.router_bwd(logits, sel, top_k, mask, d_mw, d_gs, d_lg_aux, n_dyn, n_real, n_fix, float(blk.router_jitter_noise),
-                              token_drop=bool(blk.token_drop))
+                              token_drop=bool(blk.token_drop), round_factor=ctx.round_factor)
         E = n_dyn + n_fix
         dl16 = torch.zeros((S, 16), dtype=bf, device=dev)
         dl16[:, :E] = d_lg.to(bf)

@@ -69,7 +69,10 @@ def pack_gate_up(wg: torch.Tensor, wu: torch.Tensor) -> torch.Tensor:
 def router_fwd(x: Optional[torch.Tensor], gate_w: Optional[torch.Tensor], *, n_dyn: int, n_real: int, n_fix: int,
                top_p: float, fixed_top_k: int = 0, jitter_eps: float = 0.01, logits_in: Optional[torch.Tensor] = None,
                attn_mask: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None, rms_eps: float = 1e-6,
-               want_h: bool = False, logits_bf16: Optional[bool] = None) -> dict:
+               want_h: bool = False, logits_bf16: Optional[bool] = None, gumbel: Optional[torch.Tensor] = None,
+               rand_u: Optional[torch.Tensor] = None) -> dict:
+    """gumbel [S, n_dyn, n_dyn] / rand_u [S, n_dyn] fp32: the training branch of the mixer (core.py:111-137) with its noise as an
+    input; the result then carries `round_factor` [S, n_dyn] (mask_for_one per round) for router_bwd."""
     E = n_dyn + n_fix
     if logits_in is not None:
         S = logits_in.shape[0]
@@ -99,6 +102,11 @@ def router_fwd(x: Optional[torch.Tensor], gate_w: Optional[torch.Tensor], *, n_d
         jitter_eps=jitter_eps, rms_eps=rms_eps, logits_out=_p(o["logits"]), top_k=_p(o["top_k"]), sel=_p(o["sel"]),
         expert_mask=_p(o["expert_mask"]), routing_w=_p(o["routing_weights"]), global_w=_p(o["global_weight"]),
         moe_w=_p(o["moe_weight"]))
+    if gumbel is not None:
+        assert rand_u is not None and tuple(gumbel.shape) == (S, n_dyn, n_dyn) and tuple(rand_u.shape) == (S, n_dyn)
+        gk, uk = gumbel.float().contiguous(), rand_u.float().contiguous()
+        o["round_factor"] = torch.empty((S, n_dyn), dtype=torch.float32, device=dev)
+        a.gumbel, a.rand_u, a.round_factor = gk.data_ptr(), uk.data_ptr(), o["round_factor"].data_ptr()
     L.check(L.lib().umoe_router_fwd(C.byref(a), _stream()), "umoe_router_fwd")
     if h is not None:
         o["h"] = h
@@ -475,14 +483,14 @@ def permute_bwd(dxe, slot_of, dx_shared, n_fix: int, extra=None):
 
 
 def router_bwd(logits, sel, top_k, expert_mask, d_moe_w, d_gw_shared, d_logits_in, n_dyn: int, n_real: int, n_fix: int,
-               jitter_eps: float, token_drop: bool = False) -> torch.Tensor:
-    """token_drop: `expert_mask` is the mask AFTER the drop and the extra renormalisation of core.py:328-329 is in the graph."""
+               jitter_eps: float, token_drop: bool = False, round_factor: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """token_drop: `expert_mask` is the mask AFTER the drop and the extra renormalisation of core.py:328-329 is in the graph.
+    round_factor: mask_for_one per (token, round) of the differentiable-router forward (AudioMoERoutingFunction.backward)."""
     S, E = logits.shape
     out = torch.empty((S, E), dtype=torch.float32, device=logits.device)
-    fn = L.lib().umoe_router_bwd_drop if token_drop else L.lib().umoe_router_bwd
-    L.check(fn(_p(logits), int(logits.dtype == torch.bfloat16), _p(sel), _p(top_k), _p(expert_mask), _p(d_moe_w),
-                                    _p(d_gw_shared), _p(d_logits_in), S, n_dyn, n_real, n_fix, float(jitter_eps), _p(out), _stream()),
-            "umoe_router_bwd")
+    L.check(L.lib().umoe_router_bwd_ex(_p(logits), int(logits.dtype == torch.bfloat16), _p(sel), _p(top_k), _p(expert_mask), _p(d_moe_w),
+                                       _p(d_gw_shared), _p(d_logits_in), S, n_dyn, n_real, n_fix, float(jitter_eps), int(bool(token_drop)),
+                                       _p(round_factor), _p(out), _stream()), "umoe_router_bwd_ex")
     return out
 
 
