@@ -401,7 +401,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
         const int head = kvh * G + g;
         float* po = a.part_o + (((size_t)qi * a.H + head) * a.splits + split) * HD + cg * 8;
         float* pm = a.part_ml + (((size_t)qi * a.H + head) * a.splits + split) * 2;
-        if (a.sync) {   // agent-coherent (write-through, sc1) stores: read by a workgroup on another XCD in this same launch
+        if (a.splits == 1 && !a.sync) {
+            // one key split: this workgroup holds the whole softmax -- the merge of umoe_attn_combine over ONE partial is o / l
+            // (its scale exp(m - m) is exactly 1), so the output is written here and the combine launch is skipped
+            uint16_t y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[j] = f2bf(L > 0.f ? acc[j] / L : 0.f);
+            st16(a.out + ((size_t)qi * a.H + head) * HD + cg * 8,
+                 make_uint4((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16),
+                            (uint32_t)y[4] | ((uint32_t)y[5] << 16), (uint32_t)y[6] | ((uint32_t)y[7] << 16)));
+        } else if (a.sync) {   // agent-coherent (write-through, sc1) stores: read by a workgroup on another XCD in this same launch
 #pragma unroll
             for (int j = 0; j < 8; ++j) __hip_atomic_store(po + j, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cg == 0) {
@@ -523,7 +532,7 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     if (nqi <= 65535u) {
         launch_attn(a, dim3((unsigned)a->splits, (unsigned)a->KVH, nqi), s);
         UMOE_LAUNCH_CHECK();
-        if (!a->sync) {
+        if (!a->sync && a->splits > 1) {
             launch_attn_combine(a, dim3((unsigned)a->H, nqi), s);
             UMOE_LAUNCH_CHECK();
         }
@@ -544,7 +553,7 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
             UMOE_REQUIRE(a->nq <= 65535, "umoe_attn_decode: nq too large");
             launch_attn(&b, dim3((unsigned)a->splits, (unsigned)a->KVH, (unsigned)a->nq), s);
             UMOE_LAUNCH_CHECK();
-            launch_attn_combine(&b, dim3((unsigned)a->H, (unsigned)a->nq), s);
+            if (a->splits > 1) launch_attn_combine(&b, dim3((unsigned)a->H, (unsigned)a->nq), s);
             UMOE_LAUNCH_CHECK();
         }
     }
