@@ -524,6 +524,22 @@ int umoe_rvq_nearest(const float* z, const float* codebooks, const float* in_w, 
                      const float* out_b, int NQ, int CB, int cd, int Dl, int T, int32_t* codes, float* resid_ws,
                      umoe_stream_t stream);
 
+/* DAC conv stacks (third-party descript-audio-codec 1.0.0 DAC.encode / DAC.decode behind utils/UniMoE_Audio_utils.py:112-113,123-124;
+ * restated from the published architecture, PARITY UNPINNED, every dimension a load-time parameter).  fp32, [B][C][L] layout.
+ * The Snake activation of the PRECEDING layer (x + sin(alpha x)^2 / (alpha + 1e-9), per input channel) is fused into the input
+ * load when snake_alpha != NULL; bias, the residual add of a ResidualUnit (resid, same shape as y) and the decoder's final tanh
+ * (act = 1) into the store.  Weights are the weight-normalised tensors already folded (g * v / |v|, done once at load time).
+ *   umoe_dac_conv1d:            w [Cout][Cin][K], Lout = (L + 2 pad - dilation (K - 1) - 1) / stride + 1
+ *   umoe_dac_conv_transpose1d:  w [Cin][Cout][K], Lout = (L - 1) stride - 2 pad + K + out_pad */
+int umoe_dac_conv1d(const float* x, const float* w, const float* bias, const float* snake_alpha, const float* resid, int B, int Cin,
+                    int L, int Cout, int K, int stride, int dilation, int pad, int act, float* y, int* Lout_out, umoe_stream_t stream);
+int umoe_dac_conv_transpose1d(const float* x, const float* w, const float* bias, const float* snake_alpha, int B, int Cin, int L,
+                              int Cout, int K, int stride, int pad, int out_pad, float* y, int* Lout_out, umoe_stream_t stream);
+/* windowed-sinc resampling to the codec's rate (torchaudio.transforms.Resample as used at utils.py:101-110, restated): with o / n =
+ * orig / new frequency over their gcd, kern [n][2 width + o] the filter bank (built by the host from the published formula),
+ * y[b][frame * n + phase] = sum_t kern[phase][t] * x[b][frame * o - width + t] (zero outside [0, L)). */
+int umoe_dac_resample(const float* x, const float* kern, int B, int L, int o, int n, int width, int Lout, float* y, umoe_stream_t stream);
+
 /* ------------------------------------------------------------------ decode engine
  * Owns workspace + KV cache and enqueues a whole decode step (36 layers + head + sampler + delay
  * bookkeeping) from one host call, optionally replayed as a hipGraph.  Restates

@@ -1,0 +1,82 @@
+"""End to end through the reference's task API (UniMoE_Audio.py:105-200 / utils/UniMoE_Audio_mod.py:294-482) on the HIP path:
+prompt wav -> Dac.encode -> delayed prompt codes -> prompt pairs -> generate() -> delay reverted -> Dac.decode -> wav files.
+The HF tokenizer files and the DAC weights do not exist offline: a stand-in tokenizer (fixed vocabulary, left padding, the
+placeholder id for <|AUDIO_PLACEHOLDER|>) and a randomly initialised codec take their place -- the plumbing is what is tested."""
+import os
+import re
+import types
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class StandInTokenizer:
+    """splits on the reference's special tokens, hashes everything else to ids < 290; left padding like mod.py:104"""
+
+    def __init__(self, placeholder_id: int):
+        self.placeholder_id = placeholder_id
+
+    def __call__(self, texts, add_special_tokens=False, return_tensors="pt", padding=True):
+        rows = []
+        for t in texts:
+            ids = []
+            for piece in re.split(r"(<\|[A-Za-z_]+\|>)", t):
+                if not piece:
+                    continue
+                if piece == "<|AUDIO_PLACEHOLDER|>":
+                    ids.append(self.placeholder_id)
+                elif piece.startswith("<|"):
+                    ids.append(200 + (sum(map(ord, piece)) % 80))
+                else:
+                    ids += [1 + (ord(ch) % 190) for ch in piece[:40]]
+            rows.append(ids)
+        T = max(len(r) for r in rows)
+        input_ids = torch.tensor([[0] * (T - len(r)) + r for r in rows])
+        mask = torch.tensor([[0] * (T - len(r)) + [1] * len(r) for r in rows])
+        return types.SimpleNamespace(input_ids=input_ids, attention_mask=mask)
+
+
+def test_text_to_speech_and_music_write_wavs(tmp_path):
+    assert torch.cuda.is_available()
+    from unimoe_audio_amd import dac as D
+    from unimoe_audio_amd.api import UniMoEAudio
+    from unimoe_audio_amd.config import UniMoEAudioConfig
+    from unimoe_audio_amd.model import UniAudioRVQQwen2_5VLMoEForConditionalGeneration as Model
+    dev = torch.device("cuda:0")
+    cfg = UniMoEAudioConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=320,
+                            dynamic_intermediate_size=128, shared_intermediate_size=64, codec_placeholder_value=300)
+    torch.manual_seed(0)
+    m = Model(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "norm" in n:
+                p.fill_(1.0)
+            elif n.endswith("bias"):
+                p.zero_()
+            else:
+                p.normal_(0, 0.05)
+    m = m.to(dev, torch.bfloat16).eval()
+    app = UniMoEAudio(None, 0, model=m)
+    app._tokenizer = StandInTokenizer(cfg.codec_placeholder_value)
+    app.dac = D.Dac(model=D.DacModel(encoder_dim=16, decoder_dim=192).init_random(2).to(dev).float())
+    # a 0.4 s mono prompt at 16 kHz
+    t = np.arange(6400) / 16000
+    src = str(tmp_path / "prompt.wav")
+    with wave.open(src, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000)
+        wf.writeframes((0.3 * np.sin(2 * np.pi * 220 * t) * 32767).astype("<i2").tobytes())
+    out = app.text_to_speech(["hello world", "second sentence"], "the prompt text", src, str(tmp_path), max_audio_seconds=1,
+                             min_audio_seconds=0, temperature=1.0, top_p=1.0, cfg_filter_top_k=45)
+    assert len(out) == 2
+    for p in out:
+        with wave.open(p, "rb") as wf:
+            assert wf.getframerate() == 16000 and wf.getsampwidth() == 2 and wf.getnchannels() == 1
+            assert wf.getnframes() >= 15999                      # min_duration = 1 s (UniMoE_Audio.py:148; int(pad_seconds * 16000) truncates like the reference)
+    out2 = app.text_to_music("calm piano", str(tmp_path), max_audio_seconds=1, min_audio_seconds=0)
+    assert len(out2) == 1 and os.path.isfile(out2[0])
+    with pytest.raises(ValueError):
+        app.text_to_speech(["x"], "p", None, str(tmp_path))      # "Please provide a reference audio file."

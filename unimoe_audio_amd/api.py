@@ -6,9 +6,9 @@ Keeps both spellings the reference ships: the HF-directory flavour (`UniMoE_Audi
 positive prompt pairing and `max_tokens = 50 * seconds` follow the reference (mod.py:56-59,343-348,449-466;
 UniMoE_Audio.py:137-138).
 
-Tokenizer (HF files under `model_path`) and the DAC codec (`descript-audio-codec`, weights_16khz.pth) are third-party
-assets that are not available offline; they are loaded lazily and a clear error is raised when they are missing.  The
-token-generation path itself (`generate_codes`) needs neither and is what tests/bench exercise.
+The tokenizer (HF files under `model_path`) and the DAC weights (weights_16khz.pth) are assets that are not available offline; they
+are loaded lazily and a clear error is raised when they are missing.  The codec itself runs on the HIP path (unimoe_audio_amd/dac.py).
+tests/test_gpu_api.py drives text_to_speech / text_to_music end to end with a stand-in tokenizer and a randomly initialised codec.
 """
 from __future__ import annotations
 
@@ -63,14 +63,22 @@ class UniMoEAudio:
 
     @property
     def dac(self):
+        """The DAC codec on the HIP path (unimoe_audio_amd/dac.py; reference utils/UniMoE_Audio_utils.py:56-134).  Weights are looked
+        for like the reference does (DAC_WEIGHTS, <model_path>/dac_model/weights_16khz.pth, ...); FileNotFoundError when absent."""
         if self._dac is None:
-            try:
-                import dac  # noqa: F401  (descript-audio-codec==1.0.0, reference configs/enviroment.yml:56)
-            except Exception as e:
-                raise ImportError("descript-audio-codec is not installed: waveform <-> code conversion (Dac.encode/decode, "
-                                  "reference utils/UniMoE_Audio_utils.py:56-134) is unavailable; generate_codes() still works") from e
-            raise NotImplementedError("DAC conv encoder/decoder are outside the accelerated path this round (SURVEY.md 8f-2)")
+            from .dac import Dac
+            cand = None
+            if self.model_path:
+                for p in (os.path.join(self.model_path, "dac_model", "weights_16khz.pth"), os.path.join(self.model_path, "weights_16khz.pth")):
+                    if os.path.isfile(p):
+                        cand = p
+                        break
+            self._dac = Dac(cand, device=self.device)
         return self._dac
+
+    @dac.setter
+    def dac(self, codec):
+        self._dac = codec
 
     # ---- the accelerated part: tokens in, codes out -----------------------------------------------------------------
     @torch.no_grad()
