@@ -98,3 +98,23 @@ def test_ctypes_mirrors_have_the_size_and_offsets_of_the_c_structs(tmp_path):
         assert int(got[cname]) == C.sizeof(cls), (cname, got[cname], C.sizeof(cls))
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_restaging_barriers_behind_transposing_reads_are_pinned():
+    """ds_read_b64_tr_b16 (__builtin_amdgcn_ds_read_tr16_b64): hipcc (ROCm 7.2) emitted such reads BEHIND the __syncthreads() that
+    ends an iteration, where the next tile's stores race with them (umoe_attn_bwd.hip header).  The fix is structural: in front of
+    every barrier behind which a tile read by transposing reads is restaged, the accumulators those reads feed pass through a
+    volatile asm (TR_PIN8 / the acc_o pin), which cannot move across s_barrier.  This test keeps the structure: in the two sources
+    that use the builtin, every `lstore(buf ^ 1)` (the restage) is followed by a pin before its `__syncthreads()`."""
+    import re
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unimoe_audio_amd", "csrc")
+    found = 0
+    for f in ("umoe_attn.hip", "umoe_attn_bwd.hip"):
+        src = open(os.path.join(csrc, f)).read()
+        assert "__builtin_amdgcn_ds_read_tr16_b64" in src
+        for m in re.finditer(r"lstore\(buf \^ 1\);", src):
+            tail = src[m.end(): m.end() + 700]
+            sync = tail.index("__syncthreads()")
+            assert ("TR_PIN8(" in tail[:sync]) or ('"+v"(acc_o[0])' in tail[:sync]), (f, src[: m.start()].count("\n") + 1)
+            found += 1
+    assert found >= 3

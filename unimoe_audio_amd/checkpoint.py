@@ -125,6 +125,64 @@ def load_checkpoint(model: torch.nn.Module, path: str, ep_rank: int = 0, ep_size
     return missing, [k for k in unexpected if not k.startswith(COLD_PREFIXES)]
 
 
+def init_moe_from_dense(dense_mlp: Dict[str, "torch.Tensor"], target_shapes: Dict[str, tuple], *, moe_copy: str = "all",
+                        n_dynamic_experts: int = 8, ep_rank: int = 0, ep_size: int = 1, initializer_range: float = 0.02,
+                        generator: Optional["torch.Generator"] = None) -> Dict[str, "torch.Tensor"]:
+    """Dense -> MoE FFN initialisation of the reference's training entry (UniMoEV2-Preview/training/train_unimoev2_qwen2vl.py:
+    155-240): every expert tensor `...layers.L.mlp.(fixed_real_moe|dynamic_real_moe.deepspeed_moe.experts.deepspeed_experts).E.<rest>`
+    is cut out of the dense `...layers.L.mlp.<rest>` -- rows [offset, offset + I) of gate / up (output-feature slices), columns of
+    down -- with ONE running offset per source tensor that advances over the dynamic experts in name order and wraps (asserting it
+    lands exactly on the end), while shared experts always take the slice at offset 0.  `moe_copy`: "all" = every expert is cut /
+    copied; "single" = expert 0 only, the others N(0, initializer_range^2) weights / zero biases; "none" = nothing.  Expert-parallel
+    quirk kept: the ROW path starts rank r at (r * experts_per_rank * I) % rows, the COLUMN path always at 0 (:186-189 vs :209-213).
+    dense_mlp: {"<prefix>.layers.L.mlp.gate_proj.weight": tensor, ...}; target_shapes: name -> shape of every expert tensor of the
+    MoE model.  Returns name -> tensor for the expert tensors it initialises."""
+    import re
+    out: Dict[str, torch.Tensor] = {}
+    if moe_copy == "none":
+        return out
+    pat = re.compile(r"(.*layers\.(\d+)\.mlp)\.(fixed_real_moe|dynamic_real_moe\.deepspeed_moe\.experts\.deepspeed_experts)\.(\d+)(\..*)")
+    offset: Dict[str, int] = {}
+    per_rank = n_dynamic_experts // ep_size
+    for name, shape in target_shapes.items():
+        m = pat.match(name)
+        if not m:
+            continue
+        src_name = m.group(1) + m.group(5)
+        kind, expert = m.group(3), int(m.group(4))
+        src = dense_mlp[src_name]
+        shared = kind == "fixed_real_moe"
+        if moe_copy == "all" or expert == 0:
+            if shape[0] != src.shape[0]:
+                if not shared and src_name not in offset:
+                    offset[src_name] = (ep_rank * per_rank * shape[0]) % src.shape[0]
+                off = 0 if shared else offset[src_name]
+                out[name] = src[off: off + shape[0]].clone()
+                if not shared:
+                    offset[src_name] += shape[0]
+                    if offset[src_name] >= src.shape[0]:
+                        assert offset[src_name] == src.shape[0], (src.shape[0], shape[0], offset[src_name])
+                        offset[src_name] %= src.shape[0]
+            elif len(shape) > 1 and shape[1] != src.shape[1]:
+                if not shared and src_name not in offset:
+                    offset[src_name] = 0
+                off = 0 if shared else offset[src_name]
+                out[name] = src[:, off: off + shape[1]].clone()
+                if not shared:
+                    offset[src_name] += shape[1]
+                    if offset[src_name] >= src.shape[1]:
+                        assert offset[src_name] == src.shape[1], (src.shape[1], shape[1], offset[src_name])
+                        offset[src_name] %= src.shape[1]
+            else:
+                out[name] = src.clone()
+        elif moe_copy == "single":
+            if name.endswith("weight"):
+                out[name] = torch.empty(tuple(shape), dtype=src.dtype).normal_(mean=0.0, std=initializer_range, generator=generator)
+            else:
+                out[name] = torch.zeros(tuple(shape), dtype=src.dtype)
+    return out
+
+
 def invalidate_packed(model: torch.nn.Module) -> None:
     """Drop every MFMA-packed weight copy derived from the parameters (model.packed(), each DCMoE block's prepare()) and the
     decode engine built on them: the next forward / generate re-packs from the live tensors.  Called after every load; call it

@@ -715,7 +715,10 @@ __global__ __launch_bounds__(64 * GP) void attn_prefill_kernel(const umoe_attn_a
             }
         }
         if (more) lstore(buf ^ 1);
-        asm volatile("" ::: "memory");   // keeps the transposing-read builtins above the barrier (see umoe_attn_bwd.hip)
+        // keeps the transposing-read builtins above the barrier (cause and argument: umoe_attn_bwd.hip, TR_PIN8): the accumulators
+        // they feed pass through a volatile asm, which cannot move across s_barrier
+        asm volatile("" ::: "memory");
+        asm volatile("" : "+v"(acc_o[0]), "+v"(acc_o[1]), "+v"(acc_o[2]), "+v"(acc_o[3]), "+v"(acc_o[4]), "+v"(acc_o[5]), "+v"(acc_o[6]), "+v"(acc_o[7]));
         __syncthreads();
     }
     // ---- output: lane (h, q): d = db*16 + 4h + r of query t0 + q ----

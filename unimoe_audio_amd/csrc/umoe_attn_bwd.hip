@@ -17,8 +17,13 @@ typedef short v8s_t __attribute__((ext_vector_type(8)));
 
 // hipcc (ROCm 7.2) moved __builtin_amdgcn_ds_read_tr16_b64 calls BELOW a following __syncthreads() (seen in the ISA of the
 // dK/dV kernel: the transposing reads of the second half-step sat after the barrier, racing with the next tile's stores --
-// wrong dV in the last d-block only).  A compiler-level memory fence in front of the barrier pins them.
+// wrong dV in the last d-block only, timing dependent; the cause is the compiler's placement, not a missing lgkmcnt wait: the
+// builtin is not ordered against the barrier the way ordinary LDS loads are).  Pinned at the source, by construction: in front
+// of every barrier behind which a tile is restaged, the ACCUMULATORS fed by transposing reads pass through an `asm volatile`
+// (TR_PIN8).  Volatile asm and s_barrier keep their program order, the MFMAs that write the accumulators must precede the asm,
+// and their operand reads must precede the MFMAs -- whatever the compiler thinks of the builtin.
 #define TR_FENCE() asm volatile("" ::: "memory")
+#define TR_PIN8(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]))
 
 __device__ __forceinline__ int kvo(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
 
@@ -152,6 +157,7 @@ __global__ __launch_bounds__(64 * GP) void attn_bwd_dq_kernel(const umoe_attn_bw
         }
         if (more) lstore(buf ^ 1);
         TR_FENCE();
+        TR_PIN8(acc);
         __syncthreads();
     }
     if (live_wave && q_ok) {
@@ -278,6 +284,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const umoe_attn_b
             }
         }
         if (step + 1 < n_steps) lstore(buf ^ 1);
+        TR_FENCE();
+        TR_PIN8(dvT);
+        TR_PIN8(dkT);
         __syncthreads();
     }
     if (P > 1) {

@@ -222,3 +222,40 @@ class _HeadFn(torch.autograd.Function):
 
 def ops_f32_head(x, w):
     return _HeadFn.apply(x, w)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Training-side glue around the step: optimizer parameter groups.
+def moe_param_groups(model, weight_decay: float = 0.0, no_decay_suffixes=("bias", "layernorm.weight", "norm.weight")):
+    """The parameter groups the reference trainer hands its optimizer (UniMoEV2-Preview/training/moe_trainer.py:291-332):
+    `decay_parameters` / `no_decay_parameters` (transformers' rule: no decay on biases and norm weights), then DeepSpeed's
+    `split_params_into_different_moe_groups_for_optimizer` (deepspeed 0.15.1, restated): every expert parameter -- marked
+    `allreduce = False` with its `group_name` by AudioExperts (core.py:401-404) -- moves into a group of its own per (original
+    group, expert-parallel group name), flagged `moe: True`, so the optimizer / ZeRO reduce it over the expert-data-parallel
+    group only.  Returns the list of dicts ready for torch.optim.*."""
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    is_nd = lambda n: any(n.endswith(s) for s in no_decay_suffixes)      # noqa: E731
+    groups = [
+        {"params": [p for n, p in named if not is_nd(n)], "weight_decay": weight_decay, "name": "decay_parameters",
+         "params_source": [n for n, p in named if not is_nd(n)]},
+        {"params": [p for n, p in named if is_nd(n)], "weight_decay": 0.0, "name": "no_decay_parameters",
+         "params_source": [n for n, p in named if is_nd(n)]},
+    ]
+    is_moe = lambda p: hasattr(p, "allreduce") and not p.allreduce       # noqa: E731  (deepspeed.moe.utils.is_moe_param)
+    names = sorted({p.group_name for g in groups for p in g["params"] if is_moe(p)})
+    out = []
+    moe_groups = []
+    for g in groups:
+        per = {k: {**{kk: vv for kk, vv in g.items() if kk not in ("params", "params_source", "name")}, "name": k, "moe": True, "params": [],
+                   "params_source": []} for k in names}
+        keep_p, keep_n = [], []
+        for n, p in zip(g["params_source"], g["params"]):
+            if is_moe(p):
+                per[p.group_name]["params"].append(p)
+                per[p.group_name]["params_source"].append(n)
+            else:
+                keep_p.append(p)
+                keep_n.append(n)
+        out.append({**g, "params": keep_p, "params_source": keep_n})
+        moe_groups += [v for v in per.values() if v["params"]]
+    return out + moe_groups
