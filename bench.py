@@ -308,6 +308,10 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     shared_gpu = world > ndev                          # rehearsal of N ranks on fewer GPUs: ranks share cards, no RCCL
+    if shared_gpu:
+        # workgroups of one launch hand rows to each other (umoe_gemm_args.rider_pub): they must all be resident, which two
+        # processes on one card cannot promise each other
+        os.environ["UMOE_RIDER_PUB"] = "0"
     torch.cuda.set_device(local % ndev)
     device = torch.device("cuda", local % ndev)
     if not torch.cuda.is_available():

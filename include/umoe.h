@@ -181,6 +181,9 @@ typedef struct {
     const umoe_router_args* fused_router; /* optional HOST pointer (SwiGLU, nt = 14, <= 16 rows, n_dyn 9 / n_fix 2, D 2048 / 4096, S <= 16):
                                * the router of these tokens runs INSIDE this launch as S extra workgroups (its outputs are complete when
                                * the launch is); the GEMM itself must not depend on them (dense-expert decode: h_out NULL, see norm_only) */
+    const void* rider_pub;    /* decode engine only (NULL otherwise), with fused_router: HOST pointer to the hand-off descriptor -- the riders
+                               * also produce the normalised rows `a` (fused_router->h_out == a) and HAND them to the GEMM workgroups of
+                               * this same launch, which stream their first weight chunk while they wait: no RMSNorm launch in front */
 } umoe_gemm_args;
 #define UMOE_GROUPS_INLINE 12
 

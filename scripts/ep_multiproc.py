@@ -26,6 +26,8 @@ def main():
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % ndev)
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo")
+    if world > ndev:
+        os.environ["UMOE_RIDER_PUB"] = "0"       # processes sharing a card: see bench.py
     cfg = small_cfg(hidden_size=2048, num_attention_heads=16, num_key_value_heads=2, dynamic_intermediate_size=2752,
                     shared_intermediate_size=1376, num_hidden_layers=layers)
     m, _ = build(cfg, 1, 0.02)                       # same seed in every process: slices of one model

@@ -47,7 +47,7 @@ class Group(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("groups", vp), ("num_groups", i32), ("max_rows", i32), ("max_n_blocks", i32), ("max_k", i32),
                 ("a", vp), ("lda", i32), ("norm_w", vp), ("rms_eps", f32), ("resid", vp), ("out", vp), ("ldo", i32),
-                ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32), ("waves", i32), ("ksplit", i32), ("part_stride", C.c_long), ("groups_host", vp), ("flat_wgs", i32), ("cache_policy", i32), ("fused_router", vp)]
+                ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32), ("waves", i32), ("ksplit", i32), ("part_stride", C.c_long), ("groups_host", vp), ("flat_wgs", i32), ("cache_policy", i32), ("fused_router", vp), ("rider_pub", vp)]
 
 
 class TGroup(C.Structure):

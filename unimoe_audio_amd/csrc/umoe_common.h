@@ -197,6 +197,14 @@ int umoe_ep_pull_pack(const umoe_ep_xfer& x, const uint16_t* own_rows, hipStream
 int umoe_router_norm_push(const umoe_router_args* a, const umoe_ep_xfer& x, hipStream_t s);
 int umoe_ep_rccl_allgather(void* comm, const void* send, void* recv, size_t bytes, hipStream_t s);
 
+// ---- riders publish the normalised rows inside the gate/up launch (umoe_gemm_args.rider_pub -> this, host side) ------------
+struct umoe_rider_pub {
+    uint32_t* flags;           // device [S] words, one per token row, monotonic epochs
+    const uint32_t* step;      // device word: decode steps taken so far
+    int layer, layers;         // epoch = *step * layers + layer + 1
+    uint32_t* err;             // device word, sticky: 2 = a workgroup gave up waiting for the riders
+};
+
 // ---- weight-streaming GEMM over several 16-row tiles per weight pass (umoe_gemm_mt.hip; expert parallel decode) --------
 #define UMOE_MT_MAXG 4
 #define UMOE_MT_MAXT UMOE_MAX_EP

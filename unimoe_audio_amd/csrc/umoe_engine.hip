@@ -52,6 +52,8 @@ struct umoe_engine {
     int32_t* d_delay = nullptr;
     umoe_group_t* d_groups = nullptr;  // per layer: [qkv 1][o 1][gateup G][down G]; then [head 1]
     std::vector<umoe_group_t> h_groups;  // host copy: descriptors travel by value in the GEMM kernel arguments
+    std::vector<umoe_group_t> h_gu_pub;  // per layer: the gate/up groups with the SHARED experts first -- their tile-less workgroups
+                                         // (the riders) then come early in dispatch order, in front of almost every workgroup that waits for them
     int groups_for_tok = -1;
     // carved buffers
     uint16_t *x = nullptr, *hin = nullptr, *x1 = nullptr, *h2 = nullptr, *qkv = nullptr, *q_r = nullptr, *attn_out = nullptr,
@@ -77,6 +79,8 @@ struct umoe_engine {
     // lists, no dispatch kernel, no device-produced row counts in the GEMM prologues) and the combine selects by mask
     bool dense_experts = true;
     bool fuse_router = true;     // UMOE_FUSE_ROUTER: dense decode runs the router inside the gate/up launch (see run_layer)
+    bool rider_pub = true;       // UMOE_RIDER_PUB: the riders also produce the normalised rows and hand them to the GEMM workgroups of the
+                                 // same launch (umoe_gemm_args.rider_pub): no RMSNorm launch in front of gate/up
     bool attn_single = false;    // UMOE_ATTN_SINGLE: decode attention merges its key splits in the same launch (umoe_attn_args.sync);
                                  // measured 3.644 vs 3.585 ms/step: ticket + coherent re-read cost more than the combine launch
     int flat_wgs = 0;            // UMOE_FLAT_WGS: workgroups of the flat gate/up launch; measured 42.4 us (256 slices of 6-7
@@ -242,6 +246,13 @@ static int build_groups(umoe_engine* e, int n_tok, hipStream_t s) {
             dn[x].out_row_base = slots_routed + i * n_tok; dn[x].n_blocks = c.hidden / 16; dn[x].k = c.inter_shared;
         }
     }
+    e->h_gu_pub.assign((size_t)c.layers * G, umoe_group_t{});
+    for (int l = 0; l < c.layers; ++l) {
+        const umoe_group_t* gu = &h[(size_t)l * GPL + 2];
+        umoe_group_t* o = &e->h_gu_pub[(size_t)l * G];
+        for (int i = 0; i < c.n_fix; ++i) o[i] = gu[c.n_real + i];
+        for (int x = 0; x < c.n_real; ++x) o[c.n_fix + x] = gu[x];
+    }
     umoe_group_t* hg = &h[(size_t)c.layers * GPL];
     memset(hg, 0, sizeof(umoe_group_t));
     hg->w = e->codec_head_w; hg->static_count = c.rows;
@@ -285,7 +296,8 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
         umoe_engine_destroy(e);
         return -2;
     }
-    if (hipMalloc(&e->ep_words, 64) != hipSuccess || hipMemset(e->ep_words, 0, 64) != hipSuccess) {
+    // [0] decode steps taken, [1] sticky hand-off error, [16..32) row flags of the rider hand-off (umoe_gemm_args.rider_pub)
+    if (hipMalloc(&e->ep_words, 256) != hipSuccess || hipMemset(e->ep_words, 0, 256) != hipSuccess) {
         umoe_set_error("umoe_engine_create: hipMalloc failed (state words)");
         umoe_engine_destroy(e);
         return -2;
@@ -319,6 +331,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (const char* v = getenv("UMOE_FLAT_WGS")) e->flat_wgs = atoi(v);
     if (const char* v = getenv("UMOE_ATTN_SINGLE")) e->attn_single = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_ROUTER")) e->fuse_router = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_RIDER_PUB")) e->rider_pub = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -753,7 +766,10 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // chain as its own small launch: the 4.4 us serial routing chain per token leaves the critical path.
     const bool fuse_router = dense && e->fuse_router && !tiled && !(e->overlap_shared && c.n_fix > 0) && c.n_dyn == 9 && c.n_fix == 2 &&
                              (D == 2048 || D == 4096) && n_tok <= 16 && !(e->flat_wgs > 0);
-    if (fuse_router) {
+    const bool pub_riders = fuse_router && e->rider_pub;
+    if (pub_riders) {
+        rc = 0;                  // no launch here: the riders write h2 inside the gate/up launch and hand it over (ra.h_out stays h2)
+    } else if (fuse_router) {
         umoe_router_args rn = ra;
         rn.norm_only = 1;
         rc = umoe_router_fwd(&rn, s);
@@ -765,6 +781,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     }
     if (rc) return rc;
     PROF(K_ROUTER);
+    umoe_rider_pub rpub{};
+    rpub.flags = e->ep_words + 16; rpub.step = e->ep_words; rpub.layer = l; rpub.layers = c.layers; rpub.err = e->ep_words + 1;
     // 7./8. experts.  The shared experts need no routing: with `overlap_shared` they run on a second stream from the
     // residual stream x1 (their own RMSNorm prologue) BESIDE the latency-bound router + dispatch (forked after o_proj,
     // see below) and are joined before the combine; otherwise routed + shared share one launch each.
@@ -777,6 +795,10 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     if (dense) {             // per-CU byte balance decides this kernel (see umoe_gemm.hip): 7 pairs per workgroup, flat slices
         gu.nt = 14;
         if (fuse_router) gu.fused_router = &ra;
+        if (pub_riders) {
+            gu.rider_pub = &rpub;
+            gu.groups_host = e->h_gu_pub.data() + (size_t)l * G;     // shared experts first (riders early in dispatch order)
+        }
         if (e->flat_wgs > 0 && ceil_div((c.n_real * c.inter_dyn + c.n_fix * c.inter_shared) / 16, e->flat_wgs) <= 7) gu.flat_wgs = e->flat_wgs;
     }
     // (dense mode with the post-attention RMSNorm in this launch's staging prologue, so that it would not wait for the

@@ -76,8 +76,12 @@ struct umoe_group_pack { umoe_group_t g[UMOE_GROUPS_INLINE]; };
 // FR ("fused router", umoe_gemm_args.fused_router): the z-slice in front of the first group holds one workgroup per token that runs the
 // Top-P router (threads 0..255; umoe_router_dev.h) instead of a GEMM tile -- 16 workgroups on CUs the 226 GEMM workgroups leave
 // idle.  The GEMM of the dense-expert decode layout does not read the router's outputs, the combine launch after it does.
-template <int NT, int U, int PRO, int EPI, int WV, bool FR = false>
-__global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_router_args ra, const int rider_mode) {
+// PUB (umoe_gemm_args.rider_pub, with FR): the riders also WRITE the normalised rows this GEMM stages (ra.h_out == p.a) and publish
+// one flag per row; the GEMM workgroups request their first weight chunk, then wait for the 16 flags (one lane each, bounded), then
+// stage the rows with sc1 loads -- the hand-off hides behind the weight stream's first round trip and the RMSNorm launch disappears.
+template <int NT, int U, int PRO, int EPI, int WV, bool FR = false, bool PUB = false>
+__global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_router_args ra, const int rider_mode,
+                                                            const umoe_rider_pub pub) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // riders (FR).  rider_mode 1: an extra z-slice in front of the first group (x = token); 2: the launch's DEAD workgroups (x beyond
     // a short group's tiles -- the grid is a box over the widest group) take the tokens in (z, x) order: no extra workgroups, the
@@ -97,8 +101,14 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
         if (token >= 0) {
             if (token < ra.S && blockIdx.y == 0 && threadIdx.x < 256) {
                 TL_ENTER(5);
-                if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
-                else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
+                uint32_t* pf = nullptr;
+                uint32_t pe = 0;
+                if constexpr (PUB) {
+                    pf = pub.flags;
+                    pe = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
+                }
+                if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS, pf, pe);
+                else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS, pf, pe);
                 TL_EXIT(5);
             }
             return;
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     //    requested FIRST, the weight stream right behind them -- the tile is staged while the first chunk is in flight;
     //  * ragged groups: the activation addresses hang on device-produced tables (count -> offset -> gather list), so the
     //    weight stream goes first and overlaps that chain.
-    const bool ragged = g.count || g.row_off || g.rows;
+    const bool ragged = PUB || g.count || g.row_off || g.rows;   // (PUB: weights first too -- the rows do not exist yet)
     // second register stage requested before the staging too (static groups): HBM has work queued for the whole prologue.
     // Only where the registers allow it without spilling (checked per instantiation with -S: private_segment_fixed_size 0).
     constexpr bool DEEP = false;   // measured: gate/up NT 14 35.3 -> 42.6 us, down 23.8 -> 29.8 us -- MORE bytes in flight made it slower
@@ -207,6 +217,25 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     const int roff = g.row_off ? *g.row_off : 0;
     const int row0 = blockIdx.y * 16;
     if (row0 >= count) return;   // (an expert no row chose: its first chunk was requested for nothing -- rare at 16 rows)
+    if constexpr (PUB) {
+        // wait for the riders of THIS launch: lanes 0..count-1 of wave 0 poll one row flag each; bounded (a rider that never runs --
+        // an admitted workgroup that is not resident -- ends the wait with the sticky error word set)
+        if (tid < count) {
+            const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
+            umoe_gu32* f = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.flags + row0 + tid));
+            umoe_gu32* err = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.err));
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned spins = 0;; ++spins) {
+                if ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 1023u) == 1023u && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 200000000ull)) {
+                    __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- stage the 16-row activation tile: every global load of a thread is in flight before the first LDS write ----
     {
@@ -248,7 +277,16 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
             for (int n = 0; n < 16; ++n) {
                 const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
                 buf[n] = make_uint4(0, 0, 0, 0);
-                if (valid && i < QW) buf[n] = ld16(src + (h * Q8 + ia + i) * 8);
+                if (valid && i < QW) {
+                    if constexpr (PUB) {   // rows handed over inside this launch: every load of them is an sc1 load
+                        typedef uint32_t u32x4_pub __attribute__((ext_vector_type(4)));
+                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, 16 * p.lda * 2, 0x00020000);
+                        const u32x4_pub t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((arow * (long)p.lda + g.a_col_off + (h * Q8 + ia + i) * 8) * 2), 0, 16);
+                        buf[n] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                    } else {
+                        buf[n] = ld16(src + (h * Q8 + ia + i) * 8);
+                    }
+                }
             }
             if (ib0 == 0 && !ragged) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -447,14 +485,14 @@ static size_t gemm_lds_bytes(int max_k, int NT, int WV, int ksplit, int pro = UM
     return a > red ? a : red;
 }
 
-template <int NT, int U, int PRO, int EPI, int WV = 4, bool FR = false>
+template <int NT, int U, int PRO, int EPI, int WV = 4, bool FR = false, bool PUB = false>
 static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
     const int ksplit = a->ksplit > 1 ? a->ksplit : 1;
     const size_t lds = gemm_lds_bytes(a->max_k, NT, WV, ksplit, PRO);
     UMOE_REQUIRE(lds <= 160 * 1024, "umoe_grouped_gemm: K=%d needs %zu bytes of LDS (> 160 KiB)", a->max_k, lds);
     static size_t configured = 0;  // per instantiation
     if (lds > configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, U, PRO, EPI, WV, FR>),
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, U, PRO, EPI, WV, FR, PUB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
@@ -480,7 +518,18 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
         rider_mode = (dead >= ra.S && ksplit == 1 && grid.y == 1 && force != 1) ? 2 : 1;
         if (rider_mode == 1) grid.z += 1;        // the router's workgroups: x = token, z = 0 (in front of the first group)
     }
-    wstream_gemm<NT, U, PRO, EPI, WV, FR><<<grid, WV * 64, lds, s>>>(b, gp, ra, rider_mode);
+    umoe_rider_pub pub;
+    memset(&pub, 0, sizeof(pub));
+    if (PUB) {
+        pub = *reinterpret_cast<const umoe_rider_pub*>(a->rider_pub);
+        UMOE_REQUIRE(pub.flags && pub.step && pub.err && ra.h_out == a->a && ra.norm_w && grid.y == 1 && a->max_rows <= 16 && a->groups_host,
+                     "umoe_grouped_gemm: rider_pub needs flags / step / err, fused_router->h_out == a (with norm_w), <= 16 rows, host descriptors");
+        for (int i = 0; i < a->num_groups; ++i)
+            UMOE_REQUIRE(!a->groups_host[i].rows && !a->groups_host[i].count && !a->groups_host[i].row_off && a->groups_host[i].a_row_base == 0 &&
+                             a->groups_host[i].a_col_off == 0 && a->groups_host[i].static_count == ra.S,
+                         "umoe_grouped_gemm: rider_pub needs static groups over rows [0, S) of `a` (group %d)", i);
+    }
+    wstream_gemm<NT, U, PRO, EPI, WV, FR, PUB><<<grid, WV * 64, lds, s>>>(b, gp, ra, rider_mode, pub);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -595,6 +644,7 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
                                      a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE,
                                  "umoe_grouped_gemm: fused_router needs <= 16 rows, n_dyn 9 / n_fix 2, D 2048 / 4096, S <= %d workgroups of the launch",
                                  ceil_div(a->max_n_blocks, 14));
+                    if (a->rider_pub) return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8, true, true>(a, s);
                     return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8, true>(a, s);
                 }
                 return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s);

@@ -374,8 +374,12 @@ __device__ __forceinline__ int route_from_logits(const umoe_router_args& a, cons
 // NORM_ONLY: stop after h_out = RMSNorm(x) (the same arithmetic, bit for bit, as the full body): the decode engine runs this as its
 // own small launch in front of the expert GEMM and lets the full body (h_out = NULL) ride INSIDE the gate/up launch as extra
 // workgroups -- the routing chain (4.4 us of serial work per token) leaves the critical path.
+// pub_flag != NULL (riders of the dense decode gate/up launch, umoe_gemm_args.rider_pub): the normalised row h_out[s] is HANDED to
+// the GEMM workgroups of the SAME launch -- stored write-through (sc1), drained by every storing wave in front of the body's own
+// barrier, then lane 0 publishes `pub_epoch` in pub_flag[s] (hand-off form: cdna_hip_programming.md Guideline 16 R1).
 template <int ND, int NF, int TB, bool NORM_ONLY>
-__device__ __forceinline__ void router4_body(const umoe_router_args& a, const int s, const int tid, float* lds TL_PARAM) {
+__device__ __forceinline__ void router4_body(const umoe_router_args& a, const int s, const int tid, float* lds TL_PARAM,
+                                             uint32_t* pub_flag = nullptr, uint32_t pub_epoch = 0) {
 
     constexpr int NEc = ND + NF;
     constexpr int T = TB;
@@ -433,7 +437,16 @@ __device__ __forceinline__ void router4_body(const umoe_router_args& a, const in
                 for (int j = 0; j < 8; ++j) f[j] = rbf(w[j] * rbf(f[j] * rs));
                 xv[n] = pack8(f);
             }
-            if (a.h_out) st16(a.h_out + (size_t)s * a.D + c * 8, xv[n]);
+            if (a.h_out) {
+                if (pub_flag) {
+                    typedef uint32_t u32x4_pub __attribute__((ext_vector_type(4)));
+                    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(a.h_out + (size_t)s * a.D, 0, a.D * 2, 0x00020000);
+                    const u32x4_pub v4 = {xv[n].x, xv[n].y, xv[n].z, xv[n].w};
+                    __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, c * 16, 0, 16);      // aux 16 = sc1 (agent scope write-through)
+                } else {
+                    st16(a.h_out + (size_t)s * a.D + c * 8, xv[n]);
+                }
+            }
             if (NORM_ONLY) continue;
 #pragma unroll
             for (int e = 0; e < NEc; ++e) {
@@ -448,7 +461,10 @@ __device__ __forceinline__ void router4_body(const umoe_router_args& a, const in
     if (NORM_ONLY) return;
     const float mine = reduce16_to_lanes(acc, lane);
     if (lane < UMOE_MAXE) lg_part[wave][lane] = mine;
+    if (pub_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its sc1 stores
     __syncthreads();
+    if (pub_flag && tid == 0)
+        __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub_flag + s)), pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wave != 0) return;
     float full = -INFINITY;
     if (lane < NEc) full = round_t(((lg_part[0][lane] + lg_part[1][lane]) + lg_part[2][lane]) + lg_part[3][lane], T);
