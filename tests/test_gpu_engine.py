@@ -359,6 +359,49 @@ def test_training_step_full_width_layer_at_6240_tokens_vs_autograd_oracle(dev, j
     assert routed[len(routed) // 2] < lim["rm"] and routed[-1] < lim["rw"], routed[-6:]
 
 
+def test_generate_with_teacher_labels_golden_loss_and_guidance(dev, capsys):
+    """DecoderOutput.labels_prefill (reference model.py:1138-1171): the first `debug_guidance_step` steps feed the labels forward,
+    every step prints the golden loss; the loss equals the oracle's formula on the engine's own logits."""
+    from oracle import decode as OD
+    from unimoe_audio_amd.codec_utils import DecoderOutput, prepare_audio_prompt
+    from unimoe_audio_amd.model import golden_loss
+    cfg = small_cfg()
+    m, w = build(cfg, 41, 0.08)
+    B, T, max_tokens = 2, 10, 12
+    ids, am, codec = prompt(cfg, B, T, 42, [2, 0, 0, 0])
+    pre, psteps = prepare_audio_prompt(cfg, [None] * B)
+    torch.manual_seed(43)
+    labels = torch.randint(0, 1024, (B, max_tokens + 24, cfg.codec_channels))
+    labels[:, 0] = cfg.codec_bos_value
+    gm = m.to(dev)
+    dec = DecoderOutput(pre.clone(), psteps, dev, labels_prefill=labels)
+    codes, lengths = gm.generate(ids, am, dec, max_tokens, max_tokens, codec_input_ids=codec, cfg_scale=2.0, do_sample=False,
+                                 eos_prob_mul_factor=0.8, debug_guidance_step=4)
+    out = capsys.readouterr().out
+    assert out.count("golden loss:") == max_tokens and len(gm.golden_losses) == max_tokens
+    toks = dec.generated_tokens.cpu()
+    for s in range(1, 5):                                   # guided steps: the generated entries of the token buffer ARE the labels
+        gen = pre[:, s] == -1
+        assert torch.equal(toks[:, s][gen].long(), labels[:, s][gen])
+    assert not torch.equal(toks[:, 6].long(), labels[:, 6])                      # free running afterwards
+    # formula check on hand-made logits (channel-0 weight 3, masks as in model.py:1022-1026, empty channels skipped)
+    g = torch.randn(3, 12, 1027)
+    lab = torch.randint(0, 1024, (3, 12))
+    lab[:, 5] = 1025
+    lab[0, 0] = 1024
+    ref = None
+    for c in range(12):
+        l = lab[:, c].clone()
+        l[l > 1024] = -100
+        if c:
+            l[l >= 1024] = -100
+            if int((l != -100).sum()) == 0:
+                continue
+        t = torch.nn.functional.cross_entropy(g[:, c], l, ignore_index=-100) * (3 if c == 0 else 1)
+        ref = t if ref is None else ref + t
+    assert torch.allclose(golden_loss(g, lab, 1024), ref)
+
+
 def test_checkpoint_round_trip_generates_identical_codes(dev, tmp_path):
     """unimoe_audio_amd.checkpoint: HF-style shards (reference key spelling, index json) -> from_pretrained straight onto the
     device -> the same codes, bit for bit, as the model the checkpoint was written from (same kernels, same weights)."""

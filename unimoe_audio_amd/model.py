@@ -272,6 +272,39 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
                                                   all_router_expert_mask=out.all_router_expert_mask,
                                                   all_router_weight=out.all_router_weight, aux_balance_loss=aux_mean)
 
+    def _run_with_labels(self, eng, dec_output, max_tokens, min_tokens, cfg_scale, eos_mul, debug_guidance_step, use_graph):
+        """generate() with teacher labels in the DecoderOutput (reference model.py:1138-1143,1155,1019-1048,1170-1171): every step
+        prints the "golden loss" of the labels under the guided logits, and the first `debug_guidance_step` steps (all of them
+        for -1) feed the LABELS forward instead of the sample.  A diagnostic path: one host round trip per step."""
+        cfg = self.config
+        B, C, V, eos = eng.batch, cfg.codec_channels, cfg.codec_vocab_size, cfg.codec_eos_value
+        labels = dec_output.labels_prefill.to(self.device)
+        step0 = int(eng.state[4 * B].item())
+        self.golden_losses = []
+        budget = max_tokens - step0
+        for i in range(budget):
+            dec_step = step0 + i
+            lab = labels[:, dec_step + 1] if dec_step + 1 < labels.shape[1] else None
+            guided_step = lab is not None and (dec_step < debug_guidance_step or debug_guidance_step == -1)
+            if guided_step:                          # pred = labels: the masked update keeps what is already in the token buffer
+                cur = eng.tokens[:, dec_step + 1]
+                eng.tokens[:, dec_step + 1] = torch.where(cur == -1, lab.to(torch.int32), cur)
+            eng.step(use_graph)
+            if lab is not None:
+                lg = eng.copy_buffer("logits", torch.float32, (2 * B, C, V)).view(B, 2, C, V)
+                guided = (lg[:, 1] + cfg_scale * (lg[:, 1] - lg[:, 0])) if cfg_scale != 0 else lg[:, 1].clone()      # model.py:994-999
+                if min_tokens is None or dec_step >= min_tokens:                                                     # enable_eos
+                    guided[:, :, eos + 1:] = float("-inf")
+                    guided[:, 1:, eos:] = float("-inf")
+                else:
+                    guided[:, :, eos:] = float("-inf")
+                guided[:, 0, eos] *= eos_mul
+                gl = golden_loss(guided, lab, eos)
+                self.golden_losses.append(None if gl is None else float(gl))
+                print(f"golden loss: {gl}")                                                                          # model.py:1048
+            if eng.all_done():
+                break
+
     # ---- engine -----------------------------------------------------------------------------------------
     def _pack_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -309,12 +342,33 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
         eng.start_decode(dec_output.generated_tokens, dec_output.prefill_steps, int(max_tokens), min_tokens,
                          cfg_scale=cfg_scale, temperature=temperature, top_p=top_p, top_k=cfg_filter_top_k,
                          eos_mul=eos_prob_mul_factor, do_sample=do_sample, seed=seed)
-        eng.run(use_graph=use_graph, poll_every=poll_every)
+        if getattr(dec_output, "labels_prefill", None) is not None:
+            self._run_with_labels(eng, dec_output, int(max_tokens), min_tokens, cfg_scale, eos_prob_mul_factor, int(debug_guidance_step),
+                                  use_graph)
+        else:
+            eng.run(use_graph=use_graph, poll_every=poll_every)
         codes, lengths, tokens = eng.finish()
         dec_output.generated_tokens = tokens
         if codes is None:
             print("Warning: Nothing generated for any sequence in the batch.")        # model.py:1230
         return codes, lengths
+
+
+def golden_loss(guided_BxCxV: torch.Tensor, labels_BxC: torch.Tensor, eos: int) -> Optional[torch.Tensor]:
+    """The teacher's loss of one decode step (reference _decoder_step, model.py:1019-1048): labels above EOS are ignored on channel 0,
+    labels >= EOS on the delayed channels; CrossEntropy per channel on the GUIDED logits (after CFG, masks and the EOS factor),
+    channel 0 weighted 3, channels without a valid label skipped (except channel 0)."""
+    lab = labels_BxC.clone().long()
+    lab[lab > eos] = -100
+    rest = lab[:, 1:]
+    rest[rest >= eos] = -100
+    total = None
+    for c in range(lab.shape[1]):
+        if c != 0 and int((lab[:, c] != -100).sum()) == 0:
+            continue
+        l = torch.nn.functional.cross_entropy(guided_BxCxV[:, c].float(), lab[:, c], ignore_index=-100) * (3 if c == 0 else 1)
+        total = l if total is None else total + l
+    return total
 
 
 class DecodeEngine:
