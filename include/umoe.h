@@ -543,6 +543,19 @@ int umoe_dac_conv_transpose1d(const float* x, const float* w, const float* bias,
  * y[b][frame * n + phase] = sum_t kern[phase][t] * x[b][frame * o - width + t] (zero outside [0, L)). */
 int umoe_dac_resample(const float* x, const float* kern, int B, int L, int o, int n, int width, int Lout, float* y, umoe_stream_t stream);
 
+/* Vision tower pieces (reference utils/UniMoE_Audio_utils.py:756-900 over the third-party transformers vision block /
+ * attention / MLP / patch merger).  The projections run on umoe_tiled_gemm; these are the rest.
+ *   umoe_vision_rope: apply_rotary_pos_emb_vision on q and k inside the fused qkv buffer [S][3][H][hd] (fp32 arithmetic, one rounding);
+ *                     cos / sin [S][hd] fp32.
+ *   umoe_vision_attn: non-causal attention of token s over the keys [seg_lo[s], seg_hi[s]) of its cu_seqlens segment; out [S][H*hd].
+ *   umoe_swiglu_pair: gu [S][2I] = (gate | up) with biases -> h [S][ldh] = bf16(bf16(silu(g)) * u), columns [I, ldh) zero.
+ *   umoe_gelu:        exact GELU in place (patch merger). */
+int umoe_vision_rope(uint16_t* qkv, const float* cos_t, const float* sin_t, int S, int H, int hd, umoe_stream_t stream);
+int umoe_vision_attn(const uint16_t* qkv, const int32_t* seg_lo, const int32_t* seg_hi, int S, int H, int hd, float scale, uint16_t* out,
+                     umoe_stream_t stream);
+int umoe_swiglu_pair(const uint16_t* gu, int S, int I, int ldh, uint16_t* h, umoe_stream_t stream);
+int umoe_gelu(uint16_t* x, long n, umoe_stream_t stream);
+
 /* ------------------------------------------------------------------ decode engine
  * Owns workspace + KV cache and enqueues a whole decode step (36 layers + head + sampler + delay
  * bookkeeping) from one host call, optionally replayed as a hipGraph.  Restates
@@ -598,6 +611,11 @@ size_t umoe_engine_workspace_bytes(const umoe_engine* e);
 /* prefill: x [rows*T][D] input embeddings (host builds them: text embed + codec scatter, model.py:663-670),
  * valid [rows][T] 0/1 attention mask (left padded). Fills the KV cache. */
 int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T, umoe_stream_t stream);
+/* the same with explicit rotary positions (multimodal prompts, reference get_rope_index model.py:513-652): pos3_host [3][rows][T]
+ * int32 (NULL = from the mask as above), next_pos_host [rows] = position of the first generated token of each row = max position + 1
+ * (the reference's cache_position + rope_deltas; NULL = number of valid tokens) */
+int umoe_engine_prefill_pos(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T, const int32_t* pos3_host,
+                            const int32_t* next_pos_host, umoe_stream_t stream);
 /* decode bookkeeping state + token buffer (device, owned by caller) */
 typedef struct {
     int32_t* tokens;          /* [B][Tmax][C], -1 = to be generated */

@@ -574,6 +574,76 @@ def gen_attn(ref, out):
         save(os.path.join(out, f"attn_{dt_name}.npz"), **d)
 
 
+class _VisionRotary453(torch.nn.Module):
+    """THIRD-PARTY compatibility stub: transformers 4.53.1 `Qwen2_5_VisionRotaryEmbedding` (the version the reference pins,
+    configs/enviroment.yml:178) -- forward(seqlen) = outer(arange(seqlen), inv_freq).  The 5.15.0 class installed here takes
+    position ids instead, which the reference's own rot_pos_emb (utils.py:786-813) does not pass."""
+
+    def __init__(self, dim, theta=10000.0):
+        super().__init__()
+        self.dim, self.theta = dim, theta
+
+    def forward(self, seqlen):
+        # fp32 like a model loaded through from_pretrained(torch_dtype=bf16): the buffer is created with an explicit float dtype
+        # and never loaded from the checkpoint, so it does not follow the parameters to bf16 (a later module.to(bf16) would)
+        inv_freq = 1.0 / (self.theta ** (torch.arange(0, self.dim, 2, dtype=torch.float) / self.dim))
+        return torch.outer(torch.arange(int(seqlen), dtype=torch.float), inv_freq)
+
+
+def gen_vision(ref, out):
+    """The reference's OWN vision tower (utils/UniMoE_Audio_utils.py:585-900: Conv3D patch embedding, window index, rot_pos_emb,
+    32 x Qwen2_5_VLVisionBlock, patch merger, un-permute) at a reduced size, and `get_rope_index` (model.py:513-652)."""
+    U = ref.utils
+    U.Qwen2_5_VisionRotaryEmbedding = _VisionRotary453
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLVisionConfig
+    kw = dict(depth=3, hidden_size=160, intermediate_size=348, num_heads=2, in_channels=3, patch_size=14, spatial_merge_size=2,
+              temporal_patch_size=2, window_size=112, fullatt_block_indexes=[1], out_hidden_size=64, hidden_act="silu")
+    vc = Qwen2_5_VLVisionConfig(**kw)
+    vc._attn_implementation = "sdpa"
+    torch.manual_seed(3100)
+    m = U.Qwen2_5_VisionTransformerPretrainedModel(vc)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() > 1:
+                p.normal_(0, 0.05)
+            elif "norm" in n or "ln_q" in n:
+                p.copy_(1 + 0.05 * torch.randn_like(p))
+            else:
+                p.normal_(0, 0.02)
+    m = m.to(torch.bfloat16).eval()
+    grid = torch.tensor([[2, 16, 16], [1, 8, 12], [1, 18, 10]])          # two clips and a frame whose sides do not fill whole windows
+    N = int((grid[:, 0] * grid[:, 1] * grid[:, 2]).sum())
+    x = torch.randn(N, 3 * 2 * 14 * 14).to(torch.bfloat16)
+    with torch.no_grad():
+        y = m(x, grid_thw=grid)
+        h0 = m.patch_embed(x)
+        widx, cu_win = m.get_window_index(grid)
+        rot = m.rot_pos_emb(grid)
+    d = {"in_x": x, "in_grid": grid, "out_y": y, "out_patch": h0, "out_window_index": widx, "out_cu_window": torch.tensor(cu_win),
+         "out_rot": rot, "cfg_json": np.frombuffer(__import__("json").dumps(kw).encode(), dtype=np.uint8)}
+    for n, p in m.state_dict().items():
+        d["w." + n] = p
+    save(os.path.join(out, "vision_tower.npz"), **d)
+    # get_rope_index: an unbound call on a stand-in `self` that carries the config fields it reads (model.py:521-525, 575-579)
+    cfgns = types.SimpleNamespace(vision_config=types.SimpleNamespace(spatial_merge_size=2, tokens_per_second=2), image_token_id=301,
+                                  video_token_id=302, vision_start_token_id=303)
+    fake = types.SimpleNamespace(config=cfgns)
+    fn = ref.model.UniAudioRVQQwen2_5VLMoEForConditionalGeneration.get_rope_index
+    ids = torch.randint(0, 290, (3, 60))
+    am = torch.ones(3, 60, dtype=torch.long)
+    am[0, :9] = 0
+    am[2, :21] = 0
+    # row 0: one video of grid [2, 4, 6] -> 12 tokens; row 1: an image [1, 4, 4] -> 4 tokens and a video [3, 6, 4] -> 18; row 2: text only.
+    # seconds per temporal grid 2.5 and 0.5: the reference casts them to the long dtype of its index tensor (:597-601): 2 and 0
+    ids[0, 20] = 303; ids[0, 21:33] = 302
+    ids[1, 5] = 303; ids[1, 6:10] = 301; ids[1, 30] = 303; ids[1, 31:49] = 302
+    vg, sec = torch.tensor([[2, 4, 6], [3, 6, 4]]), torch.tensor([2.5, 0.5])
+    pos, delta = fn(fake, ids, torch.tensor([[1, 4, 4]]), vg, sec, am)
+    pos_t, delta_t = fn(fake, ids, None, None, None, am)                     # text-only branch (:634-652)
+    save(os.path.join(out, "rope_index.npz"), in_ids=ids, in_mask=am, in_image_grid=torch.tensor([[1, 4, 4]]),
+         in_video_grid=vg, in_second_per_grid=sec, out_pos=pos, out_delta=delta, out_pos_text=pos_t, out_delta_text=delta_t)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
@@ -583,7 +653,7 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     ref = _ref_shim.load_reference(True)
     gens = dict(router=gen_router_ids, dcmoe=gen_dcmoe, dcmoebwd=gen_dcmoe_bwd, compress=gen_compress, delay=gen_delay,
-                sampler=gen_sampler, generate=gen_generate, attn=gen_attn)
+                sampler=gen_sampler, generate=gen_generate, attn=gen_attn, vision=gen_vision)
     for k, fn in gens.items():
         if a.only and k not in a.only.split(","):
             continue

@@ -135,7 +135,7 @@ EXPORTS = [
     "umoe_attn_prefill_bwd_workspace_bytes", "umoe_attn_prefill_bwd",
     "umoe_ep_unique_id", "umoe_ep_comm_create", "umoe_ep_comm_destroy", "umoe_ep_all_to_all",
     "umoe_ep_ipc_export", "umoe_ep_ipc_open", "umoe_ep_ipc_close", "umoe_engine_ep_region", "umoe_engine_ep_connect",
-    "umoe_engine_ep_error", "umoe_token_drop", "umoe_router_bwd_drop", "umoe_router_bwd_ex", "umoe_dac_conv1d", "umoe_dac_conv_transpose1d", "umoe_dac_resample",
+    "umoe_engine_ep_error", "umoe_token_drop", "umoe_router_bwd_drop", "umoe_router_bwd_ex", "umoe_dac_conv1d", "umoe_dac_conv_transpose1d", "umoe_dac_resample", "umoe_vision_rope", "umoe_vision_attn", "umoe_swiglu_pair", "umoe_gelu", "umoe_engine_prefill_pos",
 ]
 
 EP_PEER, EP_LOOPBACK, EP_RCCL = 0, 1, 2
@@ -174,6 +174,11 @@ def lib():
         L.umoe_dac_conv1d.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, C.POINTER(i32), vp]
         L.umoe_dac_conv_transpose1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, C.POINTER(i32), vp]
         L.umoe_dac_resample.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+        L.umoe_vision_rope.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+        L.umoe_vision_attn.argtypes = [vp, vp, vp, i32, i32, i32, f32, vp, vp]
+        L.umoe_swiglu_pair.argtypes = [vp, i32, i32, i32, vp, vp]
+        L.umoe_gelu.argtypes = [vp, C.c_long, vp]
+        L.umoe_engine_prefill_pos.argtypes = [vp, vp, vp, i32, vp, vp, vp]
         L.umoe_token_drop.argtypes = [vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
         L.umoe_rmsnorm_residual_bwd.argtypes = [vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, C.c_size_t, vp]
         L.umoe_dispatch_build_aligned.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -868,6 +868,11 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
 // ------------------------------------------------------------------------------------ prefill
 extern "C" int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T,
                                    umoe_stream_t stream) {
+    return umoe_engine_prefill_pos(e, x, valid_host, T, nullptr, nullptr, stream);
+}
+
+extern "C" int umoe_engine_prefill_pos(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T, const int32_t* pos3_host,
+                                       const int32_t* next_pos_host, umoe_stream_t stream) {
     UMOE_REQUIRE(e && x && valid_host && T > 0, "umoe_engine_prefill: bad argument");
     const umoe_engine_cfg& c = e->c;
     UMOE_REQUIRE(T < c.Lmax, "umoe_engine_prefill: prompt length %d does not fit Lmax %d", T, c.Lmax);
@@ -888,15 +893,19 @@ extern "C" int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint
             cnt += v;
             if (v && first == T) first = t;
             const int p = v ? cnt - 1 : 1;
-            for (int k = 0; k < 3; ++k) pos[(size_t)k * n_tok + r * T + t] = p;
+            for (int k = 0; k < 3; ++k) {
+                const int pk = pos3_host ? pos3_host[((size_t)k * c.rows + r) * T + t] : p;
+                UMOE_REQUIRE(pk >= 0 && pk < e->max_pos, "umoe_engine_prefill: position %d outside the rope table (%d)", pk, e->max_pos);
+                pos[(size_t)k * n_tok + r * T + t] = pk;
+            }
             kvp[r * T + t] = t;
         }
         // left padding assumed (tokenizer padding_side="left", mod.py:104): valid keys are [first, L)
         for (int t = first; t < T; ++t)
             UMOE_REQUIRE(valid_host[(size_t)r * T + t], "umoe_engine_prefill: row %d is not left-padded", r);
         start[r] = first;
-        vc[r] = cnt;
-        UMOE_REQUIRE(cnt + c.Lmax - T < e->max_pos, "umoe_engine_prefill: rope table too short");
+        vc[r] = next_pos_host ? next_pos_host[r] : cnt;           // position of the first generated token (decode: + steps taken)
+        UMOE_REQUIRE(vc[r] >= 0 && vc[r] + c.Lmax - T < e->max_pos, "umoe_engine_prefill: rope table too short");
     }
     UMOE_HIP(hipMemcpyAsync(e->pos3, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, s));
     UMOE_HIP(hipMemcpyAsync(e->kv_pos, kvp.data(), kvp.size() * 4, hipMemcpyHostToDevice, s));
