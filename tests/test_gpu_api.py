@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 class StandInTokenizer:
     """splits on the reference's special tokens, hashes everything else to ids < 290; left padding like mod.py:104"""
 
-    def __init__(self, placeholder_id: int):
+    def __init__(self, placeholder_id: int, special=None):
         self.placeholder_id = placeholder_id
+        self.special = special or {}
 
     def __call__(self, texts, add_special_tokens=False, return_tensors="pt", padding=True):
         rows = []
@@ -29,6 +30,8 @@ class StandInTokenizer:
                     continue
                 if piece == "<|AUDIO_PLACEHOLDER|>":
                     ids.append(self.placeholder_id)
+                elif piece in self.special:
+                    ids.append(self.special[piece])
                 elif piece.startswith("<|"):
                     ids.append(200 + (sum(map(ord, piece)) % 80))
                 else:
@@ -80,3 +83,39 @@ def test_text_to_speech_and_music_write_wavs(tmp_path):
     assert len(out2) == 1 and os.path.isfile(out2[0])
     with pytest.raises(ValueError):
         app.text_to_speech(["x"], "p", None, str(tmp_path))      # "Please provide a reference audio file."
+
+
+def test_video_text_to_music_writes_a_wav(tmp_path):
+    """BASELINE configs[4] path through the task API (UniMoE_Audio.py:203-257): frames -> processor patch layout -> vision tower ->
+    video tokens + caption -> generate() with 3-D mRoPE positions -> codec decode -> wav."""
+    from unimoe_audio_amd import dac as D
+    from unimoe_audio_amd.api import UniMoEAudio
+    from unimoe_audio_amd.config import UniMoEAudioConfig
+    from unimoe_audio_amd.model import UniAudioRVQQwen2_5VLMoEForConditionalGeneration as Model
+    dev = torch.device("cuda:0")
+    vc = dict(depth=2, hidden_size=160, intermediate_size=348, num_heads=2, in_chans=3, patch_size=14, spatial_merge_size=2, temporal_patch_size=2,
+              window_size=112, fullatt_block_indexes=[1], out_hidden_size=256, tokens_per_second=2)
+    cfg = UniMoEAudioConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1, vocab_size=320,
+                            dynamic_intermediate_size=128, shared_intermediate_size=64, codec_placeholder_value=300, vision_config=vc,
+                            image_token_id=301, video_token_id=302, vision_start_token_id=303, vision_end_token_id=304)
+    torch.manual_seed(0)
+    m = Model(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "norm" in n or "ln_q" in n:
+                p.fill_(1.0)
+            elif n.endswith("bias"):
+                p.zero_()
+            else:
+                p.normal_(0, 0.05)
+    m = m.to(dev, torch.bfloat16).eval()
+    app = UniMoEAudio(None, 0, model=m)
+    app._tokenizer = StandInTokenizer(cfg.codec_placeholder_value, {"<|video_pad|>": 302, "<|vision_start|>": 303, "<|vision_end|>": 304})
+    app.dac = D.Dac(model=D.DacModel(encoder_dim=16, decoder_dim=192).init_random(2).to(dev).float())
+    frames = (torch.rand(8, 120, 160, 3) * 255).to(torch.uint8)              # 8 frames, resized inside the 64-token budget
+    out = app.video_text_to_music(frames, "slow strings", str(tmp_path), max_audio_seconds=1, min_audio_seconds=0)
+    assert len(out) == 1 and os.path.isfile(out[0])
+    with wave.open(out[0], "rb") as wf:
+        assert wf.getframerate() == 16000 and wf.getnframes() >= 15999
+    with pytest.raises(ValueError):
+        app.video_text_to_music("clip.mp4", "x", str(tmp_path))                # file decoding is not available offline

@@ -67,3 +67,70 @@ def test_vision_tower_vs_oracle_at_model_width(dev):
     rel = float((y - ref).norm() / ref.norm())
     print("\\nVISION TOWER vs oracle at model width: rel", rel)
     assert rel < 2 ** -6
+
+
+def test_generate_with_video_prompt_prefill_and_steps_vs_oracle(dev):
+    """The multimodal decode path end to end at small width: vision tower -> video embeddings scattered over <|video_pad|> tokens ->
+    3-D mRoPE positions (get_rope_index) -> engine prefill with explicit positions -> teacher-forced decode steps at position
+    T + step + rope_delta.  Checker: oracle vision tower + oracle text model fed the reference-shaped position ids."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_engine import build, small_cfg
+    from oracle import decode as OD
+    from oracle import vision as OV
+    from unimoe_audio_amd.codec_utils import prepare_audio_prompt
+    from unimoe_audio_amd.model import DecodeEngine
+    vc = dict(depth=2, hidden_size=160, intermediate_size=348, num_heads=2, in_chans=3, patch_size=14, spatial_merge_size=2, temporal_patch_size=2,
+              window_size=112, fullatt_block_indexes=[1], out_hidden_size=256, tokens_per_second=2)
+    cfg = small_cfg(vision_config=vc, image_token_id=301, video_token_id=302, vision_start_token_id=303, vision_end_token_id=304)
+    m, w = build(cfg, 51, 0.06)
+    B, T, steps, MAXT = 2, 48, 4, 44
+    torch.manual_seed(52)
+    ids = torch.randint(0, 290, (2 * B, T))
+    am = torch.ones(2 * B, T, dtype=torch.long)
+    am[0, :5] = 0
+    am[2, :2] = 0
+    grid = torch.tensor([[2, 4, 6]] * (2 * B))                       # every row carries one clip: 2 x 4 x 6 patches -> 12 video tokens
+    for r in range(2 * B):
+        ids[r, 10] = 303
+        ids[r, 11:23] = 302
+        ids[r, 23] = 304
+    px = torch.randn(2 * B * 48, 1176).to(torch.bfloat16)
+    sec = torch.tensor([2.0] * (2 * B))
+    # ---- oracle
+    vw = {k[len("visual."):]: v for k, v in w.items() if k.startswith("visual.")}
+    emb = OV.vision_forward(vc, vw, px, grid)
+    x = OD.input_embedding(cfg, w, ids, None)
+    x = x.masked_scatter((ids == 302).unsqueeze(-1).expand_as(x), emb.to(x.dtype))
+    pos, delta = OV.rope_index(ids, None, grid, sec, am, merge=2, tokens_per_second=2, image_token_id=301, video_token_id=302, vision_start_token_id=303)
+    tm = OD.TextModelOracle(cfg, w)
+    pre, psteps = prepare_audio_prompt(cfg, [None] * B)
+    step0 = min(psteps) - 1
+    forced = torch.randint(0, 1024, (B, max(pre.shape[1], step0 + steps + 2), cfg.codec_channels)).to(torch.int32)
+    keep = pre.to(torch.int32) != -1
+    forced[:, : pre.shape[1]][keep] = pre.to(torch.int32)[keep]
+    with torch.no_grad():
+        _, cache, _ = tm.forward(x, am.bool(), pos, None)
+        key_valid = am.bool()
+        refs = []
+        for s in range(steps):
+            key_valid = torch.cat([key_valid, torch.ones((2 * B, 1), dtype=torch.bool)], -1)
+            p1 = (T + s + delta).expand(-1, 1)                         # cache_position + rope_deltas (model.py:779-790), all three streams
+            tok2 = forced[:, step0 + s: step0 + s + 1].long().repeat_interleave(2, dim=0)
+            h, cache, _ = tm.forward(OD.codec_embedding(cfg, w, tok2), key_valid, p1, cache)
+            refs.append(torch.nn.functional.linear(h, w["codec_head.weight"]).float()[:, -1])
+    # ---- HIP path
+    gm = m.to(dev)
+    xg = gm.multimodal_embedding(ids.to(dev), None, pixel_values_videos=px.to(dev), video_grid_thw=grid)
+    assert float((xg.cpu().float() - x.float()).norm() / x.float().norm()) < 2 ** -6
+    pos_g, delta_g = gm.get_rope_index(ids, None, grid, sec, am)
+    assert torch.equal(pos_g.cpu(), pos) and torch.equal(delta_g.cpu(), delta)
+    eng = DecodeEngine(gm, B, Lmax=T + MAXT + 8, Tmax=MAXT + 64)
+    eng.prefill(xg.reshape(-1, cfg.hidden_size).contiguous(), am.to(dev), position_ids=pos_g, rope_deltas=delta_g)
+    eng.start_decode(forced, psteps, MAXT, 6, cfg_scale=3.0, temperature=1.0, top_p=1.0, top_k=45, eos_mul=0.8, do_sample=False)
+    for s in range(steps):
+        eng.step(use_graph=(s >= 2))
+        got = eng.copy_buffer("logits", torch.float32, (2 * B, cfg.codec_channels * cfg.codec_vocab_size)).cpu()
+        rel = (got - refs[s]).norm(dim=-1) / refs[s].norm(dim=-1)
+        assert float(rel.median()) < 0.03 and float(rel.max()) < 0.25, (s, rel.tolist())
+    eng.close()

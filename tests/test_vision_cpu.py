@@ -47,3 +47,27 @@ def test_state_dict_names_of_the_reference_geometry():
     assert tuple(sd["blocks.1.attn.qkv.weight"].shape) == (3840, 1280) and tuple(sd["blocks.1.mlp.down_proj.weight"].shape) == (1280, 3420)
     assert tuple(sd["merger.mlp.0.weight"].shape) == (5120, 5120) and tuple(sd["merger.mlp.2.weight"].shape) == (2048, 5120)
     assert "merger.ln_q.weight" in sd and "blocks.0.norm2.weight" in sd
+
+
+def test_frames_to_patches_layout_against_a_plain_loop():
+    """the processor's patch layout restated with loops: patch index = ((t * gh/m + bh) * gw/m + bw) * m*m + ih * m + iw, inside a
+    patch (channel, time, row, column)"""
+    torch.manual_seed(0)
+    F_, H, W = 4, 56, 84
+    fr = torch.rand(F_, H, W, 3)
+    patches, grid = V.frames_to_patches(fr, max_pixels=10 ** 9, min_pixels=1)
+    assert grid.tolist() == [2, 4, 6] and patches.shape == (48, 1176)
+    x = (fr.permute(0, 3, 1, 2) - torch.tensor(V.CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(V.CLIP_STD).view(1, 3, 1, 1)
+    n = 0
+    for t in range(2):
+        for bh in range(2):
+            for bw in range(3):
+                for ih in range(2):
+                    for iw in range(2):
+                        r0, c0 = (bh * 2 + ih) * 14, (bw * 2 + iw) * 14
+                        ref = x[2 * t:2 * t + 2, :, r0:r0 + 14, c0:c0 + 14].permute(1, 0, 2, 3).reshape(-1)
+                        assert torch.allclose(patches[n], ref, atol=1e-6), n
+                        n += 1
+    assert V.smart_resize(480, 640, 28, 4 * 28 * 28, 64 * 28 * 28) == (168, 252)      # floor to the factor inside the 64-token budget (<= 50 176 px)
+    p2, g2 = V.frames_to_patches((torch.rand(3, 3, 100, 100) * 255).to(torch.uint8))
+    assert g2.tolist()[0] == 2 and p2.shape[0] == int(g2.prod())                       # odd frame count: last frame repeated

@@ -159,8 +159,40 @@ class UniMoEAudio:
                                      temperature, top_p, cfg_filter_top_k, eos_prob_mul_factor, do_sample)
         return self._finish(audios, output_dir, save_name)
 
-    def video_text_to_music(self, video, caption, output_dir: str = "./", **kw) -> List[str]:
-        raise NotImplementedError("video inputs need the vision tower, which is outside the accelerated path (SURVEY.md 8f-1)")
+    def video_text_to_music(self, video, caption: Union[str, List[str]], output_dir: str = "./", max_audio_seconds: int = 20,
+                            min_audio_seconds: int = 8, temperature: float = 1.0, top_p: float = 1.0, cfg_filter_top_k: int = 45,
+                            save_name: str = "video_music", cfg_scale: float = 10.0, eos_prob_mul_factor: float = 0.6, do_sample: bool = True,
+                            fps: float = 1.0, sampling_fps: float = 1.0, max_frames: int = 8, **_) -> List[str]:
+        """reference UniMoE_Audio.py:203-257 / utils/UniMoE_Audio_mod.py:483-619: a video (here: its frames, a uint8 / float tensor
+        [F, H, W, 3] or [F, 3, H, W]; file decoding needs moviepy / qwen_vl_utils, absent offline) + a caption -> music.  The frames are
+        resized to multiples of 28 px within the reference's pixel budget (mod.py:49-53: at most 64 * 28 * 28 per frame), cut into the
+        processor's patch layout and sent through the vision tower; their tokens sit between <|vision_start|> and <|vision_end|>."""
+        from .vision import frames_to_patches
+        caption = self._texts(caption)
+        if isinstance(video, (str, bytes, os.PathLike)):
+            raise ValueError("video: pass the frames as a [F, H, W, 3] or [F, 3, H, W] tensor (file decoding is not available offline)")
+        frames = video if torch.is_tensor(video) else torch.as_tensor(video)
+        if frames.dim() != 4:
+            raise ValueError("video: pass the frames as a [F, H, W, 3] or [F, 3, H, W] tensor (file decoding is not available offline)")
+        patches, grid = frames_to_patches(frames[:max_frames], max_pixels=64 * 28 * 28)
+        n_tok = int(grid.prod()) // 4
+        vid = "<|vision_start|>" + "<|video_pad|>" * n_tok + "<|vision_end|>"
+        neg = SYSTEM_MESSAGE + INPUT_FORMAT.format(vid + "<|MUSIC_START|>Low quality.<|MUSIC_END|>") + AUDIO_START
+        texts = []
+        for c in caption:
+            texts += [neg, SYSTEM_MESSAGE + INPUT_FORMAT.format(vid + "<|MUSIC_START|>" + c + "<|MUSIC_END|>") + AUDIO_START]
+        enc = self.tokenizer(texts, add_special_tokens=False, return_tensors="pt", padding=True)
+        R = len(texts)
+        cfg = self.model.config
+        prefill, steps = prepare_audio_prompt(cfg, [None] * (R // 2))
+        dec = DecoderOutput(prefill, steps, self.device)
+        codes, lengths = self.model.generate(enc.input_ids, enc.attention_mask, dec, max_tokens=max_audio_seconds * 50,
+                                             min_tokens=min_audio_seconds * 50, pixel_values_videos=patches.repeat(R, 1),
+                                             video_grid_thw=grid[None].repeat(R, 1), second_per_grid_ts=torch.full((R,), 2.0 / max(sampling_fps, 1e-6)),
+                                             cfg_scale=cfg_scale, temperature=temperature, top_p=top_p, cfg_filter_top_k=cfg_filter_top_k,
+                                             eos_prob_mul_factor=eos_prob_mul_factor, do_sample=do_sample)
+        audios = [] if codes is None else generate_output(cfg, codes, lengths)
+        return self._finish(audios, output_dir, save_name)
 
 
 def create_unimoe_audio(model_path: str, device_id: int = 0) -> UniMoEAudio:

@@ -58,6 +58,12 @@ class UniMoEAudioConfig:
     codec_pad_value: int = 1025
     codec_bos_value: int = 1026
     codec_placeholder_value: Optional[int] = 151665
+    # multimodal (config.json:32,147-185): token ids and the vision tower's geometry (None = text / audio only)
+    image_token_id: int = 151655
+    video_token_id: int = 151656
+    vision_start_token_id: int = 151652
+    vision_end_token_id: int = 151653
+    vision_config: Optional[dict] = None
 
     # ---- derived -------------------------------------------------------------
     @property
@@ -91,6 +97,9 @@ class UniMoEAudioConfig:
         rope = text.get("rope_scaling") or raw.get("rope_scaling") or {}
         if "mrope_section" in rope:
             merged["mrope_section"] = rope["mrope_section"]
+        for k in ("image_token_id", "video_token_id", "vision_start_token_id", "vision_end_token_id", "vision_config"):
+            if raw.get(k) is not None:
+                merged[k] = raw[k]
         names = {f.name for f in cls.__dataclass_fields__.values()}
         kw = {k: v for k, v in merged.items() if k in names}
         if "mlp_dynamic_top_k" in kw:

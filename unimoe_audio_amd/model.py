@@ -106,6 +106,9 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
         self.codec_head = nn.Linear(config.hidden_size, self.num_channels * self.codec_vocab_size, bias=False)
         if with_lm_head:  # unused on the audio-token path (computed and discarded by the reference, model.py:817)
             self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        if getattr(config, "vision_config", None):      # reference model.py:476-478: `self.visual`, same parameter names
+            from .vision import Qwen2_5_VisionTransformerPretrainedModel
+            self.visual = Qwen2_5_VisionTransformerPretrainedModel(config.vision_config)
         self._engine: Optional["DecodeEngine"] = None
 
     @property
@@ -161,9 +164,46 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
             x = x.masked_scatter(m, ce)
         return x
 
+    # ---- multimodal prompt pieces (reference model.py:513-652,634-652,708-751) -------------------------------------
+    def _vision(self):
+        v = getattr(self, "visual", None)
+        if v is None:
+            raise NotImplementedError("this model was built without a vision tower (config.vision_config is None)")
+        return v
+
+    def get_video_features(self, pixel_values_videos: torch.Tensor, video_grid_thw: torch.Tensor):
+        v = self._vision()
+        emb = v(pixel_values_videos.to(self.device, v.dtype), grid_thw=video_grid_thw)
+        return torch.split(emb, (video_grid_thw.prod(-1) // v.spatial_merge_size ** 2).tolist())
+
+    def get_image_features(self, pixel_values: torch.Tensor, image_grid_thw: torch.Tensor):
+        v = self._vision()
+        emb = v(pixel_values.to(self.device, v.dtype), grid_thw=image_grid_thw)
+        return torch.split(emb, (image_grid_thw.prod(-1) // v.spatial_merge_size ** 2).tolist())
+
+    def get_rope_index(self, input_ids=None, image_grid_thw=None, video_grid_thw=None, second_per_grid_ts=None, attention_mask=None):
+        from .vision import rope_index
+        cfg = self.config
+        vc = cfg.vision_config or {}
+        return rope_index(input_ids, image_grid_thw, video_grid_thw, second_per_grid_ts, attention_mask,
+                          spatial_merge_size=vc.get("spatial_merge_size", 2), tokens_per_second=vc.get("tokens_per_second", 2),
+                          image_token_id=cfg.image_token_id, video_token_id=cfg.video_token_id, vision_start_token_id=cfg.vision_start_token_id)
+
+    def multimodal_embedding(self, input_ids, codec_input_ids=None, pixel_values=None, image_grid_thw=None, pixel_values_videos=None,
+                             video_grid_thw=None):
+        """text / codec embeddings with the image and video embeddings scattered over their placeholder tokens (the working path of
+        the reference's forward, model.py:706-751; its generate() drops the pixels in **kwargs)"""
+        from .vision import scatter_vision_embeddings
+        x = self.calculate_input_embedding(input_ids, codec_input_ids)
+        if pixel_values is not None:
+            x = scatter_vision_embeddings(x, input_ids, self.config.image_token_id, torch.cat(self.get_image_features(pixel_values, image_grid_thw), 0), "Image")
+        if pixel_values_videos is not None:
+            x = scatter_vision_embeddings(x, input_ids, self.config.video_token_id, torch.cat(self.get_video_features(pixel_values_videos, video_grid_thw), 0), "Video")
+        return x
+
     # ---- packed weights shared by forward() and the decode engine ------------------------------------------
     def packed(self) -> dict:
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = tuple((p.data_ptr(), p._version) for n, p in self.named_parameters() if not n.startswith("visual."))
         if getattr(self, "_pk", None) is not None and self._pk_key == key:
             return self._pk
         layers = []
@@ -307,7 +347,7 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
 
     # ---- engine -----------------------------------------------------------------------------------------
     def _pack_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version) for n, p in self.named_parameters() if not n.startswith("visual."))
 
     def engine(self, batch: int, max_prompt: int, max_tokens: int, attn_splits: int = 8, ep=None) -> "DecodeEngine":
         """The decode engine for this shape, rebuilt when the shape, the weights (data pointer / version of any parameter) or the
@@ -328,8 +368,6 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
                  temperature: float = 1.2, top_p: float = 0.95, cfg_filter_top_k: int = 45,
                  eos_prob_mul_factor: float = 0.8, do_sample: bool = True, debug_guidance_step: int = 0, use_cache=True,
                  seed: int = 0, use_graph: bool = True, poll_every: int = 16):
-        if pixel_values is not None or pixel_values_videos is not None:
-            raise NotImplementedError("vision inputs are outside the accelerated path (SURVEY.md 8f-1)")
         if not use_cache:
             raise NotImplementedError("use_cache=False is not supported: the engine always keeps a KV cache")
         dev = self.device
@@ -337,8 +375,14 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
         B = input_ids.shape[0] // 2
         T = input_ids.shape[1]
         eng = self.engine(B, T, int(max_tokens))
-        x = self.calculate_input_embedding(input_ids, None if codec_input_ids is None else codec_input_ids.to(dev))
-        eng.prefill(x.reshape(-1, x.shape[-1]).contiguous(), attention_mask)
+        pos3 = deltas = None
+        if pixel_values is not None or pixel_values_videos is not None:
+            x = self.multimodal_embedding(input_ids, None if codec_input_ids is None else codec_input_ids.to(dev), pixel_values, image_grid_thw,
+                                          pixel_values_videos, video_grid_thw)
+            pos3, deltas = self.get_rope_index(input_ids, image_grid_thw, video_grid_thw, second_per_grid_ts, attention_mask)   # model.py:753-777
+        else:
+            x = self.calculate_input_embedding(input_ids, None if codec_input_ids is None else codec_input_ids.to(dev))
+        eng.prefill(x.reshape(-1, x.shape[-1]).contiguous(), attention_mask, position_ids=pos3, rope_deltas=deltas)
         eng.start_decode(dec_output.generated_tokens, dec_output.prefill_steps, int(max_tokens), min_tokens,
                          cfg_scale=cfg_scale, temperature=temperature, top_p=top_p, top_k=cfg_filter_top_k,
                          eos_mul=eos_prob_mul_factor, do_sample=do_sample, seed=seed)
@@ -399,7 +443,7 @@ class DecodeEngine:
         L.check(L.lib().umoe_engine_create(C.byref(c), C.byref(h)), "umoe_engine_create")
         self.h = h
         self.keep: List[torch.Tensor] = []
-        self._pack_weights()
+        self._pack_weights(max_pos)
         if ep is not None and ep.size > 1 and ep_connect:
             ep.connect(self.h)
         self.tokens = None
@@ -411,7 +455,7 @@ class DecodeEngine:
         self.keep.append(t)
         return t
 
-    def _pack_weights(self):
+    def _pack_weights(self, max_pos_override=None):
         m, cfg, lib = self.model, self.cfg, L.lib()
         bf = torch.bfloat16
         for p in m.parameters():
@@ -445,7 +489,9 @@ class DecodeEngine:
                                rm_exp_gate=reg, rm_exp_up=reu, rm_exp_down=red, rm_sh_gate=rsg, rm_sh_up=rsu, rm_sh_down=rsd)
             L.check(lib.umoe_engine_set_layer(self.h, li, C.byref(w)), "umoe_engine_set_layer")
         emb, head = mpk["emb"], mpk["head"]
-        max_pos = self.Lmax + 8
+        # (slack: the temporal stream of a video advances by seconds-per-grid * tokens_per_second per frame pair, model.py:597-603)
+        max_pos = self.Lmax + 4104 if max_pos_override is None else int(max_pos_override)
+        self.max_pos = max_pos
         cos, sin = ops.rope_tables(max_pos, cfg.head_dim, cfg.rope_theta, self.dev)
         self._k(cos), self._k(sin)
         delay = (C.c_int32 * cfg.codec_channels)(*cfg.codec_delay_pattern)
@@ -456,12 +502,25 @@ class DecodeEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def prefill(self, x: torch.Tensor, attention_mask: torch.Tensor):
+    def prefill(self, x: torch.Tensor, attention_mask: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
+                rope_deltas: Optional[torch.Tensor] = None):
+        """position_ids [3, rows, T] / rope_deltas [rows, 1] (get_rope_index): multimodal prompts; a generated token then sits at
+        position T + steps + delta on all three streams (the reference's cache_position + rope_deltas, model.py:779-790)."""
         rows, T = attention_mask.shape
         assert rows == self.rows and x.shape == (rows * T, self.cfg.hidden_size) and x.dtype == torch.bfloat16
         valid = attention_mask.to(torch.uint8).cpu().contiguous()
         self.T_prompt = T
-        L.check(L.lib().umoe_engine_prefill(self.h, x.data_ptr(), valid.data_ptr(), T, self._stream()), "umoe_engine_prefill")
+        if position_ids is None:
+            L.check(L.lib().umoe_engine_prefill(self.h, x.data_ptr(), valid.data_ptr(), T, self._stream()), "umoe_engine_prefill")
+        else:
+            assert tuple(position_ids.shape) == (3, rows, T) and rope_deltas is not None
+            pos = position_ids.to(torch.int32).cpu().contiguous()
+            nxt = (rope_deltas.reshape(rows).to(torch.int64).cpu() + T).to(torch.int32).contiguous()
+            need = int(max(int(pos.max()), int(nxt.max()) + self.Lmax - T)) + 2
+            if need > self.max_pos:
+                raise L.UmoeError(f"rope table of the engine covers {self.max_pos} positions, the prompt needs {need}")
+            L.check(L.lib().umoe_engine_prefill_pos(self.h, x.data_ptr(), valid.data_ptr(), T, pos.data_ptr(), nxt.data_ptr(), self._stream()),
+                    "umoe_engine_prefill_pos")
         self.captured = False
 
     def start_decode(self, prefill_tokens: torch.Tensor, prefill_steps: List[int], max_tokens: int, min_tokens,

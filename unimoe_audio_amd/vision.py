@@ -266,3 +266,45 @@ def scatter_vision_embeddings(inputs_embeds: torch.Tensor, input_ids: torch.Tens
     if n_tok != n_feat:
         raise ValueError(f"{what} features and {what.lower()} tokens do not match: tokens: {n_tok}, features {n_feat}")
     return inputs_embeds.masked_scatter(mask.unsqueeze(-1).expand_as(inputs_embeds), embeds.to(inputs_embeds.device, inputs_embeds.dtype))
+
+
+# ----------------------------------------------------------------------------------------------- frames -> processor patch layout
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def smart_resize(h: int, w: int, factor: int = 28, min_pixels: int = 4 * 28 * 28, max_pixels: int = 64 * 28 * 28) -> Tuple[int, int]:
+    """sides rounded to multiples of `factor`, area inside [min_pixels, max_pixels], aspect ratio kept (the Qwen2-VL processor's rule,
+    called through qwen_vl_utils at utils/UniMoE_Audio_mod.py:158-195 with the pixel budget of mod.py:49-53)"""
+    hb, wb = max(factor, round(h / factor) * factor), max(factor, round(w / factor) * factor)
+    if hb * wb > max_pixels:
+        beta = math.sqrt((h * w) / max_pixels)
+        hb, wb = max(factor, math.floor(h / beta / factor) * factor), max(factor, math.floor(w / beta / factor) * factor)
+    elif hb * wb < min_pixels:
+        beta = math.sqrt(min_pixels / (h * w))
+        hb, wb = math.ceil(h * beta / factor) * factor, math.ceil(w * beta / factor) * factor
+    return hb, wb
+
+
+def frames_to_patches(frames: torch.Tensor, patch: int = 14, tpatch: int = 2, merge: int = 2, max_pixels: int = 64 * 28 * 28,
+                      min_pixels: int = 4 * 28 * 28) -> Tuple[torch.Tensor, torch.Tensor]:
+    """[F, H, W, 3] or [F, 3, H, W] (uint8 or float in [0, 1]) -> (patches [grid_t * grid_h * grid_w, 3 * tpatch * patch^2] float32,
+    grid_thw [3]) in the processor's order: temporal pairs, merge x merge blocks of patches, then (channel, time, row, column) inside a
+    patch -- the layout the reference's patch embedding unflattens (utils.py:719-725).  PARITY UNPINNED for the resize filter (the
+    third-party processor needs torchvision / PIL, absent offline): bicubic with antialiasing via torch."""
+    x = frames
+    if x.shape[-1] == 3 and x.shape[1] != 3:
+        x = x.permute(0, 3, 1, 2)
+    x = x.float() / (255.0 if frames.dtype == torch.uint8 else 1.0)
+    F_, _, h, w = x.shape
+    hb, wb = smart_resize(h, w, patch * merge, min_pixels, max_pixels)
+    if (hb, wb) != (h, w):
+        x = torch.nn.functional.interpolate(x, size=(hb, wb), mode="bicubic", align_corners=False, antialias=True).clamp(0, 1)
+    mean, std = torch.tensor(CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    x = (x - mean.to(x.device)) / std.to(x.device)
+    if F_ % tpatch:
+        x = torch.cat([x, x[-1:].expand(tpatch - F_ % tpatch, -1, -1, -1)], 0)       # the last frame repeats to fill the temporal patch
+    gt, gh, gw = x.shape[0] // tpatch, hb // patch, wb // patch
+    x = x.reshape(gt, tpatch, 3, gh // merge, merge, patch, gw // merge, merge, patch)
+    x = x.permute(0, 3, 6, 4, 7, 2, 1, 5, 8)
+    return x.reshape(gt * gh * gw, 3 * tpatch * patch * patch).contiguous(), torch.tensor([gt, gh, gw])
