@@ -177,7 +177,15 @@ def roofline(cfg, info, args, ep=1):
     U = info["mean_experts_hit"]
     n_fix, n_real = cfg.mlp_fixed_expert_num, cfg.mlp_dynamic_expert_num
     ms, n = info["prof"]["gateup"]
-    if ep == 1:
+    fused = ep == 1 and info["prof"].get("down", (0.0, 0))[1] == 0      # no down-projection launch: the fused expert launch ran
+    if fused:
+        # gate + up + down weights of every routed expert hit and of the shared experts, bf16: both expert GEMMs of the
+        # layer are ONE launch (every workgroup: gate/up slice, publish, down slice)
+        bytes_per_launch = (U * 3 * Id * D + n_fix * 3 * Is * D) * 2.0
+        kname = "moe_fused_kernel"
+        what = (" (grouped gate/up SwiGLU + down projections of 8 routed + 2 shared experts in one launch; 16 of its tile-less "
+                "workgroups run the Top-P router and hand the normalised rows over)")
+    elif ep == 1:
         # gate+up weights of every routed expert hit + of the shared experts, bf16; activations / outputs < 0.3 %
         bytes_per_launch = (U * 2 * Id * D + n_fix * 2 * Is * D) * 2.0
         kname = "wstream_gemm<14, 1, 0, 2, 8, true>"
@@ -206,9 +214,10 @@ def roofline(cfg, info, args, ep=1):
         try:
             with open(PROFILE_REF) as f:
                 ref = json.load(f)
-            out["traffic"] = ref["traffic_bytes"]
-            out["traffic_source"] = ref["source"]
-            out["rocprof_kernel_us"] = ref["kernel_us"]
+            if ref.get("kernel", "wstream_gemm") .startswith(kname.split("<")[0]):     # (the reference must be of the kernel that ran)
+                out["traffic"] = ref["traffic_bytes"]
+                out["traffic_source"] = ref["source"]
+                out["rocprof_kernel_us"] = ref["kernel_us"]
         except Exception:
             pass
     return out

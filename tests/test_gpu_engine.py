@@ -436,9 +436,15 @@ def test_router_riding_in_the_gate_up_launch_is_bit_identical(dev, monkeypatch):
     ids, am, codec = prompt(cfg, B, T, 4, [1] + [0] * (2 * B - 1))
     pre, psteps = prepare_audio_prompt(cfg, [None] * B)
     outs = []
-    for fuse, mode in (("0", "0"), ("1", "1"), ("1", "0")):
+    # (fourth / fifth variant: the hand-off off; the gate/up workgroups normalising x1 themselves, umoe_engine.hip gu_norm)
+    # sixth: gate/up and down as two launches instead of the fused expert launch (umoe_moe_fused), which the default (third) uses
+    for fuse, mode, pub, gun, fm in (("0", "0", "1", "0", "1"), ("1", "1", "1", "0", "1"), ("1", "0", "1", "0", "1"), ("1", "0", "0", "0", "1"),
+                                     ("1", "0", "1", "1", "1"), ("1", "0", "1", "0", "0")):
+        monkeypatch.setenv("UMOE_FUSE_MOE", fm)
         monkeypatch.setenv("UMOE_FUSE_ROUTER", fuse)
         monkeypatch.setenv("UMOE_RIDER_MODE", mode)
+        monkeypatch.setenv("UMOE_RIDER_PUB", pub)
+        monkeypatch.setenv("UMOE_GU_NORM", gun)
         m, _ = build(cfg, 31, 0.03)
         m = m.to(dev)
         dec = DecoderOutput(pre.clone(), psteps, dev)

@@ -40,9 +40,9 @@ void umoe_set_error(const char* fmt, ...);
 static __device__ unsigned long long* g_tl;
 // time stamps stay in registers until the kernel's exit: nothing but s_memrealtime is added to the measured path
 struct tl_state { unsigned long long m[10]; };
-__device__ __forceinline__ void tl_exit(const tl_state& st, int kid) {
+__device__ __forceinline__ void tl_exit(const tl_state& st, int kid, unsigned long long t_exit = 0) {
     if (threadIdx.x != 0) return;
-    const unsigned long long t = wall_clock64();
+    const unsigned long long t = t_exit ? t_exit : wall_clock64();
     // layer = finished combine workgroups / workgroups per combine launch (second word, set by the harness)
     const int div = (int)g_tl[UMOE_TL_CTR + 1];
     int lay = (int)__atomic_load_n(&g_tl[UMOE_TL_CTR], __ATOMIC_RELAXED) / (div > 0 ? div : 1);
@@ -54,6 +54,19 @@ __device__ __forceinline__ void tl_exit(const tl_state& st, int kid) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
 #pragma unroll
         for (int k = 3; k < 10; ++k) g_tl[b + k] = st.m[k];
+    }
+    // per-workgroup dump of ONE kernel id in ONE layer (words 2 / 3 behind the counter: kernel id + 1, layer): entry, marks, exit,
+    // and where the workgroup ran (XCC_ID, HW_ID)
+    if ((int)g_tl[UMOE_TL_CTR + 2] == kid + 1 && (int)g_tl[UMOE_TL_CTR + 3] == lay) {
+        const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (wg < 1024) {
+            unsigned long long* d = g_tl + UMOE_TL_CTR + 8 + wg * 12;
+#pragma unroll
+            for (int k = 3; k < 10; ++k) d[k - 3] = st.m[k];
+            d[7] = t;
+            d[8] = ((unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
+            d[9] = 1;
+        }
     }
     if (kid == 9) atomicAdd(&g_tl[UMOE_TL_CTR], 1ull);
 }
@@ -204,6 +217,12 @@ struct umoe_rider_pub {
     int layer, layers;         // epoch = *step * layers + layer + 1
     uint32_t* err;             // device word, sticky: 2 = a workgroup gave up waiting for the riders
 };
+
+// The two expert GEMMs of a dense decode layer (gate/up SwiGLU with riders + rider_pub, then the down projections) in ONE launch
+// (umoe_gemm.hip moe_fused_kernel; decode engine only).  `gu` as for umoe_grouped_gemm with nt 14, fused_router and rider_pub; `dn`
+// with nt 6, dn->a == gu->out; `flags`: device words, one per gate/up workgroup of the launch box (>= num_groups * ceil(max pairs / 7)).
+// Returns 1 (nothing launched) when the shapes do not allow the fusion: the caller then issues the two launches.
+int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* flags, int flag_words, hipStream_t s);
 
 // ---- weight-streaming GEMM over several 16-row tiles per weight pass (umoe_gemm_mt.hip; expert parallel decode) --------
 #define UMOE_MT_MAXG 4

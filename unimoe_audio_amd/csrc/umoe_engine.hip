@@ -79,6 +79,8 @@ struct umoe_engine {
     // lists, no dispatch kernel, no device-produced row counts in the GEMM prologues) and the combine selects by mask
     bool dense_experts = true;
     bool fuse_router = true;     // UMOE_FUSE_ROUTER: dense decode runs the router inside the gate/up launch (see run_layer)
+    bool fuse_moe = true;        // UMOE_FUSE_MOE: gate/up and down projections of a dense decode layer in ONE launch (umoe_moe_fused)
+    bool gu_norm = false;        // UMOE_GU_NORM: the gate/up workgroups normalise x1 in their staging prologue (no hand-off, no norm launch)
     bool rider_pub = true;       // UMOE_RIDER_PUB: the riders also produce the normalised rows and hand them to the GEMM workgroups of the
                                  // same launch (umoe_gemm_args.rider_pub): no RMSNorm launch in front of gate/up
     bool attn_single = false;    // UMOE_ATTN_SINGLE: decode attention merges its key splits in the same launch (umoe_attn_args.sync);
@@ -297,7 +299,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
         return -2;
     }
     // [0] decode steps taken, [1] sticky hand-off error, [16..32) row flags of the rider hand-off (umoe_gemm_args.rider_pub)
-    if (hipMalloc(&e->ep_words, 256) != hipSuccess || hipMemset(e->ep_words, 0, 256) != hipSuccess) {
+    if (hipMalloc(&e->ep_words, 4096) != hipSuccess || hipMemset(e->ep_words, 0, 4096) != hipSuccess) {
         umoe_set_error("umoe_engine_create: hipMalloc failed (state words)");
         umoe_engine_destroy(e);
         return -2;
@@ -332,6 +334,8 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (const char* v = getenv("UMOE_ATTN_SINGLE")) e->attn_single = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_ROUTER")) e->fuse_router = atoi(v) != 0;
     if (const char* v = getenv("UMOE_RIDER_PUB")) e->rider_pub = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_GU_NORM")) e->gu_norm = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_FUSE_MOE")) e->fuse_moe = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -766,8 +770,14 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // chain as its own small launch: the 4.4 us serial routing chain per token leaves the critical path.
     const bool fuse_router = dense && e->fuse_router && !tiled && !(e->overlap_shared && c.n_fix > 0) && c.n_dyn == 9 && c.n_fix == 2 &&
                              (D == 2048 || D == 4096) && n_tok <= 16 && !(e->flat_wgs > 0);
-    const bool pub_riders = fuse_router && e->rider_pub;
-    if (pub_riders) {
+    // gu_norm: the gate/up workgroups normalise x1 themselves in their staging prologue (the router body's summation tree: the same
+    // bits), so that launch waits for nobody -- no norm launch, no hand-off
+    const bool gu_norm = fuse_router && e->gu_norm && D == 2048;
+    const bool pub_riders = fuse_router && e->rider_pub && !gu_norm;
+    if (gu_norm) {
+        rc = 0;
+        ra.h_out = nullptr;
+    } else if (pub_riders) {
         rc = 0;                  // no launch here: the riders write h2 inside the gate/up launch and hand it over (ra.h_out stays h2)
     } else if (fuse_router) {
         umoe_router_args rn = ra;
@@ -795,6 +805,10 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     if (dense) {             // per-CU byte balance decides this kernel (see umoe_gemm.hip): 7 pairs per workgroup, flat slices
         gu.nt = 14;
         if (fuse_router) gu.fused_router = &ra;
+        if (gu_norm) {
+            gu.a = e->x1; gu.norm_w = L.w.post_norm; gu.rms_eps = c.rms_eps; gu.prologue = UMOE_PRO_RMSNORM;
+            gu.groups_host = e->h_gu_pub.data() + (size_t)l * G;     // (same order as the hand-off variant: shared experts first)
+        }
         if (pub_riders) {
             gu.rider_pub = &rpub;
             gu.groups_host = e->h_gu_pub.data() + (size_t)l * G;     // shared experts first (riders early in dispatch order)
@@ -820,11 +834,11 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         ta.groups = tg; ta.num_groups = G; ta.max_rows = n_tok; ta.a = e->h2; ta.lda = D; ta.out = e->hbuf; ta.ldo = Imax;
         ta.epilogue = UMOE_EPI_SWIGLU;
         rc = umoe_tiled_gemm(&ta, s);
-    } else {
+    } else if (!(pub_riders && e->fuse_moe)) {
         rc = umoe_grouped_gemm(&gu, s);
     }
     if (rc) return rc;
-    PROF(K_GATEUP);
+    if (!(pub_riders && e->fuse_moe)) PROF(K_GATEUP);
     umoe_gemm_args dn{};
     dn.groups = g + 2 + G; dn.groups_host = gh + 2 + G; dn.num_groups = ov ? c.n_real : G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16;
     dn.max_k = ov ? c.inter_dyn : Imax;
@@ -846,11 +860,23 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         ta.groups = tg; ta.num_groups = G; ta.max_rows = n_tok; ta.a = e->hbuf; ta.lda = Imax; ta.out = e->ybuf; ta.ldo = D;
         ta.epilogue = UMOE_EPI_BF16;
         rc = umoe_tiled_gemm(&ta, s);
+        if (rc) return rc;
+        PROF(K_DOWN);
+    } else if (pub_riders && e->fuse_moe) {
+        // both expert GEMMs in one launch (words 64.. of ep_words: one flag per gate/up workgroup); shapes that do not allow it
+        // fall back to the two launches
+        rc = umoe_moe_fused(&gu, &dn, e->ep_words + 64, 1024 - 64, s);
+        if (rc == 1) {
+            if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
+            rc = umoe_grouped_gemm(&dn, s);
+        }
+        if (rc) return rc;
+        PROF(K_GATEUP);          // (the fused launch is booked as gate/up: zero down launches tell the reader which form ran)
     } else {
         rc = umoe_grouped_gemm(&dn, s);
+        if (rc) return rc;
+        PROF(K_DOWN);
     }
-    if (rc) return rc;
-    PROF(K_DOWN);
     if (ov) UMOE_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
     // 9. combine + residual -> next layer input                   core.py:488,342-351; model.py:242
     umoe_combine_args cb{};

@@ -79,10 +79,23 @@ struct umoe_group_pack { umoe_group_t g[UMOE_GROUPS_INLINE]; };
 // PUB (umoe_gemm_args.rider_pub, with FR): the riders also WRITE the normalised rows this GEMM stages (ra.h_out == p.a) and publish
 // one flag per row; the GEMM workgroups request their first weight chunk, then wait for the 16 flags (one lane each, bounded), then
 // stage the rows with sc1 loads -- the hand-off hides behind the weight stream's first round trip and the RMSNorm launch disappears.
-template <int NT, int U, int PRO, int EPI, int WV, bool FR = false, bool PUB = false>
-__global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_router_args ra, const int rider_mode,
-                                                            const umoe_rider_pub pub) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// XW (fused expert launch, moe_fused_kernel below): 1 = this GEMM PUBLISHES its output tile to workgroups of the same launch (SwiGLU
+// epilogue: write-through stores, drain, one flag per workgroup); 2 = this GEMM's activation rows were published that way (weights
+// first, then wait for the producers' flags, then sc1 loads; the second register stage of the weight stream is requested right
+// behind the rows).  Returns 0 when the workgroup finished a tile, 1 when it had none (riders, tile-less workgroups of the box).
+struct wg_coord { unsigned x, y, z, gx; };     // workgroup coordinates inside this GEMM's grid box and the box's x extent
+struct umoe_fuse_x {
+    uint32_t* flags;                        // one word per workgroup of the PRODUCING GEMM (z * gx + x); epochs as in umoe_rider_pub
+    int prod_base[UMOE_GROUPS_INLINE];      // per group of the CONSUMING GEMM: first flag and number of flags it waits for
+    int prod_n[UMOE_GROUPS_INLINE];
+};
+template <int NT, int U, int PRO, int EPI, int WV, bool FR, bool PUB, int XW>
+__device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_group_pack& gp, const umoe_router_args& ra, const int rider_mode,
+                                            const umoe_rider_pub& pub, const umoe_fuse_x& fx, const wg_coord blk, char* smem
+#ifdef UMOE_TIMELINE
+                                            , tl_state* tl_carry = nullptr      // XW 1: the stamps leave with the caller, written after the second GEMM
+#endif
+) {
     // riders (FR).  rider_mode 1: an extra z-slice in front of the first group (x = token); 2: the launch's DEAD workgroups (x beyond
     // a short group's tiles -- the grid is a box over the widest group) take the tokens in (z, x) order: no extra workgroups, the
     // launch still fits the chip in one wave (with the extra slice 275 workgroups were launched on 256 CUs and 7 real GEMM tiles
@@ -90,16 +103,16 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     if constexpr (FR) {
         int token = -1;
         if (rider_mode == 1) {
-            if (blockIdx.z == 0) token = (int)blockIdx.x;
+            if (blk.z == 0) token = (int)blk.x;
         } else {
-            const int live = (gp.g[blockIdx.z].n_blocks + NT - 1) / NT;
-            if ((int)blockIdx.x >= live) {
-                token = (int)blockIdx.x - live;
-                for (unsigned i = 0; i < blockIdx.z; ++i) token += (int)gridDim.x - (gp.g[i].n_blocks + NT - 1) / NT;
+            const int live = (gp.g[blk.z].n_blocks + NT - 1) / NT;
+            if ((int)blk.x >= live) {
+                token = (int)blk.x - live;
+                for (unsigned i = 0; i < blk.z; ++i) token += (int)blk.gx - (gp.g[i].n_blocks + NT - 1) / NT;
             }
         }
         if (token >= 0) {
-            if (token < ra.S && blockIdx.y == 0 && threadIdx.x < 256) {
+            if (token < ra.S && blk.y == 0 && threadIdx.x < 256) {
                 TL_ENTER(5);
                 uint32_t* pf = nullptr;
                 uint32_t pe = 0;
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
                 else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS, pf, pe);
                 TL_EXIT(5);
             }
-            return;
+            return 1;
         }
     }
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -123,20 +136,20 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     // p.flat_wgs equal slices of ALL groups' gate/up pairs, so every CU streams the same number of bytes whatever the
     // group sizes are (the per-CU byte balance decides this kernel, see the launcher).  A slice may straddle two groups.
     const bool flat = EPI == UMOE_EPI_SWIGLU && p.flat_wgs > 0;
-    const unsigned zg = blockIdx.z - ((FR && rider_mode == 1) ? 1u : 0u);      // group index
+    const unsigned zg = blk.z - ((FR && rider_mode == 1) ? 1u : 0u);      // group index
     const umoe_group_t g = p.groups_host ? gp.g[flat ? 0 : zg] : p.groups[zg];
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-    const int ks = blockIdx.x % ksplit;      // K-slice of this workgroup (fp32 partial slab `ks`)
-    const int nb0 = (blockIdx.x / ksplit) * NT;
+    const int ks = ksplit > 1 ? (int)(blk.x % ksplit) : 0;      // K-slice of this workgroup (fp32 partial slab `ks`)
+    const int nb0 = (ksplit > 1 ? (int)(blk.x / ksplit) : (int)blk.x) * NT;
     int fp0 = 0, fnp = 0;                    // flat: first global pair and number of pairs of this workgroup
     if (flat) {
         int P = 0;
         for (int i = 0; i < p.num_groups; ++i) P += gp.g[i].n_blocks >> 1;
-        fp0 = (int)(((long)blockIdx.x * P) / p.flat_wgs);
-        fnp = (int)(((long)(blockIdx.x + 1) * P) / p.flat_wgs) - fp0;
-        if (fnp <= 0) return;
+        fp0 = (int)(((long)blk.x * P) / p.flat_wgs);
+        fnp = (int)(((long)(blk.x + 1) * P) / p.flat_wgs) - fp0;
+        if (fnp <= 0) return 1;
     } else if (nb0 >= g.n_blocks) {
-        return;
+        return 1;
     }
     // flat: global pair -> (group, pair inside the group)
     auto locate = [&](int pp, int& grp, int& lp) {
@@ -206,17 +219,39 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     //    requested FIRST, the weight stream right behind them -- the tile is staged while the first chunk is in flight;
     //  * ragged groups: the activation addresses hang on device-produced tables (count -> offset -> gather list), so the
     //    weight stream goes first and overlaps that chain.
-    const bool ragged = PUB || g.count || g.row_off || g.rows;   // (PUB: weights first too -- the rows do not exist yet)
+    const bool ragged = PUB || XW == 2 || g.count || g.row_off || g.rows;   // (PUB / XW 2: weights first too -- the rows do not exist yet)
     // second register stage requested before the staging too (static groups): HBM has work queued for the whole prologue.
     // Only where the registers allow it without spilling (checked per instantiation with -S: private_segment_fixed_size 0).
     constexpr bool DEEP = false;   // measured: gate/up NT 14 35.3 -> 42.6 us, down 23.8 -> 29.8 us -- MORE bytes in flight made it slower
     if (ragged && i0 < i1) load_chunk(w0, i0);
+    // (XW 2: measured on the fused expert launch, 300 decode steps: second register stage requested here, in front of the wait for
+    //  the producers, 3.26-3.29 ms/step; right behind the rows 3.26-3.28; a THIRD stage in front of the wait 3.40-3.43 -- more bytes
+    //  in flight per CU made the launch slower, as in the two-launch form)
     TL_MARK(KID, 4);
 
     const int count = g.count ? *g.count : g.static_count;
     const int roff = g.row_off ? *g.row_off : 0;
-    const int row0 = blockIdx.y * 16;
-    if (row0 >= count) return;   // (an expert no row chose: its first chunk was requested for nothing -- rare at 16 rows)
+    const int row0 = blk.y * 16;
+    if (row0 >= count) return 1;   // (an expert no row chose: its first chunk was requested for nothing -- rare at 16 rows)
+    if constexpr (XW == 2) {
+        // wait for the workgroups of THIS launch that produced this group's rows: lane i of wave 0 polls producer i's flag (bounded)
+        const int np = fx.prod_n[zg];
+        if (tid < np) {
+            const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
+            umoe_gu32* f = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(fx.flags + fx.prod_base[zg] + tid));
+            umoe_gu32* err = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.err));
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned spins = 0;; ++spins) {
+                if ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 1023u) == 1023u && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 200000000ull)) {
+                    __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
     if constexpr (PUB) {
         // wait for the riders of THIS launch: lanes 0..count-1 of wave 0 poll one row flag each; bounded (a rider that never runs --
         // an admitted workgroup that is not resident -- ends the wait with the sticky error word set)
@@ -244,8 +279,12 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
         const int r = row0 + m;
         const bool valid = r < count;   // rows beyond the count stay unwritten: a token is one MFMA column, garbage
                                         // there never reaches another token's outputs and is never stored
-        long arow = 0;
-        if (valid) arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
+        // EVERY thread loads (threads of rows beyond the count re-read the tile's first row, chunks beyond the slice its last chunk):
+        // straight-line loads the compiler can count, so the LDS writes wait for the rows only (vmcnt(n)) while the weight chunk
+        // requested behind them is still in flight.  With a branch around each load the wait was vmcnt(0) -- the staging ended when
+        // the WEIGHTS had landed (scripts/timeline_wgs.py: loads issued over 1.0 us, tile staged 2.7 us after the first request).
+        const int rl = valid ? r : row0;
+        const long arow = g.rows ? (long)g.rows[roff + rl] : (long)(g.a_row_base + roff + rl);
         const uint16_t* src = p.a + arow * (long)p.lda + g.a_col_off;
         char* dst = smem + m * RS;
         const int Q8 = KB;       // 16-byte chunks per quarter of the full row
@@ -275,17 +314,14 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
             if (single && tid < 4 * Q8) nw1 = ld16(p.norm_w + tid * 8);
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
-                const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
-                buf[n] = make_uint4(0, 0, 0, 0);
-                if (valid && i < QW) {
-                    if constexpr (PUB) {   // rows handed over inside this launch: every load of them is an sc1 load
-                        typedef uint32_t u32x4_pub __attribute__((ext_vector_type(4)));
-                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, 16 * p.lda * 2, 0x00020000);
-                        const u32x4_pub t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((arow * (long)p.lda + g.a_col_off + (h * Q8 + ia + i) * 8) * 2), 0, 16);
-                        buf[n] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                    } else {
-                        buf[n] = ld16(src + (h * Q8 + ia + i) * 8);
-                    }
+                const int h = n >> 2, i = min(ib0 + sub + TPR * (n & 3), QW - 1);
+                if constexpr (PUB || XW == 2) {   // rows handed over inside this launch: every load of them is an sc1 load
+                    typedef uint32_t u32x4_pub __attribute__((ext_vector_type(4)));
+                    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, XW == 2 ? 0x7fffffff : 16 * p.lda * 2, 0x00020000);
+                    const u32x4_pub t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((arow * (long)p.lda + g.a_col_off + (h * Q8 + ia + i) * 8) * 2), 0, 16);
+                    buf[n] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                } else {
+                    buf[n] = ld16(src + (h * Q8 + ia + i) * 8);
                 }
             }
             if (ib0 == 0 && !ragged) {
@@ -294,17 +330,51 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
                 if (DEEP && i0 + U < i1) load_chunk(w1, i0 + U);   // both register stages in flight while the tile is staged
                 __builtin_amdgcn_sched_barrier(0);
             }
+
+            if (XW == 2 && ib0 == 0) {     // the second register stage right behind the rows (returns: first stage, rows, second stage)
+                __builtin_amdgcn_sched_barrier(0);
+                if (i0 + U < i1) load_chunk(w1, i0 + U);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            TL_MARK(KID, 9);
             if (single) {
                 float ss = 0.f;
+                if (TPR == 32 && Q8 == 64) {
+                    // K = 2048 on 8 waves: the SAME summation tree as the router body (umoe_router_dev.h router4_body: lane l of wave h
+                    // sums the 8 squares of chunk 64 h + l, xor-butterfly 32, 16, .. 1, the four wave sums added in order) -- thread
+                    // `sub` holds chunks sub and sub + 32 of every quarter, i.e. both operands of the butterfly's first level.  The
+                    // normalised rows are then bit-identical to the rows the router launches write, whichever launch made them.
+                    float q4[4];
 #pragma unroll
-                for (int n = 0; n < 16; ++n) {
-                    float f[8];
-                    unpack8(buf[n], f);
+                    for (int hq4 = 0; hq4 < 4; ++hq4) {
+                        float c2[2];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            float f[8];
+                            unpack8(buf[hq4 * 4 + k2], f);
+                            float cs = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) cs += f[j] * f[j];
+                            c2[k2] = cs;
+                        }
+                        float v = c2[0] + c2[1];
+#pragma unroll
+                        for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+                        q4[hq4] = v;
+                    }
+                    ss = ((q4[0] + q4[1]) + q4[2]) + q4[3];
+                } else {
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) {
+                        float f[8];
+                        unpack8(buf[n], f);
+                        const bool own = ib0 + sub + TPR * (n & 3) < QW;     // (a clamped re-read beyond the slice does not count)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ss += own ? f[j] * f[j] : 0.f;
+                    }
+#pragma unroll
+                    for (int o = TPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
                 }
-#pragma unroll
-                for (int o = TPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
                 rs = rsqrtf(ss / (float)K + p.rms_eps);
                 if (tid < 4 * Q8) st16(nw_lds + tid * 16, nw1);
                 __syncthreads();
@@ -361,6 +431,21 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     const int h = lane >> 4, mm = lane & 15;
     const char* bbase = smem + mm * RS;
     auto compute_chunk = [&](const u32x4_t (&src)[NT][U], int ibase) {
+        if (U >= 4 && ibase + U <= i1) {
+            // whole chunk (scalar condition): every fragment read is issued before the first MFMA.  With the per-step guard below each
+            // ds_read waited for its own round trip in front of its MFMA: 16 steps took 0.92 us in the QKV / o_proj launches
+            uint4 bv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) bv[u] = *reinterpret_cast<const uint4*>(bbase + lds_chunk_off(QS, h, ibase + u - ia, mm));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, bv[u]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, src[t][u]), bfrag, acc[t], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ii = ibase + u;
@@ -375,7 +460,7 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
         }
     };
     for (int i = i0; i < i1; i += 2 * U) {
-        if (i + U < i1 && !(DEEP && !ragged && i == i0)) load_chunk(w1, i + U);
+        if (i + U < i1 && !(((DEEP && !ragged) || XW == 2) && i == i0)) load_chunk(w1, i + U);
         compute_chunk(w0, i);
         if (i + 2 * U < i1) load_chunk(w0, i + 2 * U);
         if (i + U < i1) compute_chunk(w1, i + U);
@@ -401,7 +486,7 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
 
     // ---- epilogue: lane (h, mm) owns features 4h..4h+3 of token row mm; tiles are spread over the waves -----
     const int r = row0 + mm;
-    if (r >= count) return;
+    if (XW != 1 && r >= count) return 0;
     const long orow = (long)g.out_row_base + roff + r;
     if (EPI == UMOE_EPI_SWIGLU) {
         for (int q = wave; q < NT / 2; q += WV) {
@@ -427,10 +512,30 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
                 y[j] = f2bf(si * up);
             }
             uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + orow_q * p.ldo + col;
-            *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
+            if constexpr (XW == 1) {     // handed to workgroups of this launch: write-through (sc1) store
+                typedef uint32_t u32x2_pub __attribute__((ext_vector_type(2)));
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint16_t*>(p.out), 0, 0x7fffffff, 0x00020000);
+                const u32x2_pub v2 = {(uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16)};
+                if (r < count) __builtin_amdgcn_raw_buffer_store_b64(v2, rsrc, (int)((orow_q * p.ldo + col) * 2), 0, 16);
+            } else {
+                *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16));
+            }
         }
+        if constexpr (XW == 1) {
+            // publish: every storing wave drains its write-through stores, the workgroup meets, one lane raises this workgroup's flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
+                __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(fx.flags + blk.z * blk.gx + blk.x)), epoch, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+#ifdef UMOE_TIMELINE
+        if (XW == 1 && tl_carry) { tl_st.m[2] = wall_clock64(); *tl_carry = tl_st; return 0; }
+#endif
         TL_EXIT(KID);
-        return;
+        return 0;
     }
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
@@ -473,6 +578,45 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
         }
     }
     TL_EXIT(KID);
+    return 0;
+}
+
+template <int NT, int U, int PRO, int EPI, int WV, bool FR = false, bool PUB = false>
+__global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_router_args ra, const int rider_mode,
+                                                            const umoe_rider_pub pub) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const umoe_fuse_x fx{};
+    (void)wstream_body<NT, U, PRO, EPI, WV, FR, PUB, 0>(p, gp, ra, rider_mode, pub, fx, wg_coord{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x}, smem);
+}
+
+// The two expert GEMMs of a dense decode layer in ONE launch (8 routed + 2 shared experts, 16 rows): every workgroup computes its
+// gate/up slice (7 pairs, riders and their hand-off as in the gate/up launch), publishes it, then takes a down-projection slice (6
+// blocks): it requests that slice's first weights, waits for the gate/up workgroups of ITS expert only, stages the rows and streams.
+// What the fusion buys: no launch boundary, and the down projection's weight stream starts while other workgroups still finish
+// gate/up -- as two launches the chip idled through the down projection's 7 us prologue.  Same tiles, same K split, same reduction
+// order as the two launches: bit-identical outputs.
+__global__ __launch_bounds__(512, 1) void moe_fused_kernel(const umoe_gemm_args pg, const umoe_group_pack gg, const umoe_gemm_args pd, const umoe_group_pack gd,
+                                                            const umoe_router_args ra, const int rider_mode, const umoe_rider_pub pub, const umoe_fuse_x fx,
+                                                            const int dn_per_group) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const wg_coord b{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x};
+#ifdef UMOE_TIMELINE
+    tl_state tl_first;
+    if (wstream_body<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8, true, true, 1>(pg, gg, ra, rider_mode, pub, fx, b, smem, &tl_first)) return;
+#else
+    if (wstream_body<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8, true, true, 1>(pg, gg, ra, rider_mode, pub, fx, b, smem)) return;
+#endif
+    // live index of this workgroup among the gate/up tiles -> its down-projection slice
+    int li = (int)b.x;
+    for (unsigned i = 0; i < b.z; ++i) li += (gg.g[i].n_blocks + 13) / 14;
+    const unsigned dz = (unsigned)(li / dn_per_group), dx = (unsigned)(li % dn_per_group);
+    if ((int)dz < pd.num_groups) {
+        __syncthreads();     // (the reduction slab of the first GEMM is the staging area of the second)
+        (void)wstream_body<6, 2, UMOE_PRO_PLAIN, UMOE_EPI_BF16, 8, false, false, 2>(pd, gd, ra, 0, pub, fx, wg_coord{dx, 0u, dz, (unsigned)dn_per_group}, smem);
+    }
+#ifdef UMOE_TIMELINE
+    tl_exit(tl_first, 2, tl_first.m[2]);
+#endif
 }
 
 UMOE_TL_SETTER(gemm)
@@ -534,6 +678,61 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
     return 0;
 }
 
+int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* flags, int flag_words, hipStream_t s) {
+    UMOE_REQUIRE(gu && dn && flags, "umoe_moe_fused: null argument");
+    const int G = gu->num_groups;
+    if (!(gu->fused_router && gu->rider_pub && gu->groups_host && dn->groups_host && G == dn->num_groups && G <= UMOE_GROUPS_INLINE && gu->nt == 14 &&
+          dn->nt == 6 && gu->prologue == UMOE_PRO_PLAIN && gu->epilogue == UMOE_EPI_SWIGLU && dn->prologue == UMOE_PRO_PLAIN &&
+          dn->epilogue == UMOE_EPI_BF16 && gu->flat_wgs == 0 && gu->ksplit <= 1 && dn->ksplit <= 1 && gu->max_rows <= 16 && dn->max_rows <= 16 &&
+          dn->a == gu->out && dn->lda == gu->ldo && !dn->fused_router && gu->max_k % 32 == 0 && dn->max_k % 32 == 0))
+        return 1;
+    const umoe_router_args* r = gu->fused_router;
+    const int gx = ceil_div(gu->max_n_blocks, 14), per = ceil_div(dn->max_n_blocks, 6);
+    int live = 0, dead = 0;
+    for (int i = 0; i < G; ++i) {
+        const umoe_group_t& a = gu->groups_host[i];
+        const umoe_group_t& b = dn->groups_host[i];
+        if (a.rows || a.count || a.row_off || a.a_row_base || a.a_col_off || a.static_count != r->S || b.rows || b.count || b.row_off || b.a_col_off ||
+            b.static_count != r->S || b.bias || a.bias)
+            return 1;
+        live += ceil_div(a.n_blocks, 14);
+        dead += gx - ceil_div(a.n_blocks, 14);
+    }
+    if (dead < r->S || live < G * per || G * gx > flag_words) return 1;
+    if (!(r->S <= 16 && r->n_dyn == 9 && r->n_fix == 2 && (r->D == 2048 || r->D == 4096) && r->x && r->gate_w && r->expert_mask && !r->logits_in &&
+          !r->norm_only && r->h_out == gu->a && r->norm_w))
+        return 1;
+    umoe_fuse_x fx;
+    memset(&fx, 0, sizeof(fx));
+    fx.flags = flags;
+    for (int i = 0; i < G; ++i) {      // the gate/up group whose output rows this down group reads
+        const umoe_group_t& b = dn->groups_host[i];
+        int j = -1;
+        for (int t = 0; t < G; ++t)
+            if (gu->groups_host[t].out_row_base == b.a_row_base) j = t;
+        if (j < 0 || gu->groups_host[j].n_blocks * 8 != b.k || ceil_div(gu->groups_host[j].n_blocks, 14) > 64) return 1;
+        fx.prod_base[i] = j * gx;
+        fx.prod_n[i] = ceil_div(gu->groups_host[j].n_blocks, 14);
+    }
+    const size_t l1 = gemm_lds_bytes(gu->max_k, 14, 8, 1), l2 = gemm_lds_bytes(dn->max_k, 6, 8, 1), lds = l1 > l2 ? l1 : l2;
+    if (lds > 160 * 1024) return 1;
+    static size_t configured = 0;
+    if (lds > configured) {
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    umoe_group_pack gg, gd;
+    memset(&gg, 0, sizeof(gg));
+    memset(&gd, 0, sizeof(gd));
+    memcpy(gg.g, gu->groups_host, sizeof(umoe_group_t) * G);
+    memcpy(gd.g, dn->groups_host, sizeof(umoe_group_t) * G);
+    const umoe_rider_pub pub = *reinterpret_cast<const umoe_rider_pub*>(gu->rider_pub);
+    UMOE_REQUIRE(pub.flags && pub.step && pub.err, "umoe_moe_fused: rider_pub needs flags / step / err");
+    moe_fused_kernel<<<dim3((unsigned)gx, 1, (unsigned)G), 512, lds, s>>>(*gu, gg, *dn, gd, *r, /*rider_mode*/ 2, pub, fx, per);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
 // 8 waves per workgroup when the staging tile leaves room for only one workgroup per CU (measured: +6 % on K=2752)
 static bool use8(const umoe_gemm_args* a, int nt) {
     if (a->waves) return a->waves == 8;
@@ -584,8 +783,9 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
     UMOE_REQUIRE((a->lda & 7) == 0, "umoe_grouped_gemm: lda must be a multiple of 8 (16-byte rows)");
     UMOE_REQUIRE(a->ksplit <= 1 || (a->epilogue == UMOE_EPI_F32_RAW && a->prologue == UMOE_PRO_PLAIN && a->ksplit <= 4),
                  "umoe_grouped_gemm: ksplit > 1 needs the plain prologue and the raw fp32 partial-slab epilogue");
-    UMOE_REQUIRE(!a->fused_router || (a->epilogue == UMOE_EPI_SWIGLU && a->prologue == UMOE_PRO_PLAIN && a->nt == 14 && a->flat_wgs == 0),
-                 "umoe_grouped_gemm: fused_router rides only in the plain SwiGLU launch with nt = 14");
+    UMOE_REQUIRE(!a->fused_router || (a->epilogue == UMOE_EPI_SWIGLU && a->nt == 14 && a->flat_wgs == 0 &&
+                                      (a->prologue == UMOE_PRO_PLAIN || (a->prologue == UMOE_PRO_RMSNORM && !a->rider_pub && a->max_k == 2048))),
+                 "umoe_grouped_gemm: fused_router rides only in the SwiGLU launch with nt = 14 (RMSNorm prologue: K 2048, no rider_pub)");
     hipStream_t s = (hipStream_t)stream;
     const int pro = a->prologue, epi = a->epilogue;
     if (pro == UMOE_PRO_RMSNORM) {
@@ -595,6 +795,20 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
         if (epi == UMOE_EPI_F32) return launch_gemm_nt<UMOE_PRO_RMSNORM, UMOE_EPI_F32>(a, nt, s);
         if (epi == UMOE_EPI_SWIGLU) {  // shared experts straight from the residual stream (norm fused in the staging)
             UMOE_REQUIRE(a->max_n_blocks % 2 == 0, "umoe_grouped_gemm: SwiGLU needs gate/up block pairs");
+            if (a->nt == 14) {
+                // dense decode, the post-attention norm in THIS launch's staging prologue (no rider hand-off, no norm launch): every
+                // workgroup normalises the 16 rows it stages, with the router body's summation tree (bit-identical rows)
+                UMOE_REQUIRE(a->max_k == 2048 && a->max_rows <= 16 && a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE,
+                             "umoe_grouped_gemm: the 14-block RMSNorm SwiGLU launch needs K 2048, <= 16 rows, host descriptors");
+                if (a->fused_router) {
+                    const umoe_router_args* r = a->fused_router;
+                    UMOE_REQUIRE(r->S <= ceil_div(a->max_n_blocks, 14) && r->n_dyn == 9 && r->n_fix == 2 && r->D == 2048 && r->x && r->gate_w &&
+                                     r->expert_mask && !r->logits_in && !r->norm_only,
+                                 "umoe_grouped_gemm: fused_router needs <= 16 rows, n_dyn 9 / n_fix 2, D 2048");
+                    return launch_gemm<14, 1, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU, 8, true>(a, s);
+                }
+                return launch_gemm<14, 1, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU, 8>(a, s);
+            }
             const int ns = auto_nt(a, true);
             if (ns <= 2) return launch_gemm<2, 8, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU>(a, s);
             if (ns == 4) return launch_gemm<4, 4, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU>(a, s);

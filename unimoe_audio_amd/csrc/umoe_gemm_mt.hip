@@ -27,8 +27,10 @@ __global__ __launch_bounds__(512, 1) void wstream_mt(const umoe_mt_args p, const
         if (blockIdx.z == gridDim.z - 1) {     // riders: one workgroup per token, threads 0..255 (umoe_router_dev.h)
             const int token = (int)blockIdx.x;
             if (token < ra.S && threadIdx.x < 256) {
-                if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem));
-                else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem));
+                TL_ENTER(5);
+                if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
+                else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS);
+                TL_EXIT(5);
             }
             return;
         }

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void router_norm_push_kernel(const umoe_router
     __shared__ float lds[4 + 4 * UMOE_MAXE];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    router4_body<9, 2, 1, true>(a, s, tid, lds);
+    TL_ENTER(5);
+    router4_body<9, 2, 1, true>(a, s, tid, lds TL_PASS);
     const int nch = a.D >> 11;
     const uint32_t epoch = umoe_ep_epoch(x);
     u32x4 v[2];
