@@ -70,7 +70,7 @@ extern "C" int umoe_rmsnorm_residual_fwd(const uint16_t* x, const uint16_t* r, c
 // EP (expert parallel decode, dense layout): y_slots is this rank's RETURN slab (uncached region memory); the rows of expert e
 // arrive from rank e / E_loc (second all-to-all, core.py:480): lane e of wave 0 waits for that rank's flag of THIS token row,
 // the workgroup meets at its barrier, and every load of the slab is a system-scope (sc0 sc1) load (hand-off form: umoe_common.h).
-template <bool EP>
+template <bool EP, bool DENSE = EP>     // DENSE: the dense layout (no slot table, no partial slabs) known at compile time
 __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a, const umoe_ep_xfer x) {
     __shared__ float sh[4];
     TL_ENTER(9);
@@ -100,20 +100,34 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a,
     // rows and the residual are requested together; the accumulation order below is the reference's
     int slot[UMOE_MAXE];
     float wgt[UMOE_MAXE], swgt[UMOE_MAXE];
-    const bool fastp = !a.y_parts && a.n_real <= UMOE_MAXE && a.n_fix <= 4;
+    const bool fastp = DENSE || (!a.y_parts && a.n_real <= UMOE_MAXE && a.n_fix <= 4);
+    // dense layout (every expert computed every row): the row of expert e is e * dense_rows + s whatever the mask says, so the rows are
+    // requested TOGETHER with the tables (one round trip, not two) and the mask only decides which of them are added
+    const bool dense_rows_known = DENSE;
+    int slot_l = -1, tab_v = 0;      // lane e <- table entry e (raw value: consumed in broadcast_tables, not before)
+    float wgt_l = 0.f, sw_l = 0.f;
     if (fastp) {
         // one vector load per table (lane e <- entry e), then broadcast: a single memory round trip instead of a chain
         // of dependent scalar loads
         const int lane = threadIdx.x & 63;
-        int slot_l = -1;
-        float wgt_l = 0.f, sw_l = 0.f;
-        if (lane < a.n_real) wgt_l = a.moe_w[(size_t)s * a.n_real + lane];
-        if (a.y_shared && lane < a.n_fix) sw_l = a.global_w[(size_t)s * E + a.n_dyn + lane];
-        if (lane < a.n_real) {   // both table flavours are ONE int per (token, expert): same load, different meaning
-            const int32_t* tab = a.slot_of ? a.slot_of + (size_t)s * a.n_real : a.expert_mask + (size_t)s * a.mask_ld;
-            const int v = tab[lane];
-            slot_l = a.slot_of ? v : (v != 0 ? lane * a.dense_rows + s : -1);
+        if (DENSE) {
+            // straight-line, clamped (lanes beyond the tables re-read their last entry; never used): no branch around a load, so the
+            // compiler does not drain the queue in front of the row requests
+            wgt_l = a.moe_w[(size_t)s * a.n_real + min(lane, a.n_real - 1)];
+            sw_l = a.global_w[(size_t)s * E + a.n_dyn + min(lane, a.n_fix - 1)];
+            tab_v = a.expert_mask[(size_t)s * a.mask_ld + min(lane, a.n_real - 1)];
+        } else {
+            if (lane < a.n_real) wgt_l = a.moe_w[(size_t)s * a.n_real + lane];
+            if (a.y_shared && lane < a.n_fix) sw_l = a.global_w[(size_t)s * E + a.n_dyn + lane];
+            if (lane < a.n_real) {   // both table flavours are ONE int per (token, expert): same load, different meaning
+                const int32_t* tab = a.slot_of ? a.slot_of + (size_t)s * a.n_real : a.expert_mask + (size_t)s * a.mask_ld;
+                tab_v = tab[lane];
+            }
         }
+    }
+    auto broadcast_tables = [&]() {
+        const int lane = threadIdx.x & 63;
+        slot_l = lane < a.n_real ? ((!DENSE && a.slot_of) ? tab_v : (tab_v != 0 ? lane * a.dense_rows + s : -1)) : -1;
 #pragma unroll
         for (int e = 0; e < UMOE_MAXE; ++e) {
             slot[e] = __builtin_amdgcn_readlane(slot_l, e);
@@ -121,6 +135,11 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a,
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) swgt[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sw_l), i));
+    };
+    bool tables_ready = false;
+    if (fastp && !dense_rows_known) {
+        broadcast_tables();
+        tables_ready = true;
     }
     if constexpr (EP) {
         if (threadIdx.x < (unsigned)a.n_real) {
@@ -142,16 +161,21 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a,
                     if constexpr (EP) {
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.y_slots), 0, a.n_real * a.dense_rows * a.D * 2, 0x00020000);
-                        const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((slot[e] >= 0 ? slot[e] : 0) * a.D + c * 8) * 2, 0, UMOE_SYS_AUX);
+                        const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((e * a.dense_rows + s) * a.D + c * 8) * 2, 0, UMOE_SYS_AUX);
                         yv[e] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
                     } else {
-                        yv[e] = ld16(a.y_slots + (size_t)(slot[e] >= 0 ? slot[e] : 0) * a.D + c * 8);
+                        yv[e] = ld16(a.y_slots + (size_t)(dense_rows_known ? e * a.dense_rows + s : (slot[e] >= 0 ? slot[e] : 0)) * a.D + c * 8);
                     }
                 }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (a.y_shared && i < a.n_fix) sv[i] = ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8);
             if (a.resid) rv = ld16(a.resid + (size_t)s * a.D + c * 8);
+            if (!tables_ready) {     // dense layout: the tables are consumed only now, behind the row requests
+                __builtin_amdgcn_sched_barrier(0);
+                broadcast_tables();
+                tables_ready = true;
+            }
             TL_MARK(9, 6);
 #pragma unroll
             for (int e = 0; e < UMOE_MAXE; ++e)
@@ -244,12 +268,16 @@ extern "C" int umoe_unpermute_combine_fwd(const umoe_combine_args* a, umoe_strea
     memset(&x, 0, sizeof(x));
     if (a->ep_xfer) {
         x = *reinterpret_cast<const umoe_ep_xfer*>(a->ep_xfer);
-        UMOE_REQUIRE(!a->slot_of && !a->y_parts && a->expert_mask && a->n_real <= UMOE_MAXE && a->n_fix <= 4 && x.size >= 2 && a->n_real % x.size == 0 &&
+        UMOE_REQUIRE(!a->slot_of && !a->y_parts && a->expert_mask && a->n_real <= UMOE_MAXE && a->n_fix >= 1 && a->n_fix <= 4 && a->y_shared && a->global_w &&
+                         x.size >= 2 && a->n_real % x.size == 0 &&
                          a->S <= UMOE_EP_PARTS && a->dense_rows == a->S,
                      "umoe_unpermute_combine_fwd: the expert-parallel form needs the dense layout over <= %d rows", UMOE_EP_PARTS);
         combine_kernel<true><<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(*a, x);
     } else {
-        combine_kernel<false><<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(*a, x);
+        if (!a->slot_of && !a->y_parts && a->expert_mask && a->n_real >= 1 && a->n_real <= UMOE_MAXE && a->y_shared && a->global_w && a->n_fix >= 1 && a->n_fix <= 4)
+            combine_kernel<false, true><<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(*a, x);
+        else
+            combine_kernel<false, false><<<dim3((unsigned)a->S), 256, 0, (hipStream_t)stream>>>(*a, x);
     }
     UMOE_LAUNCH_CHECK();
     return 0;
