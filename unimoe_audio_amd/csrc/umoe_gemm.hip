@@ -89,7 +89,7 @@ struct umoe_fuse_x {
     int prod_base[UMOE_GROUPS_INLINE];      // per group of the CONSUMING GEMM: first flag and number of flags it waits for
     int prod_n[UMOE_GROUPS_INLINE];
 };
-template <int NT, int U, int PRO, int EPI, int WV, bool FR, bool PUB, int XW>
+template <int NT, int U, int PRO, int EPI, int WV, bool FR, bool PUB, int XW, bool BV = false>
 __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_group_pack& gp, const umoe_router_args& ra, const int rider_mode,
                                             const umoe_rider_pub& pub, const umoe_fuse_x& fx, const wg_coord blk, char* smem
 #ifdef UMOE_TIMELINE
@@ -137,7 +137,10 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
     // group sizes are (the per-CU byte balance decides this kernel, see the launcher).  A slice may straddle two groups.
     const bool flat = EPI == UMOE_EPI_SWIGLU && p.flat_wgs > 0;
     const unsigned zg = blk.z - ((FR && rider_mode == 1) ? 1u : 0u);      // group index
-    const umoe_group_t g = p.groups_host ? gp.g[flat ? 0 : zg] : p.groups[zg];
+    // BV (descriptors known to be by value: riders / the fused launch need them, the small decode launches are dispatched on it): plain
+    // kernel-argument reads = scalar loads.  Left to a run-time choice the compiler selects between the two ADDRESSES and reads the
+    // descriptor with flat loads through the vector memory path -- two dependent round trips in front of the first request.
+    const umoe_group_t g = (BV || FR || XW != 0) ? gp.g[flat ? 0 : zg] : (p.groups_host ? gp.g[flat ? 0 : zg] : p.groups[zg]);
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int ks = ksplit > 1 ? (int)(blk.x % ksplit) : 0;      // K-slice of this workgroup (fp32 partial slab `ks`)
     const int nb0 = (ksplit > 1 ? (int)(blk.x / ksplit) : (int)blk.x) * NT;
@@ -581,12 +584,12 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
     return 0;
 }
 
-template <int NT, int U, int PRO, int EPI, int WV, bool FR = false, bool PUB = false>
+template <int NT, int U, int PRO, int EPI, int WV, bool FR = false, bool PUB = false, bool BV = false>
 __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_router_args ra, const int rider_mode,
                                                             const umoe_rider_pub pub) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const umoe_fuse_x fx{};
-    (void)wstream_body<NT, U, PRO, EPI, WV, FR, PUB, 0>(p, gp, ra, rider_mode, pub, fx, wg_coord{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x}, smem);
+    (void)wstream_body<NT, U, PRO, EPI, WV, FR, PUB, 0, BV>(p, gp, ra, rider_mode, pub, fx, wg_coord{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x}, smem);
 }
 
 // The two expert GEMMs of a dense decode layer in ONE launch (8 routed + 2 shared experts, 16 rows): every workgroup computes its
@@ -629,14 +632,19 @@ static size_t gemm_lds_bytes(int max_k, int NT, int WV, int ksplit, int pro = UM
     return a > red ? a : red;
 }
 
-template <int NT, int U, int PRO, int EPI, int WV = 4, bool FR = false, bool PUB = false>
+template <int NT, int U, int PRO, int EPI, int WV = 4, bool FR = false, bool PUB = false, bool BV = false>
 static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
+    // the small decode launches (QKV, o_proj, codec head: one or two blocks per 4-wave workgroup, plain prologue) and the dense decode
+    // down projection: by-value descriptors known at compile time when the host passed them (see wstream_body, BV)
+    if constexpr (!BV && !FR && PRO == UMOE_PRO_PLAIN && ((NT <= 2 && WV == 4 && EPI != UMOE_EPI_SWIGLU) || (NT == 6 && WV == 8 && EPI == UMOE_EPI_BF16))) {
+        if (a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE) return launch_gemm<NT, U, PRO, EPI, WV, FR, PUB, true>(a, s);
+    }
     const int ksplit = a->ksplit > 1 ? a->ksplit : 1;
     const size_t lds = gemm_lds_bytes(a->max_k, NT, WV, ksplit, PRO);
     UMOE_REQUIRE(lds <= 160 * 1024, "umoe_grouped_gemm: K=%d needs %zu bytes of LDS (> 160 KiB)", a->max_k, lds);
     static size_t configured = 0;  // per instantiation
     if (lds > configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, U, PRO, EPI, WV, FR, PUB>),
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm<NT, U, PRO, EPI, WV, FR, PUB, BV>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         configured = lds;
     }
@@ -673,7 +681,7 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
                              a->groups_host[i].a_col_off == 0 && a->groups_host[i].static_count == ra.S,
                          "umoe_grouped_gemm: rider_pub needs static groups over rows [0, S) of `a` (group %d)", i);
     }
-    wstream_gemm<NT, U, PRO, EPI, WV, FR, PUB><<<grid, WV * 64, lds, s>>>(b, gp, ra, rider_mode, pub);
+    wstream_gemm<NT, U, PRO, EPI, WV, FR, PUB, BV><<<grid, WV * 64, lds, s>>>(b, gp, ra, rider_mode, pub);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
