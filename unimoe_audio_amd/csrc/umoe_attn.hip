@@ -199,6 +199,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
     const int h4 = lane >> 4, c = lane & 15;
 
     const bool fuse = a.qkv_raw != nullptr;      // decode: rope + append fused, the new key is NOT read from the cache
+    // every per-row scalar of the step state in ONE round trip (they are independent of each other; read where they were first used,
+    // the three rope positions cost a round trip of their own behind the key range)
+    int p0 = 0, p1 = 0, p2 = 0;
+    if (fuse) {
+        const int ntok = a.rows * a.nq;
+        p0 = a.pos3[qi]; p1 = a.pos3[ntok + qi]; p2 = a.pos3[2 * ntok + qi];
+    }
     const int kbeg_all = a.kv_start[row];
     const int kend_all = a.q_pos0[row] + t + (fuse ? 0 : 1);  // exclusive
     const int nkeys = max(kend_all - kbeg_all, 0);
@@ -213,7 +220,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
     // Q fragments (B operand): lane (h4, c = head in group) holds q[c][h4*32 + kb*8 .. +8]
     bf16x8_t qf[4];
     const int QKV_LD = (a.H + 2 * a.KVH) * HD;
-    int p0 = 0, p1 = 0, p2 = 0;
     // first key tile of this wave: requested right behind the rope operands, so the (HBM-cold) K/V rows are in flight
     // while the rope arithmetic runs (a wave's loads return in issue order: operands first, then the tile)
     uint4 kfr_first[4];
@@ -231,8 +237,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
             vraw[kk] = *reinterpret_cast<const uint32_t*>(Vc + (size_t)max(min(k0 + kk, kend - 1), 0) * HD + 2 * lane);
     };
     if (fuse) {
-        const int ntok = a.rows * a.nq;
-        p0 = a.pos3[qi]; p1 = a.pos3[ntok + qi]; p2 = a.pos3[2 * ntok + qi];
         uint4 u[4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) u[kb] = make_uint4(0, 0, 0, 0);
