@@ -470,6 +470,8 @@ typedef struct {
     int32_t* sync;            /* optional (umoe_attn_decode): [rows*nq][KVH] counters, ZERO before the first call.  When set, the
                                * last key split of a (query, kv head) to finish merges the partials itself and the combine
                                * launch disappears; the counters are zero again when the call completes */
+    int defer_merge;          /* umoe_attn_decode: 1 = leave the split partials (part_o / part_ml) unmerged -- the caller merges them
+                               * (decode engine: the merge rides in the o_proj launch) */
 } umoe_attn_args;
 int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream);
 /* causal prefill (nq = T queries per row) over keys already appended by umoe_qkv_mrope_kvappend */
@@ -480,6 +482,11 @@ int umoe_attn_prefill_fwd(const umoe_attn_args* a, umoe_stream_t stream);
  * emb [C][V][D]. */
 int umoe_codec_embed_sum(const int32_t* tok, const uint16_t* emb, int rows, int C, int V, int D, uint16_t* out,
                          umoe_stream_t stream);
+/* backward of the same (the reference's autograd of the C nn.Embedding gathers, model.py:655-661): d_emb[c][v] = sum over the rows r
+ * with tok[r][c] == v of d_out[r], fp32 accumulation in ASCENDING row order (deterministic), one rounding to bf16; rows of the table
+ * nobody selected are written as zeros.  D % 8 == 0, D <= 2048 * 8. */
+int umoe_codec_embed_sum_bwd(const int32_t* tok, const uint16_t* d_out, int rows, int C, int V, int D, uint16_t* d_emb,
+                             umoe_stream_t stream);
 
 /* CFG + masks + sampling on codec-head logits (model.py:991-1017, 873-916).
  * logits [2B][C*V] fp32 (row 2b = uncond, 2b+1 = cond).  temperature 0 or do_sample 0 => arg-max.

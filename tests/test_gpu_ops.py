@@ -814,6 +814,33 @@ def test_dense_gateup_flat_slices_equal_per_group_grid(dev, fw):
     assert float(a[:8 * S].float().abs().sum()) > 0 and float(a[8 * S:, :Is].float().abs().sum()) > 0
 
 
+@pytest.mark.parametrize("rows,C,V,D", [(700, 12, 1027, 2048), (37, 3, 19, 64), (20000, 2, 11, 256)])
+def test_codec_embed_sum_bwd_vs_index_add(dev, rows, C, V, D):
+    """umoe_codec_embed_sum_bwd (gradient of the stacked codec embedding tables, model.py:655-661 under autograd) against an fp64
+    index_add of the same rows: one bf16 rounding of a sum accumulated in fp32; ids nobody chose get exact zeros; the autograd
+    wrapper (train.CodecEmbedFn) returns the same through .backward()."""
+    from unimoe_audio_amd import ops, train as TR
+    g = torch.Generator().manual_seed(rows + V)
+    tok = torch.randint(0, V, (rows, C), generator=g)
+    dy = torch.randn(rows, D, generator=g).to(torch.bfloat16)
+    got = ops.codec_embed_sum_bwd(tok.to(dev), dy.to(dev), V).cpu()
+    ref = torch.zeros(C, V, D, dtype=torch.float64)
+    for c in range(C):
+        ref[c].index_add_(0, tok[:, c], dy.double())
+    assert torch.allclose(got.double(), ref, rtol=2 ** -7, atol=1e-6)
+    for c in range(C):
+        unused = torch.ones(V, dtype=torch.bool)
+        unused[tok[:, c]] = False
+        assert float(got[c][unused].float().abs().sum()) == 0.0
+    tabs = [torch.randn(V, D, generator=g).to(torch.bfloat16).to(dev).requires_grad_(True) for _ in range(C)]
+    out = TR.CodecEmbedFn.apply(tok.to(dev), *tabs)
+    want = sum(t.detach().cpu()[tok[:, c]] for c, t in enumerate(tabs))          # bf16 adds in channel order
+    assert torch.equal(out.cpu(), want)
+    out.backward(dy.to(dev))
+    for c in range(C):
+        assert torch.equal(tabs[c].grad.cpu(), got[c])
+
+
 @pytest.mark.parametrize("T,H,KVH,pads", [(333, 16, 2, (70, 0)), (64, 4, 4, (0, 5)), (17, 2, 1, (3, 0)), (1560, 16, 2, (0, 40))])
 def test_attention_prefill_mfma_vs_oracle(dev, T, H, KVH, pads):
     """umoe_attn_prefill_fwd (flash-attention forward on the matrix cores, transposing LDS reads for V^T) against the fp32

@@ -516,6 +516,14 @@ static void launch_attn(const umoe_attn_args* a, dim3 grid, hipStream_t s) {
     else attn_kernel<16><<<grid, 256, 0, s>>>(*a);
 }
 
+// merge of the key-split partials as a launch of its own (the engine's fallback when the merge cannot ride in the o_proj launch)
+int umoe_attn_merge(const umoe_attn_args* a, hipStream_t s) {
+    UMOE_REQUIRE(a && a->part_o && a->part_ml && a->out && a->splits >= 1, "umoe_attn_merge: bad argument");
+    launch_attn_combine(a, dim3((unsigned)a->H, (unsigned)(a->rows * a->nq)), s);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     UMOE_REQUIRE(a && (a->q || a->qkv_raw) && a->k_cache && a->v_cache && a->kv_start && a->q_pos0 && a->part_o && a->part_ml && a->out,
                  "umoe_attn_decode: null argument");
@@ -536,7 +544,7 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     if (nqi <= 65535u) {
         launch_attn(a, dim3((unsigned)a->splits, (unsigned)a->KVH, nqi), s);
         UMOE_LAUNCH_CHECK();
-        if (!a->sync && a->splits > 1) {
+        if (!a->sync && a->splits > 1 && !a->defer_merge) {
             launch_attn_combine(a, dim3((unsigned)a->H, nqi), s);
             UMOE_LAUNCH_CHECK();
         }

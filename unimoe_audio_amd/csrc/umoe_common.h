@@ -224,6 +224,13 @@ struct umoe_rider_pub {
 // Returns 1 (nothing launched) when the shapes do not allow the fusion: the caller then issues the two launches.
 int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* flags, int flag_words, hipStream_t s);
 
+// A small decode GEMM with row riders in front (umoe_gemm.hip wstream_gemm_rk, umoe_riders_dev.h; decode engine only).  kind 2: the
+// MoE combine of the previous layer rides in the QKV launch; kind 3: the attention split merge rides in the o_proj launch.
+// Returns 1 (nothing launched) when the shapes do not fit.
+struct umoe_rider2;
+int umoe_attn_merge(const umoe_attn_args* a, hipStream_t s);      // umoe_attn.hip: the split merge as its own launch
+int umoe_gemm_riders(const umoe_gemm_args* a, int kind, const umoe_rider2* r2, const umoe_rider_pub* pub, hipStream_t s);
+
 // ---- weight-streaming GEMM over several 16-row tiles per weight pass (umoe_gemm_mt.hip; expert parallel decode) --------
 #define UMOE_MT_MAXG 4
 #define UMOE_MT_MAXT UMOE_MAX_EP

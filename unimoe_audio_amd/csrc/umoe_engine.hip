@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "umoe_common.h"
+#include "umoe_riders_dev.h"
 
 namespace {
 
@@ -79,6 +80,12 @@ struct umoe_engine {
     // lists, no dispatch kernel, no device-produced row counts in the GEMM prologues) and the combine selects by mask
     bool dense_experts = true;
     bool fuse_router = true;     // UMOE_FUSE_ROUTER: dense decode runs the router inside the gate/up launch (see run_layer)
+    bool fuse_cq = true;         // UMOE_FUSE_CQ: the MoE combine of layer l rides in the QKV launch of layer l + 1 (umoe_gemm_riders kind 2)
+    bool fuse_ao = false;        // UMOE_FUSE_AO: the attention split merge rides in the o_proj launch (kind 3).  Off: measured 3.18 vs 3.13
+                                 // ms/step -- the merge is 1 us of work, its hand-off (drain, flag, poll, sc1 reload) costs more than
+                                 // the launch boundary it removes; the combine in the QKV launch (fuse_cq) wins: 3.08 vs 3.13
+    bool cb_pending = false;     // a combine stashed at the end of a layer, issued with the next layer's QKV launch
+    umoe_combine_args cb_stash{};
     bool fuse_moe = true;        // UMOE_FUSE_MOE: gate/up and down projections of a dense decode layer in ONE launch (umoe_moe_fused)
     bool gu_norm = false;        // UMOE_GU_NORM: the gate/up workgroups normalise x1 in their staging prologue (no hand-off, no norm launch)
     bool rider_pub = true;       // UMOE_RIDER_PUB: the riders also produce the normalised rows and hand them to the GEMM workgroups of the
@@ -336,6 +343,8 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (const char* v = getenv("UMOE_RIDER_PUB")) e->rider_pub = atoi(v) != 0;
     if (const char* v = getenv("UMOE_GU_NORM")) e->gu_norm = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_MOE")) e->fuse_moe = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_FUSE_CQ")) e->fuse_cq = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_FUSE_AO")) e->fuse_ao = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -693,7 +702,18 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         ta.epilogue = UMOE_EPI_BF16;
         rc = umoe_tiled_gemm(&ta, s);
     } else {
-        rc = umoe_grouped_gemm(&a, s);
+        rc = 1;
+        if (e->cb_pending) {
+            // the previous layer's combine (+ residual + this layer's input RMSNorm) rides in this launch and hands the rows over
+            e->cb_pending = false;
+            umoe_rider2 r2{};
+            r2.n_riders = n_tok; r2.cb = e->cb_stash;
+            umoe_rider_pub cpub{};
+            cpub.flags = e->ep_words + 32; cpub.step = e->ep_words; cpub.layer = l; cpub.layers = c.layers; cpub.err = e->ep_words + 1;
+            rc = umoe_gemm_riders(&a, 2, &r2, &cpub, s);
+            if (rc == 1 && (rc = umoe_unpermute_combine_fwd(&e->cb_stash, s)) == 0) rc = 1;     // shapes do not fit: the two launches
+        }
+        if (rc == 1) rc = umoe_grouped_gemm(&a, s);
     }
     if (rc) return rc;
     PROF(K_QKV);
@@ -714,6 +734,9 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     t.rows = c.rows; t.nq = T; t.H = c.heads; t.KVH = c.kv_heads; t.hd = c.head_dim; t.Lmax = c.Lmax; t.splits = splits;
     t.scale = 1.0f / sqrtf((float)c.head_dim); t.part_o = e->part_o; t.part_ml = e->part_ml; t.out = e->attn_out;
     if (T == 1 && e->attn_single) t.sync = e->attn_sync;   // decode: the last key split merges, no combine launch
+    // decode: the merge of the key splits rides in the o_proj launch (16 rider workgroups hand the merged rows over)
+    const bool merge_rides = T == 1 && !tiled && e->fuse_ao && e->rider_pub && !t.sync && splits == 8 && c.heads == 16 && c.head_dim == 128 && n_tok <= 16;
+    if (merge_rides) t.defer_merge = 1;
     if (fuse_rope) {
         t.qkv_raw = e->qkv; t.cos_tab = e->cos_tab; t.sin_tab = e->sin_tab; t.pos3 = e->pos3;
         t.sec0 = c.mrope0; t.sec1 = c.mrope1; t.sec2 = c.mrope2;
@@ -732,6 +755,18 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         ta.groups = &tg; ta.num_groups = 1; ta.max_rows = n_tok; ta.a = e->attn_out; ta.lda = HD; ta.resid = e->x; ta.out = e->x1;
         ta.ldo = D; ta.epilogue = UMOE_EPI_BF16_RESID;
         rc = umoe_tiled_gemm(&ta, s);
+    } else if (merge_rides) {
+        umoe_rider2 r2{};
+        r2.n_riders = n_tok; r2.part_o = e->part_o; r2.part_ml = e->part_ml; r2.attn_out = e->attn_out; r2.H = c.heads; r2.splits = splits;
+        umoe_rider_pub apub{};
+        apub.flags = e->ep_words + 48; apub.step = e->ep_words; apub.layer = l; apub.layers = c.layers; apub.err = e->ep_words + 1;
+        rc = umoe_gemm_riders(&o, 3, &r2, &apub, s);
+        if (rc == 1) {       // shapes do not fit the riders: merge in a launch of its own, then the plain o_proj
+            umoe_attn_args m = t;
+            m.defer_merge = 0;
+            if ((rc = umoe_attn_merge(&m, s))) return rc;
+            rc = umoe_grouped_gemm(&o, s);
+        }
     } else {
         rc = umoe_grouped_gemm(&o, s);
     }
@@ -886,6 +921,11 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
     // fused RMSNorm for the consumer of x: the next layer's input_layernorm, or the final norm in front of the head
     cb.norm_w = (l + 1 < c.layers) ? e->layers[l + 1].w.in_norm : e->final_norm; cb.norm_out = e->hin; cb.rms_eps = c.rms_eps;
+    if (dense && T == 1 && !tiled && e->fuse_cq && e->rider_pub && l + 1 < c.layers && D == 2048 && n_tok <= 16 && c.n_fix >= 1) {
+        e->cb_stash = cb;        // issued by the next layer's QKV launch (run_layer(l + 1) follows immediately)
+        e->cb_pending = true;
+        return 0;
+    }
     rc = umoe_unpermute_combine_fwd(&cb, s);
     PROF(K_COMBINE);
     return rc;
@@ -942,6 +982,7 @@ extern "C" int umoe_engine_prefill_pos(umoe_engine* e, const uint16_t* x, const 
     UMOE_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
     if ((rc = umoe_rmsnorm_residual_fwd(e->x, nullptr, e->layers[0].w.in_norm, c.rms_eps, n_tok, c.hidden, nullptr, e->hin, s)))
         return rc;
+    e->cb_pending = false;
     for (int l = 0; l < c.layers; ++l)
         if ((rc = run_layer(e, l, n_tok, T, 1, s))) return rc;
     e->T_prompt = T;
@@ -985,6 +1026,7 @@ static int enqueue_step(umoe_engine* e, const umoe_decode_io* io, hipStream_t s)
     if ((rc = umoe_rmsnorm_residual_fwd(e->x, nullptr, e->layers[0].w.in_norm, c.rms_eps, c.rows, c.hidden, nullptr, e->hin, s)))
         return rc;
     PROF(K_EMBED);
+    e->cb_pending = false;
     for (int l = 0; l < c.layers; ++l)
         if ((rc = run_layer(e, l, c.rows, 1, c.attn_splits, s))) return rc;
     // final norm + codec head -> fp32 logits                       model.py:428, 982-983

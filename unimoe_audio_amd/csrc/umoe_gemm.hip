@@ -19,6 +19,7 @@
 // Roofline: HBM. Algorithmic bytes per launch = sum over groups hit of N*K*2 (+ activations).
 #include "umoe_common.h"
 #include "umoe_router_dev.h"
+#include "umoe_riders_dev.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -592,6 +593,24 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
     (void)wstream_body<NT, U, PRO, EPI, WV, FR, PUB, 0, BV>(p, gp, ra, rider_mode, pub, fx, wg_coord{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x}, smem);
 }
 
+// A one-block-per-workgroup decode GEMM (QKV with bias / o_proj with residual: NT 1, 4 waves) with ROW riders in front
+// (umoe_riders_dev.h): workgroups [0, n_riders) run the row kernel that produces this GEMM's activation rows (RK 2: MoE combine +
+// residual + RMSNorm of the previous layer; RK 3: merge of the attention key splits) and hand them over; the GEMM tiles follow.
+template <int EPI, int RK>
+__global__ __launch_bounds__(256, 2) void wstream_gemm_rk(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_rider_pub pub, const umoe_rider2 r2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < r2.n_riders) {
+        const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
+        if constexpr (RK == 2) combine_row_dense(r2.cb, (int)blockIdx.x, reinterpret_cast<float*>(smem), pub.flags + blockIdx.x, epoch);
+        else attn_merge_row<8>(r2, (int)blockIdx.x, pub.flags + blockIdx.x, epoch);
+        return;
+    }
+    const umoe_fuse_x fx{};
+    const umoe_router_args ra{};
+    (void)wstream_body<1, 16, UMOE_PRO_PLAIN, EPI, 4, false, true, 0, true>(p, gp, ra, 0, pub, fx,
+                                                                        wg_coord{blockIdx.x - (unsigned)r2.n_riders, 0u, 0u, gridDim.x - (unsigned)r2.n_riders}, smem);
+}
+
 // The two expert GEMMs of a dense decode layer in ONE launch (8 routed + 2 shared experts, 16 rows): every workgroup computes its
 // gate/up slice (7 pairs, riders and their hand-off as in the gate/up launch), publishes it, then takes a down-projection slice (6
 // blocks): it requests that slice's first weights, waits for the gate/up workgroups of ITS expert only, stages the rows and streams.
@@ -682,6 +701,50 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
                          "umoe_grouped_gemm: rider_pub needs static groups over rows [0, S) of `a` (group %d)", i);
     }
     wstream_gemm<NT, U, PRO, EPI, WV, FR, PUB, BV><<<grid, WV * 64, lds, s>>>(b, gp, ra, rider_mode, pub);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+int umoe_gemm_riders(const umoe_gemm_args* a, int kind, const umoe_rider2* r2, const umoe_rider_pub* pub, hipStream_t s) {
+    UMOE_REQUIRE(a && r2 && pub && pub->flags && pub->step && pub->err, "umoe_gemm_riders: null argument");
+    // shapes the riders are written for; anything else: 1 = nothing launched (the caller issues the separate launches)
+    if (!(a->groups_host && a->num_groups == 1 && a->max_rows <= 16 && a->max_rows == r2->n_riders && a->prologue == UMOE_PRO_PLAIN && a->ksplit <= 1 &&
+          a->max_k % 512 == 0 && a->max_k <= 4096 && !a->fused_router && (a->lda & 7) == 0))
+        return 1;
+    const umoe_group_t& g = a->groups_host[0];
+    if (g.rows || g.count || g.row_off || g.a_row_base || g.a_col_off || g.static_count != r2->n_riders) return 1;
+    if (kind == 2) {
+        const umoe_combine_args& c = r2->cb;
+        if (!(a->epilogue == UMOE_EPI_BF16 && c.D == 2048 && c.S == r2->n_riders && !c.slot_of && !c.y_parts && c.expert_mask && c.y_slots && c.y_shared &&
+              c.global_w && c.moe_w && c.resid && c.out && c.norm_w && c.norm_out == a->a && a->lda == c.D && a->max_k == c.D && c.n_real >= 1 &&
+              c.n_real <= UMOE_MAXE && c.n_fix >= 1 && c.n_fix <= 4 && c.dense_rows >= c.S && !c.ep_xfer))
+            return 1;
+    } else if (kind == 3) {
+        if (!(a->epilogue == UMOE_EPI_BF16_RESID && a->resid && r2->splits == 8 && r2->H == 16 && r2->part_o && r2->part_ml && r2->attn_out == a->a &&
+              a->lda == r2->H * 128 && a->max_k == r2->H * 128))
+            return 1;
+    } else {
+        return 1;
+    }
+    const size_t lds = gemm_lds_bytes(a->max_k, 1, 4, 1);
+    umoe_group_pack gp;
+    memset(&gp, 0, sizeof(gp));
+    gp.g[0] = g;
+    const dim3 grid((unsigned)(r2->n_riders + a->max_n_blocks), 1, 1);
+    static size_t conf2 = 0, conf3 = 0;
+    if (kind == 2) {
+        if (lds > conf2) {
+            UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm_rk<UMOE_EPI_BF16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            conf2 = lds;
+        }
+        wstream_gemm_rk<UMOE_EPI_BF16, 2><<<grid, 256, lds, s>>>(*a, gp, *pub, *r2);
+    } else {
+        if (lds > conf3) {
+            UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm_rk<UMOE_EPI_BF16_RESID, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            conf3 = lds;
+        }
+        wstream_gemm_rk<UMOE_EPI_BF16_RESID, 3><<<grid, 256, lds, s>>>(*a, gp, *pub, *r2);
+    }
     UMOE_LAUNCH_CHECK();
     return 0;
 }

@@ -310,6 +310,68 @@ extern "C" int umoe_codec_embed_sum(const int32_t* tok, const uint16_t* emb, int
     return 0;
 }
 
+// backward: one workgroup per (vocabulary id v, channel c).  It scans the channel's token column once (thread i <- rows i, i + 256,
+// ..), keeps the match bits of every 256-row segment in LDS, then all threads walk the bits in ascending row order and add that
+// row of d_out to their 8 columns: deterministic, no atomics, no sort.  Ids nobody chose (most of a 1027-entry table at 6 k rows
+// are chosen a handful of times) cost the scan only.
+#define EMB_BWD_SEG 64     // 256-row segments per pass (16 K rows)
+__global__ __launch_bounds__(256) void codec_embed_bwd_kernel(const int32_t* __restrict__ tok, const uint16_t* __restrict__ d_out, int rows, int C,
+                                                              int V, int D, uint16_t* __restrict__ d_emb) {
+    __shared__ unsigned long long bits[EMB_BWD_SEG][4];
+    const int v = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nc8 = D >> 3;
+    float acc[8][8];     // up to 8 column chunks per thread (D <= 16384)
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+    for (int r0 = 0; r0 < rows; r0 += EMB_BWD_SEG * 256) {
+        const int nseg = min(EMB_BWD_SEG, (rows - r0 + 255) / 256);
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int r = r0 + sg * 256 + tid;
+            const bool hit = r < rows && tok[(size_t)r * C + c] == v;
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) bits[sg][wave] = m;
+        }
+        __syncthreads();
+        for (int sg = 0; sg < nseg; ++sg)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long m = bits[sg][w];
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const size_t r = (size_t)r0 + sg * 256 + w * 64 + b;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int c8 = tid + q * 256;
+                        if (c8 < nc8) {
+                            float f[8];
+                            unpack8(ld16(d_out + r * D + c8 * 8), f);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[q][j] += f[j];
+                        }
+                    }
+                }
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c8 = tid + q * 256;
+        if (c8 < nc8) st16(d_emb + ((size_t)c * V + v) * D + c8 * 8, pack8(acc[q]));
+    }
+}
+
+extern "C" int umoe_codec_embed_sum_bwd(const int32_t* tok, const uint16_t* d_out, int rows, int C, int V, int D, uint16_t* d_emb,
+                                        umoe_stream_t stream) {
+    UMOE_REQUIRE(tok && d_out && d_emb && D % 8 == 0 && D <= 2048 * 8 && C > 0 && V > 0 && rows >= 0 && C <= 65535,
+                 "umoe_codec_embed_sum_bwd: bad argument (D %% 8 == 0, D <= 16384)");
+    codec_embed_bwd_kernel<<<dim3((unsigned)V, (unsigned)C), 256, 0, (hipStream_t)stream>>>(tok, d_out, rows, C, V, D, d_emb);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ CFG + sampler
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
     z += 0x9e3779b97f4a7c15ull;

@@ -1,0 +1,139 @@
+// Riders of the small decode GEMM launches (umoe_gemm.hip wstream_gemm_rk): the latency-bound row kernels in FRONT of a GEMM run as
+// the first 16 workgroups of the GEMM's own launch and HAND their output rows to the GEMM workgroups (sc1 stores, drain, one flag per
+// row; umoe_common.h umoe_rider_pub) -- the GEMM workgroups request their whole weight slice first and wait for the flags, so the
+// launch boundary between the two kernels and the second kernel's cold start leave the chain.
+//   combine_row_dense: combine_kernel<false, true> of umoe_misc.hip for ONE row (dense decode layout, D = 2048: one 16-byte chunk per
+//     thread), same loads, same arithmetic order, same fixed-order RMSNorm sum -> bit-identical rows          (core.py:488,342-351)
+//   attn_merge_row:    attn_combine_kernel<8> of umoe_attn.hip for ONE row (thread -> head tid/16, 8 value columns)
+#pragma once
+#include "umoe_common.h"
+
+struct umoe_rider2 {
+    int n_riders;                  // rows (= rider workgroups in front of the GEMM tiles)
+    umoe_combine_args cb;          // kind 2: MoE combine + residual + next RMSNorm; cb.norm_out is the GEMM's activation operand
+    const float* part_o;           // kind 3: attention split partials [row][H][splits][128], [row][H][splits][2]
+    const float* part_ml;
+    uint16_t* attn_out;            //         merged rows [row][H * 128] = the GEMM's activation operand
+    int H, splits;
+};
+
+__device__ __forceinline__ void rider_publish(uint32_t* flag, uint32_t epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(flag)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void st16_sc1(uint16_t* base, long elem_off, uint4 v, long bytes) {
+    typedef uint32_t u32x4_pub __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+    const u32x4_pub v4 = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, (int)(elem_off * 2), 0, 16);      // aux 16 = sc1 (agent-scope write-through)
+}
+
+__device__ __forceinline__ void combine_row_dense(const umoe_combine_args& a, const int s, float* sh, uint32_t* flag, const uint32_t epoch) {
+    const int tid = threadIdx.x, lane = tid & 63, c = tid;          // D = 2048: chunk c of the row
+    const int E = a.n_dyn + a.n_fix;
+    // tables (lane e <- entry e; clamped, straight-line) and every row this token needs, all in one round trip
+    const float wgt_l = a.moe_w[(size_t)s * a.n_real + min(lane, a.n_real - 1)];
+    const float sw_l = a.global_w[(size_t)s * E + a.n_dyn + min(lane, a.n_fix - 1)];
+    const int tab_v = a.expert_mask[(size_t)s * a.mask_ld + min(lane, a.n_real - 1)];
+    uint4 yv[UMOE_MAXE], sv[4];
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < a.n_real) yv[e] = ld16(a.y_slots + (size_t)(e * a.dense_rows + s) * a.D + c * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < a.n_fix) sv[i] = ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8);
+    const uint4 rv = ld16(a.resid + (size_t)s * a.D + c * 8);
+    const uint4 nw = ld16(a.norm_w + c * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    int sel[UMOE_MAXE];
+    float wgt[UMOE_MAXE], swgt[4];
+    const int sel_l = lane < a.n_real ? (tab_v != 0) : 0;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) {
+        sel[e] = __builtin_amdgcn_readlane(sel_l, e);
+        wgt[e] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wgt_l), e));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) swgt[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sw_l), i));
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < a.n_real && sel[e]) {
+            float y[8];
+            unpack8(yv[e], y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wgt[e] * y[j];
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < a.n_fix) {
+            float y[8];
+            unpack8(sv[i], y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = rbf(acc[j] + rbf(y[j] * swgt[i]));
+        }
+    {
+        float r[8];
+        unpack8(rv, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = r[j] + acc[j];
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc[j] = rbf(acc[j]);
+        ss += acc[j] * acc[j];
+    }
+    st16(a.out + (size_t)s * a.D + c * 8, pack8(acc));        // the residual stream: read by LATER launches only
+    ss = block_sum_256(ss, sh);
+    const float rs = rsqrtf(ss / (float)a.D + a.rms_eps);
+    float w[8], f[8];
+    unpack8(nw, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(acc[j] * rs);
+    st16_sc1(a.norm_out, (long)s * a.D + c * 8, pack8(f), (long)a.S * a.D * 2);
+    rider_publish(flag, epoch);
+}
+
+template <int SP>
+__device__ __forceinline__ void attn_merge_row(const umoe_rider2& r, const int qi, uint32_t* flag, const uint32_t epoch) {
+    constexpr int HD = 128;
+    const int tid = threadIdx.x, head = tid >> 4, d8 = (tid & 15) * 8;
+    const float* pm = r.part_ml + ((size_t)qi * r.H + head) * SP * 2;
+    const float* po = r.part_o + ((size_t)qi * r.H + head) * SP * HD + d8;
+    float2 ml[SP];
+    float4 ov[SP][2];
+#pragma unroll
+    for (int s = 0; s < SP; ++s) {
+        ml[s] = *reinterpret_cast<const float2*>(pm + 2 * s);
+        ov[s][0] = *reinterpret_cast<const float4*>(po + (size_t)s * HD);
+        ov[s][1] = *reinterpret_cast<const float4*>(po + (size_t)s * HD + 4);
+    }
+    float mm = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < SP; ++s) mm = fmaxf(mm, ml[s].x);
+    float L = 0.f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SP; ++s) {
+        const float sc = (ml[s].x == -INFINITY) ? 0.f : __expf(ml[s].x - mm);
+        L += sc * ml[s].y;
+        acc[0] += sc * ov[s][0].x; acc[1] += sc * ov[s][0].y; acc[2] += sc * ov[s][0].z; acc[3] += sc * ov[s][0].w;
+        acc[4] += sc * ov[s][1].x; acc[5] += sc * ov[s][1].y; acc[6] += sc * ov[s][1].z; acc[7] += sc * ov[s][1].w;
+    }
+    uint16_t y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) y[j] = f2bf(L > 0.f ? acc[j] / L : 0.f);
+    const uint4 pk = make_uint4((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16), (uint32_t)y[4] | ((uint32_t)y[5] << 16),
+                                (uint32_t)y[6] | ((uint32_t)y[7] << 16));
+    st16_sc1(r.attn_out, ((long)qi * r.H + head) * HD + d8, pk, (long)r.n_riders * r.H * HD * 2);
+    rider_publish(flag, epoch);
+}

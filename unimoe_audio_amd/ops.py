@@ -334,6 +334,16 @@ def codec_embed_sum(tok: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def codec_embed_sum_bwd(tok: torch.Tensor, d_out: torch.Tensor, V: int) -> torch.Tensor:
+    """[C][V][D] gradient of the stacked codec embedding tables (deterministic: ascending row order, fp32 accumulation)."""
+    rows, Cc = tok.shape
+    D = d_out.shape[1]
+    d_emb = torch.empty((Cc, V, D), dtype=torch.bfloat16, device=d_out.device)
+    L.check(L.lib().umoe_codec_embed_sum_bwd(_p(tok.to(torch.int32).contiguous()), _p(d_out.to(torch.bfloat16).contiguous()), rows, Cc, V, D,
+                                             _p(d_emb), _stream()), "umoe_codec_embed_sum_bwd")
+    return d_emb
+
+
 def cfg_sample(logits: torch.Tensor, B: int, Cc: int, V: int, *, cfg_scale, temperature, top_p, top_k, eos, eos_mul,
                enable_eos=True, do_sample=True, seed=0, want_probs=False):
     pred = torch.empty((B, Cc), dtype=torch.int64, device=logits.device)

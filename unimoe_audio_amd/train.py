@@ -54,6 +54,23 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class CodecEmbedFn(torch.autograd.Function):
+    """sum_c Emb_c[tok[..., c]] (model.py:655-661: bf16 adds in channel order) with the table gradients by one HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, tok, *tables):
+        emb = torch.stack(tables, 0)                       # [C][V][D]
+        ctx.save_for_backward(tok)
+        ctx.V = emb.shape[1]
+        return ops.codec_embed_sum(tok, emb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tok,) = ctx.saved_tensors
+        d_emb = ops.codec_embed_sum_bwd(tok, dy, ctx.V)
+        return (None, *d_emb.unbind(0))
+
+
 class RMSNormFn(torch.autograd.Function):
     """Qwen2RMSNorm: w * bf16(x * rsqrt(mean(x^2) + eps))."""
 
@@ -180,7 +197,8 @@ def forward_train(model, input_ids, codec_input_ids, attention_mask, codec_label
     x = model.language_model.embed_tokens.weight[input_ids.to(dev)]
     if codec_input_ids is not None:
         ci = codec_input_ids.to(dev)
-        ce = sum(model.codec_embed_tokens[c].weight[ci[..., c]] for c in range(model.num_channels))   # model.py:655-661
+        # model.py:655-661 (sum of the per-channel embedding gathers; ids are clamped into the table like the decode kernel does)
+        ce = CodecEmbedFn.apply(ci.reshape(-1, model.num_channels), *[e.weight for e in model.codec_embed_tokens]).reshape(*ci.shape[:-1], -1)
         m = (input_ids.to(dev) == model.codec_placeholder_value).unsqueeze(-1).expand_as(x)
         x = x.masked_scatter(m, ce.to(x.dtype))
     pm = None
