@@ -21,7 +21,9 @@ def load(d, counter):
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-alg = {"wstream_gemm<14, 1, 0, 2, 8, true, true>": 202.9, "wstream_gemm<14, 1, 0, 2, 8, true, false>": 202.9, "wstream_gemm<6, 2, 0, 0, 8, false, false>": 101.4,
+alg = {"moe_fused_kernel": 304.3, "wstream_gemm_rk<0, 2>": 10.5, "wstream_gemm_rk<1, 3>": 8.4, "wstream_gemm<1, 16, 0, 0, 4, false, false, true>": 10.5,
+       "wstream_gemm<1, 16, 0, 1, 4, false, false, true>": 8.4, "wstream_gemm<2, 8, 0, 3, 4, false, false, true>": 50.5,
+       "wstream_gemm<14, 1, 0, 2, 8, true, true>": 202.9, "wstream_gemm<14, 1, 0, 2, 8, true, false>": 202.9, "wstream_gemm<6, 2, 0, 0, 8, false, false>": 101.4,
        "wstream_gemm<1, 16, 0, 0, 4, false, false>": 10.5, "wstream_gemm<1, 16, 0, 1, 4, false, false>": 8.4, "wstream_gemm<2, 8, 0, 3, 4, false, false>": 50.5,
        "wstream_gemm<14, 1, 0, 2, 8, true>": 202.9, "wstream_gemm<14, 1, 0, 2, 8, false>": 202.9, "wstream_gemm<6, 2, 0, 0, 8, false>": 101.4,
        "wstream_gemm<1, 16, 0, 0, 4, false>": 10.5, "wstream_gemm<1, 16, 0, 1, 4, false>": 8.4, "wstream_gemm<2, 8, 0, 3, 4, false>": 50.5,
