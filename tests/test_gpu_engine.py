@@ -439,9 +439,11 @@ def test_router_riding_in_the_gate_up_launch_is_bit_identical(dev, monkeypatch):
     # (fourth / fifth variant: the hand-off off; the gate/up workgroups normalising x1 themselves, umoe_engine.hip gu_norm)
     # sixth: gate/up and down as two launches instead of the fused expert launch (umoe_moe_fused), which the default (third) uses
     # seventh / eighth: the combine and the attention split merge as launches of their own instead of riding in the QKV / o_proj launches
-    for fuse, mode, pub, gun, fm, cq, ao in (("0", "0", "1", "0", "1", "1", "1"), ("1", "1", "1", "0", "1", "1", "1"), ("1", "0", "1", "0", "1", "1", "1"),
-                                             ("1", "0", "0", "0", "1", "1", "1"), ("1", "0", "1", "1", "1", "1", "1"), ("1", "0", "1", "0", "0", "1", "1"),
-                                             ("1", "0", "1", "0", "1", "0", "1"), ("1", "0", "1", "0", "1", "1", "0")):
+    # ninth: the fused expert launch with the riders handing over normalised ROWS (the default hands over the rows' scales only)
+    for fuse, mode, pub, gun, fm, cq, ao, rsh in (("0", "0", "1", "0", "1", "1", "1", "1"), ("1", "1", "1", "0", "1", "1", "1", "1"), ("1", "0", "1", "0", "1", "1", "1", "1"),
+                                                  ("1", "0", "0", "0", "1", "1", "1", "1"), ("1", "0", "1", "1", "1", "1", "1", "1"), ("1", "0", "1", "0", "0", "1", "1", "1"),
+                                                  ("1", "0", "1", "0", "1", "0", "1", "1"), ("1", "0", "1", "0", "1", "1", "0", "1"), ("1", "0", "1", "0", "1", "1", "0", "0")):
+        monkeypatch.setenv("UMOE_RS_HANDOFF", rsh)
         monkeypatch.setenv("UMOE_FUSE_CQ", cq)
         monkeypatch.setenv("UMOE_FUSE_AO", ao)
         monkeypatch.setenv("UMOE_FUSE_MOE", fm)

@@ -216,6 +216,7 @@ struct umoe_rider_pub {
     const uint32_t* step;      // device word: decode steps taken so far
     int layer, layers;         // epoch = *step * layers + layer + 1
     uint32_t* err;             // device word, sticky: 2 = a workgroup gave up waiting for the riders
+    unsigned long long* rs;    // second hand-off form (fused expert launch with the RMSNorm prologue): device [16] granules {rs, epoch}
 };
 
 // The two expert GEMMs of a dense decode layer (gate/up SwiGLU with riders + rider_pub, then the down projections) in ONE launch

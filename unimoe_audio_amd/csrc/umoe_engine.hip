@@ -80,6 +80,9 @@ struct umoe_engine {
     // lists, no dispatch kernel, no device-produced row counts in the GEMM prologues) and the combine selects by mask
     bool dense_experts = true;
     bool fuse_router = true;     // UMOE_FUSE_ROUTER: dense decode runs the router inside the gate/up launch (see run_layer)
+    bool rs_handoff = false;     // UMOE_RS_HANDOFF: fused expert launch: the riders hand over the rows' RMSNorm scales (8-byte granules), not the
+                                 // rows.  Off: bit-identical, measured 3.105-3.11 vs 3.075-3.087 ms/step -- 226 workgroups scaling the 16 rows
+                                 // they stage cost more than the drain + reload of the rows the hand-off saves
     bool fuse_cq = true;         // UMOE_FUSE_CQ: the MoE combine of layer l rides in the QKV launch of layer l + 1 (umoe_gemm_riders kind 2)
     bool fuse_ao = false;        // UMOE_FUSE_AO: the attention split merge rides in the o_proj launch (kind 3).  Off: measured 3.18 vs 3.13
                                  // ms/step -- the merge is 1 us of work, its hand-off (drain, flag, poll, sc1 reload) costs more than
@@ -344,6 +347,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (const char* v = getenv("UMOE_GU_NORM")) e->gu_norm = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_MOE")) e->fuse_moe = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_CQ")) e->fuse_cq = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_RS_HANDOFF")) e->rs_handoff = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_AO")) e->fuse_ao = atoi(v) != 0;
     *out = e;
     return 0;
@@ -809,7 +813,10 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // bits), so that launch waits for nobody -- no norm launch, no hand-off
     const bool gu_norm = fuse_router && e->gu_norm && D == 2048;
     const bool pub_riders = fuse_router && e->rider_pub && !gu_norm;
-    if (gu_norm) {
+    // fused expert launch, second hand-off form: the riders hand over the rows' SCALES only ({rs, epoch} granules); the GEMM
+    // workgroups load the raw rows x1 at launch and finish the norm themselves
+    const bool rs_handoff = pub_riders && e->fuse_moe && e->rs_handoff && D == 2048 && !tiled;
+    if (gu_norm || rs_handoff) {
         rc = 0;
         ra.h_out = nullptr;
     } else if (pub_riders) {
@@ -828,6 +835,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     PROF(K_ROUTER);
     umoe_rider_pub rpub{};
     rpub.flags = e->ep_words + 16; rpub.step = e->ep_words; rpub.layer = l; rpub.layers = c.layers; rpub.err = e->ep_words + 1;
+    rpub.rs = reinterpret_cast<unsigned long long*>(e->ep_words + 512);
     // 7./8. experts.  The shared experts need no routing: with `overlap_shared` they run on a second stream from the
     // residual stream x1 (their own RMSNorm prologue) BESIDE the latency-bound router + dispatch (forked after o_proj,
     // see below) and are joined before the combine; otherwise routed + shared share one launch each.
@@ -843,6 +851,9 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         if (gu_norm) {
             gu.a = e->x1; gu.norm_w = L.w.post_norm; gu.rms_eps = c.rms_eps; gu.prologue = UMOE_PRO_RMSNORM;
             gu.groups_host = e->h_gu_pub.data() + (size_t)l * G;     // (same order as the hand-off variant: shared experts first)
+        }
+        if (rs_handoff) {
+            gu.a = e->x1; gu.norm_w = L.w.post_norm; gu.rms_eps = c.rms_eps; gu.prologue = UMOE_PRO_RMSNORM;
         }
         if (pub_riders) {
             gu.rider_pub = &rpub;
@@ -900,7 +911,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     } else if (pub_riders && e->fuse_moe) {
         // both expert GEMMs in one launch (words 64.. of ep_words: one flag per gate/up workgroup); shapes that do not allow it
         // fall back to the two launches
-        rc = umoe_moe_fused(&gu, &dn, e->ep_words + 64, 1024 - 64, s);
+        rc = umoe_moe_fused(&gu, &dn, e->ep_words + 64, 512 - 64, s);
+        UMOE_REQUIRE(!(rc == 1 && rs_handoff), "umoe_engine: the fused expert launch refused the shapes it was configured for (UMOE_RS_HANDOFF=0 selects the other form)");
         if (rc == 1) {
             if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
             rc = umoe_grouped_gemm(&dn, s);

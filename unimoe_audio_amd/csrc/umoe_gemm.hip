@@ -121,8 +121,13 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
                     pf = pub.flags;
                     pe = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
                 }
-                if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS, pf, pe);
-                else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS, pf, pe);
+                unsigned long long* rsp = nullptr;
+                if constexpr (PUB && PRO == UMOE_PRO_RMSNORM) {   // the scale only (see router4_body rs_pub); no row flags
+                    rsp = pub.rs;
+                    pf = nullptr;
+                }
+                if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS, pf, pe, rsp);
+                else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, reinterpret_cast<float*>(smem) TL_PASS, pf, pe, rsp);
                 TL_EXIT(5);
             }
             return 1;
@@ -223,7 +228,10 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
     //    requested FIRST, the weight stream right behind them -- the tile is staged while the first chunk is in flight;
     //  * ragged groups: the activation addresses hang on device-produced tables (count -> offset -> gather list), so the
     //    weight stream goes first and overlaps that chain.
-    const bool ragged = PUB || XW == 2 || g.count || g.row_off || g.rows;   // (PUB / XW 2: weights first too -- the rows do not exist yet)
+    // (PUB / XW 2: weights first too -- the rows do not exist yet; PUB with the RMSNorm prologue: the RAW rows exist, only their scale
+    //  is handed over, so the rows are requested first like any static group's)
+    constexpr bool ROWS_HANDED = (PUB && PRO != UMOE_PRO_RMSNORM) || XW == 2;
+    const bool ragged = ROWS_HANDED || g.count || g.row_off || g.rows;
     // second register stage requested before the staging too (static groups): HBM has work queued for the whole prologue.
     // Only where the registers allow it without spilling (checked per instantiation with -S: private_segment_fixed_size 0).
     constexpr bool DEEP = false;   // measured: gate/up NT 14 35.3 -> 42.6 us, down 23.8 -> 29.8 us -- MORE bytes in flight made it slower
@@ -256,7 +264,7 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
         }
         __syncthreads();
     }
-    if constexpr (PUB) {
+    if constexpr (PUB && PRO != UMOE_PRO_RMSNORM) {
         // wait for the riders of THIS launch: lanes 0..count-1 of wave 0 poll one row flag each; bounded (a rider that never runs --
         // an admitted workgroup that is not resident -- ends the wait with the sticky error word set)
         if (tid < count) {
@@ -319,7 +327,7 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
 #pragma unroll
             for (int n = 0; n < 16; ++n) {
                 const int h = n >> 2, i = min(ib0 + sub + TPR * (n & 3), QW - 1);
-                if constexpr (PUB || XW == 2) {   // rows handed over inside this launch: every load of them is an sc1 load
+                if constexpr (ROWS_HANDED) {   // rows handed over inside this launch: every load of them is an sc1 load
                     typedef uint32_t u32x4_pub __attribute__((ext_vector_type(4)));
                     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.a), 0, XW == 2 ? 0x7fffffff : 16 * p.lda * 2, 0x00020000);
                     const u32x4_pub t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((arow * (long)p.lda + g.a_col_off + (h * Q8 + ia + i) * 8) * 2), 0, 16);
@@ -341,7 +349,28 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
                 __builtin_amdgcn_sched_barrier(0);
             }
             TL_MARK(KID, 9);
-            if (single) {
+            if (single && PUB) {
+                // the row's scale comes from its rider (one {rs, epoch} granule per row, umoe_router_dev.h rs_pub): every thread of the
+                // row polls that granule (two addresses per wave), bounded; the raw row is already in registers
+                if (tid < 4 * Q8) st16(nw_lds + tid * 16, nw1);
+                const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
+                typedef uint32_t u32x2_g __attribute__((ext_vector_type(2)));
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(pub.rs, 0, 8 * UMOE_EP_PARTS, 0x00020000);
+                umoe_gu32* err = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.err));
+                const unsigned long long t0 = wall_clock64();
+                u32x2_g gr = {0u, 0u};
+                for (unsigned spins = 0;; ++spins) {
+                    gr = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (valid ? r : row0) * 8, 0, 16);
+                    if ((int32_t)(gr[1] - epoch) >= 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((spins & 1023u) == 1023u && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 200000000ull)) {
+                        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                rs = __int_as_float((int)gr[0]);
+                __syncthreads();
+            } else if (single) {
                 float ss = 0.f;
                 if (TPR == 32 && Q8 == 64) {
                     // K = 2048 on 8 waves: the SAME summation tree as the router body (umoe_router_dev.h router4_body: lane l of wave h
@@ -617,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void wstream_gemm_rk(const umoe_gemm_args p
 // What the fusion buys: no launch boundary, and the down projection's weight stream starts while other workgroups still finish
 // gate/up -- as two launches the chip idled through the down projection's 7 us prologue.  Same tiles, same K split, same reduction
 // order as the two launches: bit-identical outputs.
+template <int GPRO>     // prologue of the gate/up GEMM: PLAIN = the riders hand the normalised rows over, RMSNORM = only their scales
 __global__ __launch_bounds__(512, 1) void moe_fused_kernel(const umoe_gemm_args pg, const umoe_group_pack gg, const umoe_gemm_args pd, const umoe_group_pack gd,
                                                             const umoe_router_args ra, const int rider_mode, const umoe_rider_pub pub, const umoe_fuse_x fx,
                                                             const int dn_per_group) {
@@ -624,9 +654,9 @@ __global__ __launch_bounds__(512, 1) void moe_fused_kernel(const umoe_gemm_args 
     const wg_coord b{blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x};
 #ifdef UMOE_TIMELINE
     tl_state tl_first;
-    if (wstream_body<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8, true, true, 1>(pg, gg, ra, rider_mode, pub, fx, b, smem, &tl_first)) return;
+    if (wstream_body<14, 1, GPRO, UMOE_EPI_SWIGLU, 8, true, true, 1>(pg, gg, ra, rider_mode, pub, fx, b, smem, &tl_first)) return;
 #else
-    if (wstream_body<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8, true, true, 1>(pg, gg, ra, rider_mode, pub, fx, b, smem)) return;
+    if (wstream_body<14, 1, GPRO, UMOE_EPI_SWIGLU, 8, true, true, 1>(pg, gg, ra, rider_mode, pub, fx, b, smem)) return;
 #endif
     // live index of this workgroup among the gate/up tiles -> its down-projection slice
     int li = (int)b.x;
@@ -753,7 +783,8 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
     UMOE_REQUIRE(gu && dn && flags, "umoe_moe_fused: null argument");
     const int G = gu->num_groups;
     if (!(gu->fused_router && gu->rider_pub && gu->groups_host && dn->groups_host && G == dn->num_groups && G <= UMOE_GROUPS_INLINE && gu->nt == 14 &&
-          dn->nt == 6 && gu->prologue == UMOE_PRO_PLAIN && gu->epilogue == UMOE_EPI_SWIGLU && dn->prologue == UMOE_PRO_PLAIN &&
+          dn->nt == 6 && (gu->prologue == UMOE_PRO_PLAIN || (gu->prologue == UMOE_PRO_RMSNORM && gu->max_k == 2048 && gu->norm_w)) &&
+          gu->epilogue == UMOE_EPI_SWIGLU && dn->prologue == UMOE_PRO_PLAIN &&
           dn->epilogue == UMOE_EPI_BF16 && gu->flat_wgs == 0 && gu->ksplit <= 1 && dn->ksplit <= 1 && gu->max_rows <= 16 && dn->max_rows <= 16 &&
           dn->a == gu->out && dn->lda == gu->ldo && !dn->fused_router && gu->max_k % 32 == 0 && dn->max_k % 32 == 0))
         return 1;
@@ -771,8 +802,10 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
     }
     if (dead < r->S || live < G * per || G * gx > flag_words) return 1;
     if (!(r->S <= 16 && r->n_dyn == 9 && r->n_fix == 2 && (r->D == 2048 || r->D == 4096) && r->x && r->gate_w && r->expert_mask && !r->logits_in &&
-          !r->norm_only && r->h_out == gu->a && r->norm_w))
+          !r->norm_only && r->norm_w))
         return 1;
+    const bool rs_mode = gu->prologue == UMOE_PRO_RMSNORM;      // the riders hand over the rows' scales, not the rows
+    if (rs_mode ? !(r->x == gu->a && r->norm_w == gu->norm_w && !r->h_out) : !(r->h_out == gu->a)) return 1;
     umoe_fuse_x fx;
     memset(&fx, 0, sizeof(fx));
     fx.flags = flags;
@@ -785,12 +818,13 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
         fx.prod_base[i] = j * gx;
         fx.prod_n[i] = ceil_div(gu->groups_host[j].n_blocks, 14);
     }
-    const size_t l1 = gemm_lds_bytes(gu->max_k, 14, 8, 1), l2 = gemm_lds_bytes(dn->max_k, 6, 8, 1), lds = l1 > l2 ? l1 : l2;
+    const size_t l1 = gemm_lds_bytes(gu->max_k, 14, 8, 1, gu->prologue), l2 = gemm_lds_bytes(dn->max_k, 6, 8, 1), lds = l1 > l2 ? l1 : l2;
     if (lds > 160 * 1024) return 1;
-    static size_t configured = 0;
-    if (lds > configured) {
-        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
+    static size_t configured[2] = {0, 0};
+    if (lds > configured[rs_mode]) {
+        if (rs_mode) UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_fused_kernel<UMOE_PRO_RMSNORM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_fused_kernel<UMOE_PRO_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[rs_mode] = lds;
     }
     umoe_group_pack gg, gd;
     memset(&gg, 0, sizeof(gg));
@@ -798,8 +832,9 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
     memcpy(gg.g, gu->groups_host, sizeof(umoe_group_t) * G);
     memcpy(gd.g, dn->groups_host, sizeof(umoe_group_t) * G);
     const umoe_rider_pub pub = *reinterpret_cast<const umoe_rider_pub*>(gu->rider_pub);
-    UMOE_REQUIRE(pub.flags && pub.step && pub.err, "umoe_moe_fused: rider_pub needs flags / step / err");
-    moe_fused_kernel<<<dim3((unsigned)gx, 1, (unsigned)G), 512, lds, s>>>(*gu, gg, *dn, gd, *r, /*rider_mode*/ 2, pub, fx, per);
+    UMOE_REQUIRE(pub.flags && pub.step && pub.err && (!rs_mode || pub.rs), "umoe_moe_fused: rider_pub needs flags / step / err (and rs)");
+    if (rs_mode) moe_fused_kernel<UMOE_PRO_RMSNORM><<<dim3((unsigned)gx, 1, (unsigned)G), 512, lds, s>>>(*gu, gg, *dn, gd, *r, /*rider_mode*/ 2, pub, fx, per);
+    else moe_fused_kernel<UMOE_PRO_PLAIN><<<dim3((unsigned)gx, 1, (unsigned)G), 512, lds, s>>>(*gu, gg, *dn, gd, *r, /*rider_mode*/ 2, pub, fx, per);
     UMOE_LAUNCH_CHECK();
     return 0;
 }

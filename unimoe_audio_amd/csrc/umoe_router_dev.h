@@ -379,7 +379,7 @@ __device__ __forceinline__ int route_from_logits(const umoe_router_args& a, cons
 // barrier, then lane 0 publishes `pub_epoch` in pub_flag[s] (hand-off form: cdna_hip_programming.md Guideline 16 R1).
 template <int ND, int NF, int TB, bool NORM_ONLY>
 __device__ __forceinline__ void router4_body(const umoe_router_args& a, const int s, const int tid, float* lds TL_PARAM,
-                                             uint32_t* pub_flag = nullptr, uint32_t pub_epoch = 0) {
+                                             uint32_t* pub_flag = nullptr, uint32_t pub_epoch = 0, unsigned long long* rs_pub = nullptr) {
 
     constexpr int NEc = ND + NF;
     constexpr int T = TB;
@@ -419,6 +419,15 @@ __device__ __forceinline__ void router4_body(const umoe_router_args& a, const in
         __syncthreads();
         ss = ((ss_part[0] + ss_part[1]) + ss_part[2]) + ss_part[3];
         rs = rsqrtf(ss / (float)a.D + a.rms_eps);
+        // rs_pub (riders of the fused expert launch, second hand-off form): instead of the normalised ROW only the row's scale leaves
+        // this workgroup -- ONE 8-byte write-through store {rs, epoch} (data and tag in one granule: no drain, no separate flag); the
+        // GEMM workgroups loaded the raw row at launch and finish the norm themselves with exactly this rs (the same bits)
+        if (rs_pub && tid == 0) {
+            typedef uint32_t u32x2_g __attribute__((ext_vector_type(2)));
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(rs_pub, 0, 8 * UMOE_EP_PARTS, 0x00020000);
+            const u32x2_g g2 = {(uint32_t)__float_as_int(rs), pub_epoch};
+            __builtin_amdgcn_raw_buffer_store_b64(g2, rsrc, s * 8, 0, 16);
+        }
     }
     TL_MARK(5, 5);
     float acc[UMOE_MAXE];
