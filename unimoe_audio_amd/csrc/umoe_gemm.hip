@@ -21,6 +21,9 @@
 #include "umoe_router_dev.h"
 #include "umoe_riders_dev.h"
 #include <string.h>
+#ifndef UMOE_POLLER_WAVE
+#define UMOE_POLLER_WAVE 0     // build-time A/B of the poller wave (see wstream_body): measured 3.094-3.11 vs 3.075-3.087 ms/step -- off
+#endif
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------ packing
@@ -235,7 +238,13 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
     // second register stage requested before the staging too (static groups): HBM has work queued for the whole prologue.
     // Only where the registers allow it without spilling (checked per instantiation with -S: private_segment_fixed_size 0).
     constexpr bool DEEP = false;   // measured: gate/up NT 14 35.3 -> 42.6 us, down 23.8 -> 29.8 us -- MORE bytes in flight made it slower
-    if (ragged && i0 < i1) load_chunk(w0, i0);
+    // The POLLER (experiment, off): a wave's loads return in issue order, so a flag poll issued behind the wave's own weight chunk
+    // comes back only when that chunk has landed; the last wave polled FIRST, with nothing in its queue, and requested its first chunk
+    // only when the rows were there.  Result (scripts/timeline_wgs.py): detection did NOT get earlier (rows staged 7.4 vs 6.6 us after
+    // entry, riders' flag stored at 3.3 us either way) -- the 3 us between flag store and detection are the memory system's latency
+    // under the weight stream (write-through of the flag, the poll's own round trip), not the wave's queue.
+    const bool poller = ROWS_HANDED && UMOE_POLLER_WAVE && wave == WV - 1;
+    if (ragged && i0 < i1 && !poller) load_chunk(w0, i0);
     // (XW 2: measured on the fused expert launch, 300 decode steps: second register stage requested here, in front of the wait for
     //  the producers, 3.26-3.29 ms/step; right behind the rows 3.26-3.28; a THIRD stage in front of the wait 3.40-3.43 -- more bytes
     //  in flight per CU made the launch slower, as in the two-launch form)
@@ -248,7 +257,8 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
     if constexpr (XW == 2) {
         // wait for the workgroups of THIS launch that produced this group's rows: lane i of wave 0 polls producer i's flag (bounded)
         const int np = fx.prod_n[zg];
-        if (tid < np) {
+        if (UMOE_POLLER_WAVE ? (poller && lane < np) : (tid < np)) {
+            const int tid = lane;      // (flag index of this lane)
             const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
             umoe_gu32* f = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(fx.flags + fx.prod_base[zg] + tid));
             umoe_gu32* err = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.err));
@@ -262,12 +272,14 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
                 }
             }
         }
+        if (poller && i0 < i1) load_chunk(w0, i0);
         __syncthreads();
     }
     if constexpr (PUB && PRO != UMOE_PRO_RMSNORM) {
         // wait for the riders of THIS launch: lanes 0..count-1 of wave 0 poll one row flag each; bounded (a rider that never runs --
         // an admitted workgroup that is not resident -- ends the wait with the sticky error word set)
-        if (tid < count) {
+        if (UMOE_POLLER_WAVE ? (poller && lane < count) : (tid < count)) {
+            const int tid = lane;      // (row of this lane)
             const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
             umoe_gu32* f = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.flags + row0 + tid));
             umoe_gu32* err = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.err));
@@ -281,6 +293,7 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
                 }
             }
         }
+        if (poller && i0 < i1) load_chunk(w0, i0);
         __syncthreads();
     }
 
