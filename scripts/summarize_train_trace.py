@@ -6,6 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = defaultdict(lambda: [0, 0])
 for r in rows:
     n = r["Kernel_Name"].replace("void ", "")
+    n = n.replace("(anonymous namespace)::", "")
     n = n[: n.index("(")] if "(" in n else n[:70]
     agg[n][0] += 1
     agg[n][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])

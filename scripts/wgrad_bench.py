@@ -61,3 +61,30 @@ for name, fn in (("wide window (k_off / k_count on device)", wide), ("wide windo
                  ("compact, 8 launches", dense8)):
     t = timeit(fn)
     print(f"{name}: {t:.1f} us  {fl / t / 1e6:.0f} TFLOP/s", flush=True)
+
+# ---- the ragged-ROW grouped products of the same layer (forward down projection: rows of every expert, N = 2048, K = 2752) ----
+S = 6240
+cnt_list = [2810] * G
+tot_rows = sum((c + 7) & ~7 for c in cnt_list)
+hbuf = torch.randn(tot_rows, I, device=dev).to(bf)
+wd = [torch.randn(D, I, device=dev).to(bf) for _ in range(G)]
+yb = torch.empty(tot_rows, D, device=dev, dtype=bf)
+counts = torch.tensor(cnt_list, device=dev, dtype=torch.int32)
+offsets = torch.tensor([sum((c + 7) & ~7 for c in cnt_list[:g]) for g in range(G)], device=dev, dtype=torch.int32)
+fl2 = 2.0 * sum(cnt_list) * D * I
+
+
+def ragged_rows(max_rows):
+    groups = [dict(w=wd[g], count=counts[g:g + 1], row_off=offsets[g:g + 1]) for g in range(G)]
+    ops.tiled_gemm(groups, hbuf, yb, max_rows=max_rows)
+
+
+def static_rows():
+    groups = [dict(w=wd[g], static_count=cnt_list[g], a_row_base=int(offsets[g]), out_row_base=int(offsets[g])) for g in range(G)]
+    ops.tiled_gemm(groups, hbuf, yb, max_rows=max(cnt_list))
+
+
+for name, fn in (("down fwd, ragged rows, max_rows 6240", lambda: ragged_rows(S)), ("down fwd, ragged rows, max_rows 2816", lambda: ragged_rows(2816)),
+                 ("down fwd, static rows", static_rows)):
+    t = timeit(fn)
+    print(f"{name}: {t:.1f} us  {fl2 / t / 1e6:.0f} TFLOP/s", flush=True)

@@ -839,6 +839,13 @@ def test_codec_embed_sum_bwd_vs_index_add(dev, rows, C, V, D):
     out.backward(dy.to(dev))
     for c in range(C):
         assert torch.equal(tabs[c].grad.cpu(), got[c])
+    # the single-table form (text embedding, model.py:655) through the same kernel
+    tab = torch.randn(V, D, generator=g).to(torch.bfloat16).to(dev).requires_grad_(True)
+    ids = tok[:, 0].reshape(1, rows).to(dev)
+    e = TR.EmbedFn.apply(ids, tab)
+    assert torch.equal(e.cpu(), tab.detach().cpu()[tok[:, 0]].reshape(1, rows, D))
+    e.backward(dy.to(dev).reshape(1, rows, D))
+    assert torch.equal(tab.grad.cpu(), got[0])
 
 
 @pytest.mark.parametrize("T,H,KVH,pads", [(333, 16, 2, (70, 0)), (64, 4, 4, (0, 5)), (17, 2, 1, (3, 0)), (1560, 16, 2, (0, 40))])
