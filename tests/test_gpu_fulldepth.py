@@ -67,10 +67,11 @@ def _save(key, rec):
     json.dump(allr, open(RESULTS, "w"), indent=1)
 
 
-@pytest.mark.parametrize("B", [8, 1])
-def test_full_depth_teacher_forced_decode_vs_oracle(full_model, B):
-    """B = 8: 16 CFG rows, dense-expert layout with the router riders (BASELINE configs[1]); B = 1: 2 rows, ragged dispatch
-    tables (configs[0])."""
+@pytest.mark.parametrize("B,ragged", [(8, False), (1, False), (1, True)])
+def test_full_depth_teacher_forced_decode_vs_oracle(full_model, B, ragged, monkeypatch):
+    """B = 8: 16 CFG rows, dense-expert layout with the router riders and the fused expert launch (BASELINE configs[1]); B = 1: 2 rows
+    (configs[0]), in the dense layout (the default from 2 rows) and through the ragged dispatch tables (UMOE_DENSE_MIN_ROWS=6)."""
+    monkeypatch.setenv("UMOE_DENSE_MIN_ROWS", "6" if ragged else "2")
     from oracle import decode as OD
     from unimoe_audio_amd.codec_utils import prepare_audio_prompt
     from unimoe_audio_amd.model import DecodeEngine
@@ -176,7 +177,7 @@ def test_full_depth_teacher_forced_decode_vs_oracle(full_model, B):
                                 "router_mask_agree_by_depth": [round(float(mask_rows[i:i + 6].mean()), 4) for i in range(0, Lyr, 6)],
                                 "rows_identical_routing_all_layers": int(sum(1 for f in first_bad if f == Lyr))})
     print("\nFULL-DEPTH PARITY", json.dumps(rec))
-    _save(f"batch{B}", rec)
+    _save(f"batch{B}" + ("_ragged" if ragged else ""), rec)
     med = max(p["logit_rel_median"] for p in rec["per_step"])
     mx = max(p["logit_rel_max"] for p in rec["per_step"])
     agree = min(p["argmax_agree"] for p in rec["per_step"])

@@ -89,6 +89,9 @@ struct umoe_engine {
                                  // the launch boundary it removes; the combine in the QKV launch (fuse_cq) wins: 3.08 vs 3.13
     bool cb_pending = false;     // a combine stashed at the end of a layer, issued with the next layer's QKV launch
     umoe_combine_args cb_stash{};
+    int dense_min_rows = 2;      // UMOE_DENSE_MIN_ROWS: fewest decode rows that take the dense-expert layout (below: ragged dispatch).  Batch 1
+                                 // (2 CFG rows, BASELINE configs[0]) hits 5-6 of the 8 experts: streaming all 8 in the fused launches costs
+                                 // fewer microseconds than the ragged path's four extra launches -- 2.91 vs 3.33 ms/step
     bool fuse_moe = true;        // UMOE_FUSE_MOE: gate/up and down projections of a dense decode layer in ONE launch (umoe_moe_fused)
     bool gu_norm = false;        // UMOE_GU_NORM: the gate/up workgroups normalise x1 in their staging prologue (no hand-off, no norm launch)
     bool rider_pub = true;       // UMOE_RIDER_PUB: the riders also produce the normalised rows and hand them to the GEMM workgroups of the
@@ -190,7 +193,7 @@ static int ensure_workspace(umoe_engine* e, int n_tok) {
 // group table for a pass over n_tok tokens
 static bool dense_mode(const umoe_engine* e, int n_tok) {
     if (e->ep_decode(n_tok)) return true;   // expert parallel decode IS the dense layout: every rank's rows visit every expert
-    return e->dense_experts && n_tok == e->c.rows && n_tok <= 16 && n_tok >= 6 && !e->overlap_shared;
+    return e->dense_experts && n_tok == e->c.rows && n_tok <= 16 && n_tok >= e->dense_min_rows && !e->overlap_shared;
 }
 
 static int build_groups(umoe_engine* e, int n_tok, hipStream_t s) {
@@ -346,6 +349,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (const char* v = getenv("UMOE_RIDER_PUB")) e->rider_pub = atoi(v) != 0;
     if (const char* v = getenv("UMOE_GU_NORM")) e->gu_norm = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_MOE")) e->fuse_moe = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_DENSE_MIN_ROWS")) e->dense_min_rows = atoi(v);
     if (const char* v = getenv("UMOE_FUSE_CQ")) e->fuse_cq = atoi(v) != 0;
     if (const char* v = getenv("UMOE_RS_HANDOFF")) e->rs_handoff = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_AO")) e->fuse_ao = atoi(v) != 0;
