@@ -138,3 +138,88 @@ def test_ep_index_math_single_process():
                 assert torch.equal(y_back[int(so[s, e])], h[s] * 2.0)
             else:
                 assert int(so[s, e]) == -1
+
+
+def _grad_worker(rank, world, port, S, out_q):
+    """Expert-parallel block under autograd: gradients of the own rows and of the LOCAL experts' weights (which collect the
+    contributions of every rank's rows through the backward of the exchange) against single-process autograd over all rows."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import router as OR
+        from oracle.dcmoe import EXPERT_FMT
+        from unimoe_audio_amd import ep as EP
+        w = _weights(_cfg(), 5)
+        n_real, n_dyn, n_fix, D = 8, 9, 2, 64
+        E_loc = n_real // world
+        params = {}
+        for e in range(n_real):
+            for p in ("gate", "up", "down"):
+                params[(e, p)] = w[EXPERT_FMT.format(e=e, p=p)].float().clone().requires_grad_(True)
+
+        def mlp(e, x):      # fp32 SwiGLU (the gradient check is about the exchange, not about bf16 rounding points)
+            return torch.nn.functional.linear(torch.nn.functional.silu(torch.nn.functional.linear(x, params[(e, "gate")])) *
+                                              torch.nn.functional.linear(x, params[(e, "up")]), params[(e, "down")])
+        hs, rs, gs = [], [], []
+        for r in range(world):       # every rank builds every rank's inputs (the single-process reference needs them all)
+            g = torch.Generator().manual_seed(200 + r)
+            hs.append(torch.randn(S, D, generator=g))
+            logits = torch.nn.functional.linear(hs[-1].to(torch.bfloat16), w["gate.weight"])
+            rs.append(OR.route(logits, n_dyn, n_real, n_fix, 0.7, 0, 0.01, None))
+            gs.append(torch.randn(S, D, generator=g))
+        h = hs[rank].clone().requires_grad_(True)
+        r = rs[rank]
+        d = OR.dispatch(r["expert_mask"], n_real)
+        disp = dict(counts=d["counts"], offsets=d["offsets"], slot_token=torch.cat([d["slot_token"], torch.zeros(1, dtype=torch.int32)]),
+                    slot_of=d["slot_of"])
+
+        def expert_fn(recv, cnt):
+            y = torch.zeros_like(recv)
+            for e_loc in range(E_loc):
+                y[:, :, e_loc] = mlp(rank * E_loc + e_loc, recv[:, :, e_loc])          # zero rows in -> zero rows out (no bias)
+            return y
+        y_back, so = EP.ep_moe(h, disp, n_real, world, dist.group.WORLD, expert_fn)
+        out = EP.ep_combine(y_back, so, r["moe_weight"].float())
+        (out * gs[rank]).sum().backward()
+        got_dh = h.grad.clone()
+        got_dw = {k: v.grad.clone() for k, v in params.items() if k[0] // E_loc == rank}
+        for v in params.values():
+            v.grad = None
+        # single-process reference over ALL ranks' rows
+        href = [x.clone().requires_grad_(True) for x in hs]
+        tot = 0.0
+        for q in range(world):
+            mw = rs[q]["moe_weight"].float()
+            acc = torch.zeros(S, D)
+            for e in range(n_real):
+                sel = (rs[q]["expert_mask"][:, e] != 0).float()[:, None]
+                acc = acc + sel * mw[:, e:e + 1] * mlp(e, href[q])
+            tot = tot + (acc * gs[q]).sum()
+        tot.backward()
+        ok = torch.allclose(got_dh, href[rank].grad, rtol=1e-4, atol=1e-5)
+        err = float((got_dh - href[rank].grad).abs().max())
+        for k, v in got_dw.items():
+            ok = ok and torch.allclose(v, params[k].grad, rtol=1e-4, atol=1e-5)
+            err = max(err, float((v - params[k].grad).abs().max()))
+        out_q.put((rank, bool(ok), err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ep_exchange_backward_world2_gloo():
+    """The exchange as an autograd node (ep._AllToAll = DeepSpeed's _AllToAll, core.py:467,480): d(own rows) and d(local experts'
+    weights, summed over the rows of BOTH ranks) equal single-process autograd."""
+    import random
+    port = random.randint(20000, 40000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, 7, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res

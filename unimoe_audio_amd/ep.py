@@ -66,6 +66,23 @@ def _a2a(out: torch.Tensor, inp: torch.Tensor, group):
     return out
 
 
+class _AllToAll(torch.autograd.Function):
+    """The exchange as an autograd node (DeepSpeed's `_AllToAll`, deepspeed 0.15.1 moe/sharded_moe.py, used at core.py:467,480):
+    forward = the all-to-all of equal slabs, backward = the SAME all-to-all applied to the gradient (the exchange is a permutation of
+    slabs across ranks and its own transpose)."""
+
+    @staticmethod
+    def forward(ctx, group, inp):
+        ctx.group = group
+        inp = inp.contiguous()
+        return _a2a(torch.empty_like(inp), inp, group)
+
+    @staticmethod
+    def backward(ctx, grad):
+        grad = grad.contiguous()
+        return None, _a2a(torch.empty_like(grad), grad, ctx.group)
+
+
 def ep_pack(h: torch.Tensor, counts: torch.Tensor, offsets: torch.Tensor, slot_token: torch.Tensor, n_real: int,
             ep_size: int):
     """Builds the send buffers: send [ep(dst), S(pos), E_loc, D] (rows of expert e compacted at positions < count[e]) and
@@ -89,8 +106,7 @@ def ep_dispatch(h: torch.Tensor, counts: torch.Tensor, offsets: torch.Tensor, sl
     Returns recv [ep(src), S(pos), E_loc, D] and recv_cnt [ep(src), E_loc]: the rows rank `src` routed to MY experts,
     compacted per expert (positions >= count are zero rows).  First all-to-all of the reference (core.py:467)."""
     send, send_cnt = ep_pack(h, counts, offsets, slot_token, n_real, ep_size)
-    recv = torch.empty_like(send)
-    _a2a(recv, send, group)
+    recv = _AllToAll.apply(group, send)          # (an autograd node: the training path differentiates through the exchange)
     recv_cnt = torch.empty_like(send_cnt)
     _a2a(recv_cnt, send_cnt, group)
     return recv, recv_cnt
@@ -107,8 +123,7 @@ def ep_recv_mask(recv_cnt: torch.Tensor, S: int) -> torch.Tensor:
 def ep_return(y: torch.Tensor, group=None) -> torch.Tensor:
     """y [ep(src), S, E_loc, D] expert outputs for the rows received -> [ep(owner), S, E_loc, D] on the token owner
     (second all-to-all, core.py:480)."""
-    out = torch.empty_like(y)
-    return _a2a(out, y.contiguous(), group)
+    return _AllToAll.apply(group, y)
 
 
 def ep_slot_of(slot_of: torch.Tensor, offsets: torch.Tensor, S: int, ep_size: int) -> torch.Tensor:
@@ -131,6 +146,18 @@ def ep_moe(h: torch.Tensor, disp: dict, n_real: int, ep_size: int, group,
     y = expert_fn(recv, recv_cnt)
     back = ep_return(y, group)
     return back.reshape(-1, back.shape[-1]), ep_slot_of(disp["slot_of"], disp["offsets"], S, ep_size)
+
+
+def ep_combine(y_back: torch.Tensor, slot_of_ep: torch.Tensor, moe_w: torch.Tensor) -> torch.Tensor:
+    """sum_e moe_w[s, e] * y_back[slot_of_ep[s, e]] in ascending expert order with fp32 accumulation and one rounding (the
+    single-GPU combine, core.py:488 + :342), as differentiable torch ops: the training path of an expert-parallel block."""
+    S, n_real = slot_of_ep.shape
+    acc = torch.zeros((S, y_back.shape[-1]), dtype=torch.float32, device=y_back.device)
+    for e in range(n_real):
+        so = slot_of_ep[:, e].long()
+        sel = (so >= 0).to(torch.float32)[:, None]
+        acc = acc + sel * moe_w[:, e:e + 1].float() * y_back[so.clamp(min=0)].float()
+    return acc.to(y_back.dtype)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
