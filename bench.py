@@ -130,6 +130,9 @@ def decode_leg(model, cfg, args, device, rank, B, ep=None, profile=True, steps=N
     tokens = eng.tokens[:, : K + W + 2].cpu().clone()
     prof = eng.profile_steps(4) if profile else None
     err = eng.ep_error() if ep is not None else 0
+    hand = eng.handoff_error()
+    if hand and not (ep is not None and hand == 1):
+        raise SystemExit(f"bench.py: an in-launch hand-off of the decode engine timed out (code {hand}): the numbers would be of a broken run")
     if ep is not None:
         barrier()                     # peers may still be reading this rank's exchange region
     info = dict(dt=dt, t_prefill=t_prefill, mean_experts_hit=float(hit.mean()), mean_top_k=float(topk.mean()), prof=prof,

@@ -572,8 +572,16 @@ class DecodeEngine:
             self.steps_run += 1
         return {k: (ms[i] / max(cnt[i], 1), cnt[i] // n) for i, k in enumerate(self.KINDS)}
 
+    def handoff_error(self) -> int:
+        """Sticky error word of the in-launch hand-offs (0 = none; 1 = an expert-parallel receive, 2 = the riders' rows, 3 = an expert's
+        SwiGLU rows were not published within the bounded wait -- e.g. a workgroup of a fused launch was not resident)."""
+        return int(self.copy_buffer("ep_words", torch.int32, (2,))[1].item())
+
     def all_done(self) -> bool:
         done = bool(int(self.state[4 * self.batch + 2].item()))
+        code = self.handoff_error()            # (the host is synchronised here anyway: fail loudly instead of decoding on stale rows)
+        if code and not (self.ep is not None and code == 1):     # (an EP receive timeout is the caller's to handle: ep_error())
+            raise L.UmoeError(f"decode engine: an in-launch hand-off timed out (code {code}); UMOE_RIDER_PUB=0 selects the launch-per-kernel path")
         if self.ep is not None and self.ep.size > 1 and self.ep.mode != "loopback" and self.ep.group is not False:
             # expert parallel: every rank keeps stepping until ALL are done (a rank that stopped would starve its peers' receives)
             import torch.distributed as dist
