@@ -430,7 +430,8 @@ __device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const 
 //        phases earlier, i.e. also the lagging group has retired those reads (lgkmcnt) before any wave issues the DMA.
 //   Tiles beyond K are staged from the zero block, so the vmcnt arithmetic is the same in every iteration.
 template <int EPI, int PRIO, int NS>
-__global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args p, const tg_pack gp, const int epi_lds_mask, const int nx, const int ny, const int nz, const int ragged_order) {
+__global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args p, const tg_pack gp, const int epi_lds_mask, const int nx, const int ny, const int nz, const int ragged_order,
+                                                           const unsigned total_wgs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef UMOE_PP_STAMPS
     const unsigned long long t_entry = clock64(), w_entry = wall_clock64();
@@ -448,18 +449,23 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     //    groups and token tiles; the grid is padded to a multiple of 8 row tiles), sweeping the nx column tiles of a row tile
     //    before the next -- every XCD gets row tiles of EVERY expert (contiguous ranges would put one expert on one XCD
     //    and let the largest expert set the time; measured in the training step: 228 -> 201 us per launch).
+    // PERSISTENT tiles (launches whose tiles are all live: grid = one workgroup per CU, total_wgs > gridDim.x): a workgroup walks the
+    // tiles lin = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8, so lin % 8 stays this workgroup's XCD and the maps below
+    // hold).  The epilogue's stores are not waited for: they drain while the next tile's first operand tiles are already on their way.
+    for (unsigned lin_it = blockIdx.x; lin_it < total_wgs; lin_it += gridDim.x) {
+    if (lin_it != blockIdx.x) __syncthreads();       // (the previous tile's LDS epilogue scratch is the ring the DMA is about to fill)
     int bx, by, bz;
     {
-        const unsigned lin = blockIdx.x, xcd = lin & 7, seq = lin >> 3;
+        const unsigned lin = lin_it, xcd = lin & 7, seq = lin >> 3;
         if (ragged_order) {
             const unsigned rr = seq / (unsigned)nx;
             bx = (int)(seq - rr * (unsigned)nx);
             const unsigned RR = rr * 8 + xcd;
-            if (RR >= (unsigned)(ny * nz)) return;       // padding row tiles
+            if (RR >= (unsigned)(ny * nz)) continue;       // padding row tiles
             bz = (int)(RR / (unsigned)ny);
             by = (int)(RR - (unsigned)bz * (unsigned)ny);
         } else {
-            const unsigned nwg = gridDim.x, q = nwg >> 3, r = nwg & 7;
+            const unsigned nwg = total_wgs, q = nwg >> 3, r = nwg & 7;
             const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
             bx = (int)(id % (unsigned)nx);
             const unsigned RR = id / (unsigned)nx;
@@ -471,9 +477,9 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
     const int count = g.count ? *g.count : g.static_count;
     const int roff = g.row_off ? *g.row_off : 0;
     const int row0 = by * 256;
-    if (row0 >= count) return;
+    if (row0 >= count) continue;
     const int n0 = bx * NTILE;
-    if (n0 >= g.n) return;
+    if (n0 >= g.n) continue;
     const int koff = g.k_off ? *g.k_off : 0;
     const int K = g.k_count ? ((*g.k_count + 7) & ~7) : g.k;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -653,13 +659,14 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
                 o[12] = t_entry; o[13] = clock64(); o[14] = w_entry; o[15] = wall_clock64();
             }
 #endif
-            return;
+            continue;
         }
     }
     int fbase[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) fbase[j] = n0 + (SW ? 32 * wc + 16 * (j & 1) : wrow[j]);
     tg_epilogue<EPI, 8>(p, g, acc, count, roff, row0 + 128 * wr, fbase, lane);
+    }   // persistent tile loop
 }
 
 template <int EPI, int PRIO, int NS>
@@ -682,7 +689,18 @@ static int launch_tgemm_pp_v(const umoe_tgemm_args* a, int max_n, hipStream_t s)
     for (int i = 0; i < a->num_groups; ++i) ragged |= a->groups[i].count != nullptr || (a->groups[i].k_count != nullptr && a->num_groups > 1);
     const long nwg = ragged ? (long)nx * (((long)ny * nz + 7) & ~7L) : (long)nx * ny * nz;
     UMOE_REQUIRE(nwg < (1L << 31), "umoe_tiled_gemm: too many tiles (%ld)", nwg);
+    // persistent tiles where every tile is live (no device-side row counts: empty tiles would unbalance a static walk, the hardware
+    // dispatcher balances those launches): one workgroup per CU
+    int rows_on_device = 0;
+    for (int i = 0; i < a->num_groups; ++i) rows_on_device |= a->groups[i].count != nullptr;
+    static int persist = -1;
+    if (persist < 0) {
+        const char* v = getenv("UMOE_TGEMM_PERSIST");
+        persist = v ? atoi(v) : 0;      // off: measured in the training step 254-259 vs 248-249 ms -- the hardware dispatcher's dynamic placement of
+                                        // one-tile workgroups beats a static walk (codec head 1225 tiles: 331 vs 329 us)
+    }
     dim3 grid((unsigned)nwg);
+    if (!rows_on_device && persist >= 8 && nwg > persist) grid = dim3((unsigned)(persist & ~7));
     // which bf16 epilogues go through LDS (bit 0 plain, 1 residual, 2 SwiGLU).  Measured at 6240 rows (scripts/kbench.py tiled):
     // residual 621 -> 833 TFLOP/s (the residual is read in whole rows too), SwiGLU +2 %, plain -5 % (stays direct)
     static int mask = -1;
@@ -690,7 +708,7 @@ static int launch_tgemm_pp_v(const umoe_tgemm_args* a, int max_n, hipStream_t s)
         const char* v = getenv("UMOE_TGEMM_EPI_LDS");
         mask = v ? atoi(v) : 6;
     }
-    tgemm_pp_kernel<EPI, PRIO, NS><<<grid, 512, lds, s>>>(*a, gp, mask, nx, ny, nz, ragged);
+    tgemm_pp_kernel<EPI, PRIO, NS><<<grid, 512, lds, s>>>(*a, gp, mask, nx, ny, nz, ragged, (unsigned)nwg);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
