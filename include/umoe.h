@@ -305,6 +305,9 @@ int umoe_transpose_slots(const uint16_t* src, int ld_src, int C, const int32_t* 
 
 /* SwiGLU backward, core.py:31,49: gu [rows][2I] = (gate | up) pre-activations saved by the forward
  * (umoe_tgemm_args.aux_out), dh [rows][I] -> dgu [rows][2I] = (dgate | dup).  total_rows: device scalar or NULL. */
+/* y[i] = bf16(float(x[i]) * noise[i]): the training-time input jitter on the gate's copy of the rows (core.py:240-244: the reference
+ * multiplies a float copy and casts back) in one pass instead of three elementwise launches.  n % 8 == 0. */
+int umoe_mul_noise(const uint16_t* x, const float* noise, long n, uint16_t* y, umoe_stream_t stream);
 int umoe_swiglu_bwd(const uint16_t* dh, int ld_dh, const uint16_t* gu, int ld_gu, int I, const int32_t* total_rows,
                     int max_rows, uint16_t* dgu, int ld_dgu, umoe_stream_t stream);
 

@@ -814,6 +814,15 @@ def test_dense_gateup_flat_slices_equal_per_group_grid(dev, fw):
     assert float(a[:8 * S].float().abs().sum()) > 0 and float(a[8 * S:, :Is].float().abs().sum()) > 0
 
 
+def test_mul_noise_is_the_three_torch_ops(dev):
+    """umoe_mul_noise == (x.float() * noise).to(bfloat16), bit for bit (core.py:240-244 input jitter on the gate's copy)."""
+    from unimoe_audio_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(333, 2048, generator=g).to(torch.bfloat16).to(dev)
+    nz = torch.empty(333, 2048).uniform_(0.99, 1.01, generator=g).to(dev)
+    assert torch.equal(ops.mul_noise(x, nz), (x.float() * nz).to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("rows,C,V,D", [(700, 12, 1027, 2048), (37, 3, 19, 64), (20000, 2, 11, 256)])
 def test_codec_embed_sum_bwd_vs_index_add(dev, rows, C, V, D):
     """umoe_codec_embed_sum_bwd (gradient of the stacked codec embedding tables, model.py:655-661 under autograd) against an fp64

@@ -126,7 +126,7 @@ EXPORTS = [
     "umoe_last_error", "umoe_abi_version", "umoe_packed_elems", "umoe_pack_weight", "umoe_pack_gate_up",
     "umoe_router_fwd", "umoe_router_dispatch_fwd", "umoe_dispatch_build", "umoe_aux_loss_fwd", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd", "umoe_shared_swiglu_fwd", "umoe_attn_prefill_fwd",
     "umoe_unpermute_combine_fwd", "umoe_rmsnorm_residual_fwd", "umoe_qkv_mrope_kvappend", "umoe_attn_decode",
-    "umoe_codec_embed_sum", "umoe_codec_embed_sum_bwd", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
+    "umoe_codec_embed_sum", "umoe_codec_embed_sum_bwd", "umoe_mul_noise", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_codec_ce_fwd", "umoe_codec_ce_bwd", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
     "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
     "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm", "umoe_dispatch_build_aligned", "umoe_transpose_slots", "umoe_swiglu_bwd",
@@ -213,6 +213,7 @@ def lib():
         L.umoe_attn_prefill_fwd.argtypes = [C.POINTER(AttnArgs), vp]
         L.umoe_codec_embed_sum.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
         L.umoe_codec_embed_sum_bwd.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+        L.umoe_mul_noise.argtypes = [vp, vp, C.c_long, vp, vp]
         L.umoe_codec_head_cfg_sample.argtypes = [C.POINTER(SampleArgs), vp]
         L.umoe_delay_step.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
         L.umoe_rvq_from_codes.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]

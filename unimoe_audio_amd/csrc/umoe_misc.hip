@@ -372,6 +372,28 @@ extern "C" int umoe_codec_embed_sum_bwd(const int32_t* tok, const uint16_t* d_ou
     return 0;
 }
 
+// ------------------------------------------------------------------------------------ input jitter
+__global__ __launch_bounds__(256) void mul_noise_kernel(const uint16_t* __restrict__ x, const float* __restrict__ nz, long n8, uint16_t* __restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float f[8];
+        unpack8(ld16(x + i * 8), f);
+        const float4 a = *reinterpret_cast<const float4*>(nz + i * 8), b = *reinterpret_cast<const float4*>(nz + i * 8 + 4);
+        f[0] *= a.x; f[1] *= a.y; f[2] *= a.z; f[3] *= a.w; f[4] *= b.x; f[5] *= b.y; f[6] *= b.z; f[7] *= b.w;
+        st16(y + i * 8, pack8(f));
+    }
+}
+
+extern "C" int umoe_mul_noise(const uint16_t* x, const float* noise, long n, uint16_t* y, umoe_stream_t stream) {
+    UMOE_REQUIRE(x && noise && y && n >= 0 && n % 8 == 0 && ((size_t)x & 15) == 0 && ((size_t)noise & 15) == 0 && ((size_t)y & 15) == 0,
+                 "umoe_mul_noise: n %% 8 == 0 and 16-byte aligned pointers");
+    if (n == 0) return 0;
+    const long n8 = n / 8;
+    const unsigned wgs = (unsigned)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+    mul_noise_kernel<<<wgs, 256, 0, (hipStream_t)stream>>>(x, noise, n8, y);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------ CFG + sampler
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {  // splitmix64 finaliser
     z += 0x9e3779b97f4a7c15ull;

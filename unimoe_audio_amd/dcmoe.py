@@ -326,7 +326,7 @@ class _DCMoETrainFn(torch.autograd.Function):
         if blk.training and blk.input_jitter_noise > 0:
             noise = torch.empty((S, D), dtype=torch.float32, device=x.device).uniform_(1.0 - blk.input_jitter_noise,
                                                                                        1.0 + blk.input_jitter_noise)
-            xg = (x.float() * noise).to(torch.bfloat16)
+            xg = ops.mul_noise(x, noise) if (S * D) % 8 == 0 else (x.float() * noise).to(torch.bfloat16)
         gmb, ru = blk._mixer_noise(S, x.device)
         r = ops.router_fwd(xg, gate_w, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, top_p=float(blk.mlp_dynamic_top_p),
                            fixed_top_k=int(blk.mlp_dynamic_top_k), jitter_eps=float(blk.router_jitter_noise),
@@ -413,14 +413,15 @@ class _DCMoETrainFn(torch.autograd.Function):
         dl16 = torch.zeros((S, 16), dtype=bf, device=dev)
         dl16[:, :E] = d_lg.to(bf)
         noise = ctx.noise
-        xT = ops.transpose((x.float() * noise).to(bf) if noise is not None else x)   # [D][Sp]; the gate saw the jittered input
+        jit = (lambda t: ops.mul_noise(t, noise)) if (noise is not None and noise.numel() % 8 == 0) else (lambda t: (t.float() * noise).to(bf))
+        xT = ops.transpose(jit(x) if noise is not None else x)              # [D][Sp]; the gate saw the jittered input
         dlT = ops.transpose(dl16)                                            # [16][Sp]
         dWgate = torch.empty((16, D), dtype=bf, device=dev)
         ops.tiled_gemm([dict(w=xT, static_count=16)], dlT, dWgate, max_rows=16)
         grads[0] = dWgate[:E]
         dx_router = ops.tlinear(dl16, ops.transpose(params[0]))              # [S][16] x [D][16]^T
         if noise is not None:
-            dx_router = (dx_router.float() * noise).to(bf)
+            dx_router = jit(dx_router)
         # 7. input gradient: slot rows back to tokens + shared experts + router
         dx = ops.permute_bwd(dxe, disp["slot_of"], dxe[cap:] if n_fix else None, n_fix, extra=dx_router)
         return (None, dx, None, None, *[gr.contiguous() if gr is not None else None for gr in grads])

@@ -334,6 +334,16 @@ def codec_embed_sum(tok: torch.Tensor, emb: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def mul_noise(x: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """bf16(x.float() * noise) in one pass (training-time input jitter, core.py:240-244)."""
+    x = x.contiguous()
+    noise = noise.contiguous()
+    assert x.dtype == torch.bfloat16 and noise.dtype == torch.float32 and x.shape == noise.shape
+    y = torch.empty_like(x)
+    L.check(L.lib().umoe_mul_noise(_p(x), _p(noise), x.numel(), _p(y), _stream()), "umoe_mul_noise")
+    return y
+
+
 def codec_embed_sum_bwd(tok: torch.Tensor, d_out: torch.Tensor, V: int) -> torch.Tensor:
     """[C][V][D] gradient of the stacked codec embedding tables (deterministic: ascending row order, fp32 accumulation)."""
     rows, Cc = tok.shape
