@@ -823,7 +823,7 @@ def test_mul_noise_is_the_three_torch_ops(dev):
     assert torch.equal(ops.mul_noise(x, nz), (x.float() * nz).to(torch.bfloat16))
 
 
-@pytest.mark.parametrize("rows,C,V,D", [(700, 12, 1027, 2048), (37, 3, 19, 64), (20000, 2, 11, 256)])
+@pytest.mark.parametrize("rows,C,V,D", [(700, 12, 1027, 2048), (37, 3, 19, 64), (20000, 2, 11, 256), (600, 1, 5000, 256), (300, 2, 1500, 64)])
 def test_codec_embed_sum_bwd_vs_index_add(dev, rows, C, V, D):
     """umoe_codec_embed_sum_bwd (gradient of the stacked codec embedding tables, model.py:655-661 under autograd) against an fp64
     index_add of the same rows: one bf16 rounding of a sum accumulated in fp32; ids nobody chose get exact zeros; the autograd

@@ -363,11 +363,78 @@ __global__ __launch_bounds__(256) void codec_embed_bwd_kernel(const int32_t* __r
     }
 }
 
+// Large tables (V much larger than the row count: the 151 936-entry text table at 6 240 rows): one workgroup per ROW instead of
+// one per id.  It scans the id column in ascending segments; the first match it meets is the smallest row with its id -- if that
+// is an earlier row, this workgroup is not the id's owner and leaves; the owner adds every matching row in ascending order (the same
+// order, hence the same bits, as the per-id kernel) and writes the table row.  Rows of the table nobody chose are zeroed by a memset
+// in front of the launch.
+__global__ __launch_bounds__(256) void codec_embed_bwd_rows_kernel(const int32_t* __restrict__ tok, const uint16_t* __restrict__ d_out, int rows,
+                                                                   int C, int V, int D, uint16_t* __restrict__ d_emb) {
+    __shared__ unsigned long long bits[EMB_BWD_SEG][4];
+    __shared__ int first_seen;
+    const int me = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int v = tok[(size_t)me * C + c];
+    if (v < 0 || v >= V) return;
+    const int nc8 = D >> 3;
+    float acc[8][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+    if (tid == 0) first_seen = 0x7fffffff;
+    __syncthreads();
+    for (int r0 = 0; r0 < rows; r0 += EMB_BWD_SEG * 256) {
+        const int nseg = min(EMB_BWD_SEG, (rows - r0 + 255) / 256);
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int r = r0 + sg * 256 + tid;
+            const bool hit = r < rows && tok[(size_t)r * C + c] == v;
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) {
+                bits[sg][wave] = m;
+                if (m) atomicMin(&first_seen, r0 + sg * 256 + wave * 64 + (__ffsll((long long)m) - 1));
+            }
+        }
+        __syncthreads();
+        if (first_seen < me) return;          // an earlier row owns this id (uniform: every thread reads the same word)
+        for (int sg = 0; sg < nseg; ++sg)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned long long m = bits[sg][w];
+                while (m) {
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const size_t r = (size_t)r0 + sg * 256 + w * 64 + b;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int c8 = tid + q * 256;
+                        if (c8 < nc8) {
+                            float f[8];
+                            unpack8(ld16(d_out + r * D + c8 * 8), f);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[q][j] += f[j];
+                        }
+                    }
+                }
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c8 = tid + q * 256;
+        if (c8 < nc8) st16(d_emb + ((size_t)c * V + v) * D + c8 * 8, pack8(acc[q]));
+    }
+}
+
 extern "C" int umoe_codec_embed_sum_bwd(const int32_t* tok, const uint16_t* d_out, int rows, int C, int V, int D, uint16_t* d_emb,
                                         umoe_stream_t stream) {
     UMOE_REQUIRE(tok && d_out && d_emb && D % 8 == 0 && D <= 2048 * 8 && C > 0 && V > 0 && rows >= 0 && C <= 65535,
                  "umoe_codec_embed_sum_bwd: bad argument (D %% 8 == 0, D <= 16384)");
-    codec_embed_bwd_kernel<<<dim3((unsigned)V, (unsigned)C), 256, 0, (hipStream_t)stream>>>(tok, d_out, rows, C, V, D, d_emb);
+    if ((long)V > 4L * rows && rows > 0 && rows <= 0x7fffffff / 2) {
+        UMOE_HIP(hipMemsetAsync(d_emb, 0, (size_t)C * V * D * 2, (hipStream_t)stream));
+        codec_embed_bwd_rows_kernel<<<dim3((unsigned)rows, (unsigned)C), 256, 0, (hipStream_t)stream>>>(tok, d_out, rows, C, V, D, d_emb);
+    } else {
+        codec_embed_bwd_kernel<<<dim3((unsigned)V, (unsigned)C), 256, 0, (hipStream_t)stream>>>(tok, d_out, rows, C, V, D, d_emb);
+    }
     UMOE_LAUNCH_CHECK();
     return 0;
 }
