@@ -91,6 +91,12 @@ int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
  * (optional [S]) = aux_balance_weight expanded per token (core.py:380-385).  out = one fp32 scalar. */
 int umoe_aux_loss_fwd(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S, int E,
                       int n_dyn, float* out, umoe_stream_t stream);
+/* the same result from two launches (64 workgroups over contiguous token ranges, fixed-order partial sums in `ws`, then one small
+ * workgroup): for many tokens (training).  ws: umoe_aux_loss_workspace_floats() floats, caller-owned.  Sums are re-associated, so
+ * the value can differ from umoe_aux_loss_fwd in the last bits. */
+int umoe_aux_loss_fwd_ws(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S, int E,
+                         int n_dyn, float* out, float* ws, umoe_stream_t stream);
+size_t umoe_aux_loss_workspace_floats(void);
 
 /* Token drop (core.py:302-329; `capacity` = _audio_expert_capacity, core.py:170-175, computed by the host in the reference's
  * float32 arithmetic).  policy 0 "probs": per dynamic column keep the `capacity` selected tokens with the largest logits (the

@@ -814,6 +814,31 @@ def test_dense_gateup_flat_slices_equal_per_group_grid(dev, fw):
     assert float(a[:8 * S].float().abs().sum()) > 0 and float(a[8 * S:, :Is].float().abs().sum()) > 0
 
 
+@pytest.mark.parametrize("weighted,bf16", [(False, True), (True, True), (False, False)])
+def test_aux_loss_two_launch_form_vs_oracle(dev, weighted, bf16):
+    """umoe_aux_loss_fwd_ws (training sizes: 64 workgroups + a finisher) against the oracle's formula (core.py:361-389) at 6 240 tokens and
+    against the one-workgroup kernel: the same sums, re-associated."""
+    import ctypes as C
+    from oracle.dcmoe import aux_loss as oracle_aux
+    from unimoe_audio_amd import ops, _lib as L
+    g = torch.Generator().manual_seed(17)
+    S, E, n_dyn = 6240, 11, 9
+    logits = (torch.randn(S, E, generator=g) * 1.5)
+    logits = logits.to(torch.bfloat16) if bf16 else logits
+    mask = (torch.rand(S, E, generator=g) < 0.45).to(torch.int32)
+    mask[:, 0] |= (mask[:, :n_dyn].sum(-1) == 0).to(torch.int32)
+    tw = torch.rand(S, generator=g) if weighted else None
+    got = ops.aux_loss(logits.to(dev), mask.to(dev), n_dyn, None if tw is None else tw.to(dev))
+    ref = oracle_aux(mask, n_dyn, logits, None if tw is None else tw.reshape(1, S))
+    assert torch.allclose(got.cpu().float(), ref.float(), rtol=1e-4, atol=1e-6), (float(got), float(ref))
+    one = torch.empty(1, dtype=torch.float32, device=dev)
+    lg, mk = logits.to(dev).contiguous(), mask.to(dev).contiguous()
+    twd = None if tw is None else tw.to(dev).float().contiguous()
+    L.check(L.lib().umoe_aux_loss_fwd(C.c_void_p(lg.data_ptr()), int(bf16), C.c_void_p(mk.data_ptr()), C.c_void_p(0 if twd is None else twd.data_ptr()),
+                                      S, E, n_dyn, C.c_void_p(one.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "umoe_aux_loss_fwd")
+    assert torch.allclose(got.cpu().float(), one.cpu()[0].float(), rtol=1e-4, atol=1e-6)
+
+
 def test_mul_noise_is_the_three_torch_ops(dev):
     """umoe_mul_noise == (x.float() * noise).to(bfloat16), bit for bit (core.py:240-244 input jitter on the gate's copy)."""
     from unimoe_audio_amd import ops

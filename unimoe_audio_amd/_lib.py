@@ -124,7 +124,7 @@ class DecodeIO(C.Structure):
 
 EXPORTS = [
     "umoe_last_error", "umoe_abi_version", "umoe_packed_elems", "umoe_pack_weight", "umoe_pack_gate_up",
-    "umoe_router_fwd", "umoe_router_dispatch_fwd", "umoe_dispatch_build", "umoe_aux_loss_fwd", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd", "umoe_shared_swiglu_fwd", "umoe_attn_prefill_fwd",
+    "umoe_router_fwd", "umoe_router_dispatch_fwd", "umoe_dispatch_build", "umoe_aux_loss_fwd", "umoe_aux_loss_fwd_ws", "umoe_aux_loss_workspace_floats", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd", "umoe_shared_swiglu_fwd", "umoe_attn_prefill_fwd",
     "umoe_unpermute_combine_fwd", "umoe_rmsnorm_residual_fwd", "umoe_qkv_mrope_kvappend", "umoe_attn_decode",
     "umoe_codec_embed_sum", "umoe_codec_embed_sum_bwd", "umoe_mul_noise", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_codec_ce_fwd", "umoe_codec_ce_bwd", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
@@ -163,6 +163,9 @@ def lib():
         L.umoe_router_fwd.argtypes = [C.POINTER(RouterArgs), vp]
         L.umoe_dispatch_build.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]
         L.umoe_aux_loss_fwd.argtypes = [vp, i32, vp, vp, i32, i32, i32, vp, vp]
+        L.umoe_aux_loss_fwd_ws.argtypes = [vp, i32, vp, vp, i32, i32, i32, vp, vp, vp]
+        L.umoe_aux_loss_workspace_floats.argtypes = []
+        L.umoe_aux_loss_workspace_floats.restype = C.c_size_t
         L.umoe_prefetch.argtypes = [vp, C.c_size_t, i32, vp]
         L.umoe_transpose_slots.argtypes = [vp, i32, i32, vp, vp, vp, i32, i32, vp, i32, vp]
         L.umoe_swiglu_bwd.argtypes = [vp, i32, vp, i32, i32, vp, i32, vp, i32, vp]

@@ -1110,6 +1110,91 @@ __global__ __launch_bounds__(256) void aux_loss_kernel(const void* __restrict__ 
     if (threadIdx.x == 0) *out = total * (float)n_dyn;
 }
 
+// Many tokens (training): the same sums in two launches -- AUX_PARTS workgroups take contiguous token ranges and leave fixed-order
+// partial sums in the caller's workspace, one small workgroup adds the parts in order and finishes the formula.  (The one-workgroup
+// kernel above took 74 us at 6 240 tokens: 25 dependent rounds of loads per thread.)
+#define AUX_PARTS 64
+__global__ __launch_bounds__(256) void aux_loss_part_kernel(const void* __restrict__ logits, int logits_bf16, const int32_t* __restrict__ mask,
+                                                            const float* __restrict__ tok_w, int S, int E, int n_dyn, float* __restrict__ ws) {
+    __shared__ float sh[4];
+    float fm[UMOE_MAXE], fp[UMOE_MAXE];
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e) fm[e] = fp[e] = 0.f;
+    float wsum = 0.f;
+    const int per = (S + AUX_PARTS - 1) / AUX_PARTS, s0 = blockIdx.x * per, s1 = min(S, s0 + per);
+    for (int s = s0 + threadIdx.x; s < s1; s += 256) {
+        float x[UMOE_MAXE];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < n_dyn) {
+                const float l = logits_bf16 ? bf2f(reinterpret_cast<const uint16_t*>(logits)[(size_t)s * E + e])
+                                            : reinterpret_cast<const float*>(logits)[(size_t)s * E + e];
+                x[e] = mask[(size_t)s * E + e] ? l : (logits_bf16 ? -3.3895313892515355e38f : -3.4028234663852886e38f);
+                mx = fmaxf(mx, x[e]);
+            }
+        float sm = 0.f, ex[UMOE_MAXE];
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < n_dyn) {
+                ex[e] = expf(x[e] - mx);
+                sm += ex[e];
+            }
+        const float w = tok_w ? tok_w[s] : 1.f;
+        wsum += w;
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < n_dyn) {
+                const float p = round_t(ex[e] / sm, logits_bf16);
+                fm[e] += w * (float)mask[(size_t)s * E + e];
+                fp[e] += w * p;
+            }
+    }
+    float* o = ws + (size_t)blockIdx.x * (2 * UMOE_MAXE + 1);
+    wsum = block_sum_256(wsum, sh);
+    if (threadIdx.x == 0) o[2 * UMOE_MAXE] = wsum;
+#pragma unroll
+    for (int e = 0; e < UMOE_MAXE; ++e)
+        if (e < n_dyn) {
+            const float a = block_sum_256(fm[e], sh), b = block_sum_256(fp[e], sh);
+            if (threadIdx.x == 0) {
+                o[e] = a;
+                o[UMOE_MAXE + e] = b;
+            }
+        }
+}
+__global__ __launch_bounds__(64) void aux_loss_fin_kernel(const float* __restrict__ ws, int logits_bf16, int has_w, int n_dyn, float* out) {
+    const int e = threadIdx.x;
+    float a = 0.f, b = 0.f, wsum = 0.f;
+    for (int q = 0; q < AUX_PARTS; ++q) {       // fixed order
+        const float* o = ws + (size_t)q * (2 * UMOE_MAXE + 1);
+        wsum += o[2 * UMOE_MAXE];
+        if (e < n_dyn) {
+            a += o[e];
+            b += o[UMOE_MAXE + e];
+        }
+    }
+    float term = 0.f;
+    if (e < n_dyn) {
+        const float pm = (!has_w && logits_bf16) ? rbf(b / wsum) : b / wsum;
+        term = (a / wsum) * pm;
+    }
+    // ascending expert order, as the one-workgroup kernel adds them
+    float total = 0.f;
+    for (int q = 0; q < n_dyn; ++q) total += __shfl(term, q, 64);
+    if (e == 0) *out = total * (float)n_dyn;
+}
+
+extern "C" int umoe_aux_loss_fwd_ws(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S,
+                                    int E, int n_dyn, float* out, float* ws, umoe_stream_t stream) {
+    UMOE_REQUIRE(logits && expert_mask && out && ws && S > 0 && n_dyn >= 1 && n_dyn <= E && E <= UMOE_MAXE, "umoe_aux_loss_fwd_ws: bad argument");
+    aux_loss_part_kernel<<<AUX_PARTS, 256, 0, (hipStream_t)stream>>>(logits, logits_bf16, expert_mask, token_weight, S, E, n_dyn, ws);
+    aux_loss_fin_kernel<<<1, 64, 0, (hipStream_t)stream>>>(ws, logits_bf16, token_weight != nullptr, n_dyn, out);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" size_t umoe_aux_loss_workspace_floats(void) { return (size_t)AUX_PARTS * (2 * UMOE_MAXE + 1); }
+
 extern "C" int umoe_aux_loss_fwd(const void* logits, int logits_bf16, const int32_t* expert_mask, const float* token_weight, int S,
                                  int E, int n_dyn, float* out, umoe_stream_t stream) {
     UMOE_REQUIRE(logits && expert_mask && out && S > 0 && n_dyn >= 1 && n_dyn <= E && E <= UMOE_MAXE, "umoe_aux_loss_fwd: bad argument");

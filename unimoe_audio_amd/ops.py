@@ -142,6 +142,11 @@ def aux_loss(logits: torch.Tensor, expert_mask: torch.Tensor, n_dyn: int, token_
     S, E = logits.shape
     out = torch.empty(1, dtype=torch.float32, device=logits.device)
     tw = None if token_weight is None else token_weight.reshape(-1).float().contiguous()
+    if S >= 2048:       # many tokens: the two-launch form (64 workgroups + a finisher)
+        ws = torch.empty(int(L.lib().umoe_aux_loss_workspace_floats()), dtype=torch.float32, device=logits.device)
+        L.check(L.lib().umoe_aux_loss_fwd_ws(_p(logits.contiguous()), int(logits.dtype == torch.bfloat16), _p(expert_mask), _p(tw), S, E, n_dyn,
+                                             _p(out), _p(ws), _stream()), "umoe_aux_loss_fwd_ws")
+        return out[0]
     L.check(L.lib().umoe_aux_loss_fwd(_p(logits.contiguous()), int(logits.dtype == torch.bfloat16), _p(expert_mask), _p(tw), S, E, n_dyn,
                                       _p(out), _stream()), "umoe_aux_loss_fwd")
     return out[0]
