@@ -41,6 +41,18 @@ def test_ep_two_processes_hip_ipc_bit_identical():
     assert rc == 0 and "BIT-IDENTICAL" in out, out[-3000:]
 
 
+def test_ep_training_step_two_processes_vs_single_block():
+    """Expert-parallel training of one DCMoE block (ep_size 2, two processes, the exchange as part of the HIP block's forward and backward,
+    core.py:455-488 under autograd) against the ep_size 1 block: outputs, input gradients, gate / shared gradients and the local experts'
+    weight gradients summed over both ranks' rows (scripts/ep_train_multiproc.py)."""
+    assert torch.cuda.is_available()
+    import random
+    port = random.randint(20000, 40000)
+    rc, out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), "scripts/ep_train_multiproc.py"])
+    assert rc == 0 and "EP-TRAIN-OK" in out, out[-3000:]
+
+
 def test_ep_loopback_emulation_runs_clean():
     """One rank of an 8-rank job in loopback (bench.py --ep-emulate): every receive is satisfied by the engine's own sends, no
     timeout, and the sampler still produces valid codes."""

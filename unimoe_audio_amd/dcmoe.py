@@ -178,8 +178,6 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         n_dyn, n_real, n_fix = self.mlp_dynamic_expert_num, self.mlp_dynamic_real_expert_num, self.mlp_fixed_expert_num
         if torch.is_grad_enabled() and (hidden_states.requires_grad or any(p.requires_grad for p in self.parameters())):
             # training: forward + backward on the HIP kernels (shipped configuration)
-            if int(self.dynamic_real_moe.ep_size) > 1:
-                raise NotImplementedError("the HIP backward runs at ep_size=1")
             for p_ in self.parameters():
                 if p_.dtype != torch.bfloat16 or not p_.is_contiguous():
                     raise L.UmoeError("training needs contiguous bfloat16 parameters")
@@ -349,16 +347,25 @@ class _DCMoETrainFn(torch.autograd.Function):
         hbuf = torch.empty((rows_total, Imax), dtype=torch.bfloat16, device=dev)
         gu = torch.empty((rows_total, 2 * Imax), dtype=torch.bfloat16, device=dev)
         ybuf = torch.empty((rows_total, D), dtype=torch.bfloat16, device=dev)
+        ep = int(blk.dynamic_real_moe.ep_size)
+        E_loc = n_real // ep
+        ctx.ep_state = None
+        if ep > 1:
+            # expert parallel (core.py:455-488): this rank holds experts [rank * E_loc, (rank + 1) * E_loc); params carries those only
+            ex = [params[1 + 3 * q: 4 + 3 * q] for q in range(E_loc)]
+            sh = [params[1 + 3 * E_loc + 3 * i: 4 + 3 * E_loc + 3 * i] for i in range(n_fix)]
+            ctx.ep_state = _ep_experts_fwd(blk, x, disp, ex, ep, E_loc, n_real, S, D, I_d, cap, ybuf)
         g_gu, g_dn = [], []
-        for e in range(n_real):
+        for e in range(n_real if ep == 1 else 0):
             off, cnt = disp["offsets"][e:e + 1], disp["counts"][e:e + 1]
             g_gu.append(dict(w=ex[e][0], w2=ex[e][1], rows=disp["slot_token"], row_off=off, count=cnt))
             g_dn.append(dict(w=ex[e][2], row_off=off, count=cnt))
         for i in range(n_fix):
             g_gu.append(dict(w=sh[i][0], w2=sh[i][1], static_count=S, out_row_base=cap + i * S))
             g_dn.append(dict(w=sh[i][2], static_count=S, a_row_base=cap + i * S, out_row_base=cap + i * S))
-        ops.tiled_gemm(g_gu, x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, aux_out=gu)
-        ops.tiled_gemm(g_dn, hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16)
+        if g_gu:
+            ops.tiled_gemm(g_gu, x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, aux_out=gu)
+            ops.tiled_gemm(g_dn, hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16)
         y_sh = ybuf[cap:] if n_fix else None
         out = ops.combine(ybuf, disp["slot_of"], moe_w, y_sh, global_w, None, n_dyn, n_fix)
         ctx.blk, ctx.dims = blk, (S, D, n_dyn, n_real, n_fix, I_d, I_s, Imax, cap, rows_total)
@@ -375,8 +382,10 @@ class _DCMoETrainFn(torch.autograd.Function):
         blk, disp = ctx.blk, ctx.disp
         S, D, n_dyn, n_real, n_fix, I_d, I_s, Imax, cap, rows_total = ctx.dims
         x, logits, sel, top_k, mask, moe_w, global_w, hbuf, gu, ybuf, *params = ctx.saved_tensors
-        ex = [params[1 + 3 * e: 4 + 3 * e] for e in range(n_real)]
-        sh = [params[1 + 3 * n_real + 3 * i: 4 + 3 * n_real + 3 * i] for i in range(n_fix)]
+        ep = int(blk.dynamic_real_moe.ep_size)
+        n_loc = n_real // ep                     # experts whose parameters this rank holds
+        ex = [params[1 + 3 * e: 4 + 3 * e] for e in range(n_loc)]
+        sh = [params[1 + 3 * n_loc + 3 * i: 4 + 3 * n_loc + 3 * i] for i in range(n_fix)]
         dev, bf = x.device, torch.bfloat16
         if d_out is None:
             d_out = torch.zeros((S, D), dtype=bf, device=dev)
@@ -390,7 +399,11 @@ class _DCMoETrainFn(torch.autograd.Function):
         # 2.-5. expert MLP backward (umoe_grouped_swiglu_bwd / umoe_shared_swiglu_bwd): dH = dY Wd, SwiGLU', dX_slots, dWd/dWg/dWu
         dxe = torch.empty((rows_total, D), dtype=bf, device=dev)
         grads = [None] * len(params)
-        if n_real:
+        if ep > 1:
+            dwg, dwu, dwd = _ep_experts_bwd(ctx.ep_state, ex, dy, dxe, disp, ep, n_loc, n_real, S, D, I_d, cap)
+            for q in range(n_loc):
+                grads[1 + 3 * q], grads[2 + 3 * q], grads[3 + 3 * q] = dwg[q], dwu[q], dwd[q]
+        elif n_real:
             dwg, dwu, dwd = ops.experts_swiglu_bwd([tuple(ex[e]) for e in range(n_real)], x=x, h=hbuf[:cap], gu=gu[:cap], dy=dy[:cap],
                                                    dx_slots=dxe[:cap], D=D, I=I_d, max_rows=S, counts=cnts, offsets=offs,
                                                    slot_token=disp["slot_token"])
@@ -400,7 +413,7 @@ class _DCMoETrainFn(torch.autograd.Function):
             dwg, dwu, dwd = ops.experts_swiglu_bwd([tuple(sh[i]) for i in range(n_fix)], x=x, h=hbuf[cap:], gu=gu[cap:], dy=dy[cap:],
                                                    dx_slots=dxe[cap:], D=D, I=I_s, max_rows=S, row_base=0)
             for i in range(n_fix):
-                b0 = 1 + 3 * n_real + 3 * i
+                b0 = 1 + 3 * n_loc + 3 * i
                 grads[b0], grads[b0 + 1], grads[b0 + 2] = dwg[i], dwu[i], dwd[i]
         Sp = ops._r8(S)
         # 6. router: d(moe_w), d(shared weights), d(aux) -> d(logits) -> gate weight and input gradients
@@ -425,6 +438,78 @@ class _DCMoETrainFn(torch.autograd.Function):
         # 7. input gradient: slot rows back to tokens + shared experts + router
         dx = ops.permute_bwd(dxe, disp["slot_of"], dxe[cap:] if n_fix else None, n_fix, extra=dx_router)
         return (None, dx, None, None, *[gr.contiguous() if gr is not None else None for gr in grads])
+
+
+# ---- expert-parallel training (core.py:455-488 under autograd: two all-to-alls forward, the same two backward) ----------------------
+# Layout of an exchange slab: [ep (destination / source rank)][S (position)][E_loc][D]; expert e = rank * E_loc + e_loc keeps the rows of
+# source rank `src` compacted at positions < count (unimoe_audio_amd/ep.py).  Every index below is arithmetic on device tensors: no
+# boolean indexing, no host read of a count.
+def _slot_to_slab(offsets, counts, n_exp, E_loc, S, cap):
+    """for slot row j of an aligned dispatch over n_exp experts: flat row ((e // E_loc) * S + pos) * E_loc + e % E_loc of the slab that
+    carries expert e's rows of this rank, and whether the slot holds a row at all (alignment padding does not)."""
+    j = torch.arange(cap, device=offsets.device)
+    offs, cnts = offsets[: n_exp + 1].long(), counts[:n_exp].long()
+    e = torch.bucketize(j, offs[1: n_exp + 1].contiguous(), right=True).clamp(max=n_exp - 1)
+    pos = j - offs[e]
+    valid = (pos >= 0) & (pos < cnts[e])
+    flat = ((e // E_loc) * S + pos.clamp(0, S - 1)) * E_loc + (e % E_loc)
+    return flat, valid, e
+
+
+def _ep_experts_fwd(blk, x, disp, ex, ep, E_loc, n_real, S, D, I_d, cap, ybuf):
+    grp = blk.dynamic_real_moe.deepspeed_moe.ep_group
+    bf, dev = torch.bfloat16, x.device
+    send, send_cnt = EP.ep_pack(x, disp["counts"], disp["offsets"], disp["slot_token"], n_real, ep)      # [ep, S, E_loc, D]
+    recv = EP._a2a(torch.empty_like(send), send, grp)                                                    # first all-to-all, core.py:467
+    recv_cnt = EP._a2a(torch.empty_like(send_cnt), send_cnt, grp)
+    T2 = ep * S
+    d2 = ops.dispatch_build_aligned(EP.ep_recv_mask(recv_cnt, S), E_loc, 8)      # the received rows, grouped per local expert
+    cap2 = ops._r8(d2["cap"])
+    j = torch.arange(cap2, device=dev)
+    offs2, cnts2 = d2["offsets"][: E_loc + 1].long(), d2["counts"][:E_loc].long()
+    e2 = torch.bucketize(j, offs2[1: E_loc + 1].contiguous(), right=True).clamp(max=E_loc - 1)
+    valid2 = ((j - offs2[e2]) >= 0) & ((j - offs2[e2]) < cnts2[e2])
+    st2 = torch.nn.functional.pad(d2["slot_token"].long(), (0, max(0, cap2 - d2["slot_token"].numel())))[:cap2]
+    src2 = st2.clamp(0, T2 - 1) * E_loc + e2                                     # row of recv.reshape(T2 * E_loc, D) behind slot j
+    xs2 = recv.reshape(T2 * E_loc, D)[src2] * valid2[:, None].to(bf)
+    hbuf2 = torch.empty((cap2, I_d), dtype=bf, device=dev)
+    gu2 = torch.empty((cap2, 2 * I_d), dtype=bf, device=dev)
+    ybuf2 = torch.zeros((cap2 + 1, D), dtype=bf, device=dev)                     # last row = zeros: the target of "no row"
+    g_gu = [dict(w=ex[q][0], w2=ex[q][1], row_off=d2["offsets"][q:q + 1], count=d2["counts"][q:q + 1]) for q in range(E_loc)]
+    g_dn = [dict(w=ex[q][2], row_off=d2["offsets"][q:q + 1], count=d2["counts"][q:q + 1]) for q in range(E_loc)]
+    ops.tiled_gemm(g_gu, xs2, hbuf2, max_rows=T2, epilogue=ops.EPI_SWIGLU, aux_out=gu2)
+    ops.tiled_gemm(g_dn, hbuf2, ybuf2, max_rows=T2, epilogue=ops.EPI_BF16)
+    so2 = d2["slot_of"].long()                                                   # [T2, E_loc], -1 = no row
+    y_full = ybuf2[torch.where(so2 >= 0, so2, torch.full_like(so2, cap2)).reshape(-1)].reshape(ep, S, E_loc, D)
+    back = EP._a2a(torch.empty_like(y_full), y_full.contiguous(), grp)           # second all-to-all, core.py:480
+    flat, valid, _ = _slot_to_slab(disp["offsets"], disp["counts"], n_real, E_loc, S, cap)
+    ybuf[:cap] = back.reshape(-1, D)[flat] * valid[:, None].to(bf)
+    return dict(grp=grp, xs2=xs2, hbuf2=hbuf2, gu2=gu2, d2=d2, cap2=cap2, src2=src2, valid2=valid2, so2=so2, flat=flat, valid=valid, T2=T2)
+
+
+def _ep_experts_bwd(st, ex, dy, dxe, disp, ep, E_loc, n_real, S, D, I_d, cap):
+    bf, dev, grp = torch.bfloat16, dy.device, st["grp"]
+    # gradients of the returned rows travel to the experts' owners ...
+    pos = torch.arange(S, device=dev)
+    offs, cnts = disp["offsets"][:n_real].long(), disp["counts"][:n_real].long()
+    live = pos[None, :] < cnts[:, None]                                          # [n_real, S]
+    slots = (offs[:, None] + pos[None, :]).clamp(max=cap - 1)
+    dy_send = dy[:cap][slots.reshape(-1)].reshape(n_real, S, D) * live[..., None].to(bf)
+    dy_send = dy_send.reshape(ep, E_loc, S, D).permute(0, 2, 1, 3).contiguous()  # [ep, S, E_loc, D]
+    dy_recv = EP._a2a(torch.empty_like(dy_send), dy_send, grp)
+    T2, cap2, d2 = st["T2"], st["cap2"], st["d2"]
+    dy2 = dy_recv.reshape(T2 * E_loc, D)[st["src2"]] * st["valid2"][:, None].to(bf)
+    dxs2 = torch.zeros((cap2 + 1, D), dtype=bf, device=dev)
+    ident = torch.arange(cap2, dtype=torch.int32, device=dev)
+    dwg, dwu, dwd = ops.experts_swiglu_bwd([tuple(ex[q]) for q in range(E_loc)], x=st["xs2"], h=st["hbuf2"], gu=st["gu2"], dy=dy2,
+                                           dx_slots=dxs2[:cap2], D=D, I=I_d, max_rows=T2, counts=d2["counts"], offsets=d2["offsets"],
+                                           slot_token=ident)
+    # ... and the gradients of the rows they received travel back to the rows' owners
+    so2 = st["so2"]
+    d_recv = dxs2[torch.where(so2 >= 0, so2, torch.full_like(so2, cap2)).reshape(-1)].reshape(ep, S, E_loc, D)
+    d_back = EP._a2a(torch.empty_like(d_recv), d_recv.contiguous(), grp)
+    dxe[:cap] = d_back.reshape(-1, D)[st["flat"]] * st["valid"][:, None].to(bf)
+    return dwg, dwu, dwd
 
 
 def _train_params(blk):

@@ -61,6 +61,12 @@ def _a2a(out: torch.Tensor, inp: torch.Tensor, group):
         return group.all_to_all(out, inp) if group.size > 1 else out.copy_(inp)
     if group is None or dist.get_world_size(group) == 1:
         out.copy_(inp)          # the reference's single-process behaviour: identity (utils.py:332-335)
+    elif inp.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo moves host memory only: device slabs are staged through the host (rehearsals of several ranks on one GPU box;
+        # a real job runs the "nccl" = RCCL backend, where the device tensors go straight into the collective)
+        h_in, h_out = inp.cpu(), torch.empty(inp.shape, dtype=inp.dtype)
+        dist.all_to_all_single(h_out, h_in, group=group)
+        out.copy_(h_out)
     else:
         dist.all_to_all_single(out, inp, group=group)
     return out
