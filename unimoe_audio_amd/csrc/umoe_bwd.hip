@@ -8,48 +8,60 @@
 
 // ------------------------------------------------------------------------------------ transposes
 // dst[c][off_g + r] = src[row(off_g + r)][c] for r < cnt_g, 0 for cnt_g <= r < roundup8(cnt_g); row(s) = rows ? rows[s] : s.
-// grid = (slot tiles of 64, column tiles of 64, groups).  counts == NULL: one group of `static_rows` rows at offset 0.
+// grid = (slot tiles of TR_TS, column tiles of 64, groups).  counts == NULL: one group of `static_rows` rows at offset 0.
+// Tile = TR_TS slots x 64 columns.  Measured in the training step (scripts/train_bench.py, same box): TR_TS 64 (128-byte segments on both
+// sides) 241.9 / 245.6 ms, TR_TS 128 (256 contiguous bytes per destination row and tile, 18 KB of LDS) 249.0 / 249.1 ms -- 64 stays.
+#ifndef TR_TS
+#define TR_TS 64
+#endif
 __device__ __forceinline__ void transpose_tile(const uint16_t* __restrict__ src, const int ld_src, const int C,
                                                const int32_t* __restrict__ rows, const int cnt, const int off,
                                                uint16_t* __restrict__ dst, const int ld_dst) {
-    __shared__ uint16_t tile[64][72];   // [slot][col], 144-byte rows: 16-byte aligned chunks, bank spread
+    __shared__ uint16_t tile[TR_TS][72];   // [slot][col], 144-byte rows: 16-byte aligned chunks, bank spread
     const int pad = (cnt + 7) & ~7;
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int r0 = blockIdx.x * TR_TS, c0 = blockIdx.y * 64;
     if (r0 >= pad) return;
     const int tid = threadIdx.x;
-    // load: thread (tr = tid / 8, ch = tid % 8) reads 8 columns of slots tr and tr + 32
+    // load: thread (tr = tid / 8, ch = tid % 8) reads 8 columns of slots tr, tr + 32, ...; every load is requested before the first
+    // LDS write (straight-line: rows beyond the count re-read the group's first row and are zeroed)
+    uint4 v[TR_TS / 32];
+    const int ch = tid & 7, c = c0 + ch * 8;
+    const bool vec = c + 8 <= C && (ld_src & 7) == 0;
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        const int r = (tid >> 3) + 32 * ps, ch = tid & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        const int c = c0 + ch * 8;
-        if (r0 + r < cnt && c < C) {
-            const long srow = rows ? (long)rows[off + r0 + r] : (long)(off + r0 + r);
+    for (int ps = 0; ps < TR_TS / 32; ++ps) {
+        const int r = (tid >> 3) + 32 * ps;
+        const bool live = r0 + r < cnt && c < C;
+        const int rr = live ? r0 + r : 0;
+        v[ps] = make_uint4(0, 0, 0, 0);
+        if (vec) {
+            const long srow = rows ? (long)rows[off + rr] : (long)(off + rr);
+            const uint4 t4 = ld16(src + srow * ld_src + c);
+            if (live) v[ps] = t4;
+        } else if (live) {
+            const long srow = rows ? (long)rows[off + rr] : (long)(off + rr);
             const uint16_t* sp = src + srow * ld_src + c;
-            if (c + 8 <= C && (ld_src & 7) == 0) {
-                v = ld16(sp);
-            } else {
-                uint16_t t[8];
+            uint16_t t[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] = (c + j < C) ? sp[j] : (uint16_t)0;
-                v = make_uint4((uint32_t)t[0] | ((uint32_t)t[1] << 16), (uint32_t)t[2] | ((uint32_t)t[3] << 16),
+            for (int q = 0; q < 8; ++q) t[q] = (c + q < C) ? sp[q] : (uint16_t)0;
+            v[ps] = make_uint4((uint32_t)t[0] | ((uint32_t)t[1] << 16), (uint32_t)t[2] | ((uint32_t)t[3] << 16),
                                (uint32_t)t[4] | ((uint32_t)t[5] << 16), (uint32_t)t[6] | ((uint32_t)t[7] << 16));
-            }
         }
-        *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = v;
     }
-    __syncthreads();
-    // store: thread (c = tid / 8 (+32), sc = tid % 8) writes 8 consecutive slots of column c
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-        const int c = (tid >> 3) + 32 * ps, sc = tid & 7;
-        if (c0 + c >= C || r0 + sc * 8 >= pad) continue;
+    for (int ps = 0; ps < TR_TS / 32; ++ps) *reinterpret_cast<uint4*>(&tile[(tid >> 3) + 32 * ps][ch * 8]) = v[ps];
+    __syncthreads();
+    // store: thread (c = tid / 16 (+16 per pass), sc = tid % 16) writes 8 consecutive slots of column c: 256 contiguous bytes per column
+    constexpr int SPC = TR_TS / 8;          // 16-byte chunks per column of the tile
+#pragma unroll
+    for (int ps = 0; ps < 64 / (256 / SPC); ++ps) {
+        const int cc = tid / SPC + (256 / SPC) * ps, sc = tid % SPC;
+        if (c0 + cc >= C || r0 + sc * 8 >= pad) continue;
         uint16_t t[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = tile[sc * 8 + j][c];
-        const uint4 v = make_uint4((uint32_t)t[0] | ((uint32_t)t[1] << 16), (uint32_t)t[2] | ((uint32_t)t[3] << 16),
+        for (int q = 0; q < 8; ++q) t[q] = tile[sc * 8 + q][cc];
+        const uint4 o = make_uint4((uint32_t)t[0] | ((uint32_t)t[1] << 16), (uint32_t)t[2] | ((uint32_t)t[3] << 16),
                                    (uint32_t)t[4] | ((uint32_t)t[5] << 16), (uint32_t)t[6] | ((uint32_t)t[7] << 16));
-        st16(dst + (size_t)(c0 + c) * ld_dst + off + r0 + sc * 8, v);
+        st16(dst + (size_t)(c0 + cc) * ld_dst + off + r0 + sc * 8, o);
     }
 }
 
@@ -71,7 +83,7 @@ static int transpose_multi(const uint16_t* const* src, uint16_t* const* dst, int
     UMOE_REQUIRE(n >= 1 && n <= 12 && (ld_dst & 7) == 0, "transpose_multi: 1..12 matrices, ld_dst %% 8");
     trans_ptrs p{};
     for (int i = 0; i < n; ++i) { p.src[i] = src[i]; p.dst[i] = dst[i]; }
-    dim3 grid((unsigned)ceil_div(((R + 7) & ~7), 64), (unsigned)ceil_div(C, 64), (unsigned)n);
+    dim3 grid((unsigned)ceil_div(((R + 7) & ~7), TR_TS), (unsigned)ceil_div(C, 64), (unsigned)n);
     transpose_multi_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, ld_src, C, R, ld_dst);
     UMOE_LAUNCH_CHECK();
     return 0;
@@ -85,7 +97,7 @@ extern "C" int umoe_transpose_slots(const uint16_t* src, int ld_src, int C, cons
     if (max_rows == 0) return 0;
     const int G = counts ? n_groups : 1;
     UMOE_REQUIRE(G >= 1 && G <= 65535, "umoe_transpose_slots: bad group count");
-    dim3 grid((unsigned)ceil_div(((max_rows + 7) & ~7), 64), (unsigned)ceil_div(C, 64), (unsigned)G);
+    dim3 grid((unsigned)ceil_div(((max_rows + 7) & ~7), TR_TS), (unsigned)ceil_div(C, 64), (unsigned)G);
     transpose_slots_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, ld_src, C, rows, counts, offsets, max_rows, dst, ld_dst);
     UMOE_LAUNCH_CHECK();
     return 0;
