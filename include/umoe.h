@@ -219,6 +219,10 @@ typedef struct {
     const int32_t* k_off;     /* optional device scalars: contract over columns [*k_off, *k_off + roundup8(*k_count)) of BOTH */
     const int32_t* k_count;   /* operands instead of [0, k) -- weight gradients over one expert's (8-aligned) slot range */
     int out_col_off;          /* element offset added to every output row of this group (attention heads side by side) */
+    int k_compact_a;          /* with k_off / k_count: > 0 = the activation operand is laid out in per-group COMPACT blocks (what
+                               * umoe_transpose_slots_compact writes): this group's block starts at element *k_off * k_compact_a (the
+                               * operand's total row count) and its rows are roundup8(*k_count) apart, columns [0, roundup8(*k_count)) */
+    int k_compact_w;          /* the same for the weight operand (total rows of `w`) */
 } umoe_tgroup_t;
 
 typedef struct {
@@ -308,6 +312,11 @@ int umoe_ep_ipc_close(void* dev_ptr);
  * transposes in Linear.backward (core.py:21-49 via torch.nn.functional.linear). */
 int umoe_transpose_slots(const uint16_t* src, int ld_src, int C, const int32_t* rows, const int32_t* counts,
                          const int32_t* offsets, int n_groups, int max_rows, uint16_t* dst, int ld_dst, umoe_stream_t stream);
+/* the same transpose into per-group COMPACT blocks: group g's block starts at dst + offsets[g] * C and holds C rows of roundup8(counts[g])
+ * elements (zero padded) -- a weight-gradient product then walks rows 5.6 KB apart instead of 50 KB (umoe_tgroup_t.k_compact_*).
+ * counts / offsets required; dst needs (sum of roundup8 counts) * C elements. */
+int umoe_transpose_slots_compact(const uint16_t* src, int ld_src, int C, const int32_t* rows, const int32_t* counts,
+                                 const int32_t* offsets, int n_groups, int max_rows, uint16_t* dst, umoe_stream_t stream);
 
 /* SwiGLU backward, core.py:31,49: gu [rows][2I] = (gate | up) pre-activations saved by the forward
  * (umoe_tgemm_args.aux_out), dh [rows][I] -> dgu [rows][2I] = (dgate | dup).  total_rows: device scalar or NULL. */

@@ -52,7 +52,7 @@ class GemmArgs(C.Structure):
 
 class TGroup(C.Structure):
     _fields_ = [("w", vp), ("w2", vp), ("bias", vp), ("rows", vp), ("row_off", vp), ("count", vp), ("static_count", i32),
-                ("a_row_base", i32), ("out_row_base", i32), ("n", i32), ("k", i32), ("ldw", i32), ("a_col_off", i32), ("k_off", vp), ("k_count", vp), ("out_col_off", i32)]
+                ("a_row_base", i32), ("out_row_base", i32), ("n", i32), ("k", i32), ("ldw", i32), ("a_col_off", i32), ("k_off", vp), ("k_count", vp), ("out_col_off", i32), ("k_compact_a", i32), ("k_compact_w", i32)]
 
 
 class TGemmArgs(C.Structure):
@@ -124,7 +124,7 @@ class DecodeIO(C.Structure):
 
 EXPORTS = [
     "umoe_last_error", "umoe_abi_version", "umoe_packed_elems", "umoe_pack_weight", "umoe_pack_gate_up",
-    "umoe_router_fwd", "umoe_router_dispatch_fwd", "umoe_dispatch_build", "umoe_aux_loss_fwd", "umoe_aux_loss_fwd_ws", "umoe_aux_loss_workspace_floats", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd", "umoe_shared_swiglu_fwd", "umoe_attn_prefill_fwd",
+    "umoe_router_fwd", "umoe_router_dispatch_fwd", "umoe_dispatch_build", "umoe_transpose_slots_compact", "umoe_aux_loss_fwd", "umoe_aux_loss_fwd_ws", "umoe_aux_loss_workspace_floats", "umoe_permute_fwd", "umoe_grouped_gemm", "umoe_grouped_swiglu_fwd", "umoe_shared_swiglu_fwd", "umoe_attn_prefill_fwd",
     "umoe_unpermute_combine_fwd", "umoe_rmsnorm_residual_fwd", "umoe_qkv_mrope_kvappend", "umoe_attn_decode",
     "umoe_codec_embed_sum", "umoe_codec_embed_sum_bwd", "umoe_mul_noise", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_codec_ce_fwd", "umoe_codec_ce_bwd", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",

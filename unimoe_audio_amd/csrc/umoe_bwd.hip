@@ -16,7 +16,7 @@
 #endif
 __device__ __forceinline__ void transpose_tile(const uint16_t* __restrict__ src, const int ld_src, const int C,
                                                const int32_t* __restrict__ rows, const int cnt, const int off,
-                                               uint16_t* __restrict__ dst, const int ld_dst) {
+                                               uint16_t* __restrict__ dst, const int ld_dst, const bool compact = false) {
     __shared__ uint16_t tile[TR_TS][72];   // [slot][col], 144-byte rows: 16-byte aligned chunks, bank spread
     const int pad = (cnt + 7) & ~7;
     const int r0 = blockIdx.x * TR_TS, c0 = blockIdx.y * 64;
@@ -61,16 +61,18 @@ __device__ __forceinline__ void transpose_tile(const uint16_t* __restrict__ src,
         for (int q = 0; q < 8; ++q) t[q] = tile[sc * 8 + q][cc];
         const uint4 o = make_uint4((uint32_t)t[0] | ((uint32_t)t[1] << 16), (uint32_t)t[2] | ((uint32_t)t[3] << 16),
                                    (uint32_t)t[4] | ((uint32_t)t[5] << 16), (uint32_t)t[6] | ((uint32_t)t[7] << 16));
-        st16(dst + (size_t)(c0 + cc) * ld_dst + off + r0 + sc * 8, o);
+        // compact: the group's own block (C rows of `pad` elements) at dst + off * C; else column window [off, off + pad) of wide rows
+        if (compact) st16(dst + (size_t)off * C + (size_t)(c0 + cc) * pad + r0 + sc * 8, o);
+        else st16(dst + (size_t)(c0 + cc) * ld_dst + off + r0 + sc * 8, o);
     }
 }
 
 __global__ __launch_bounds__(256) void transpose_slots_kernel(const uint16_t* __restrict__ src, int ld_src, int C,
                                                               const int32_t* __restrict__ rows, const int32_t* __restrict__ counts,
                                                               const int32_t* __restrict__ offsets, int static_rows,
-                                                              uint16_t* __restrict__ dst, int ld_dst) {
+                                                              uint16_t* __restrict__ dst, int ld_dst, int compact) {
     const int g = blockIdx.z;
-    transpose_tile(src, ld_src, C, rows, counts ? counts[g] : static_rows, offsets ? offsets[g] : 0, dst, ld_dst);
+    transpose_tile(src, ld_src, C, rows, counts ? counts[g] : static_rows, offsets ? offsets[g] : 0, dst, ld_dst, compact != 0);
 }
 
 // the same plain transpose [R][C] -> [C][r8(R)] of up to 12 separate matrices of one shape in ONE launch (the per-expert weight
@@ -98,7 +100,18 @@ extern "C" int umoe_transpose_slots(const uint16_t* src, int ld_src, int C, cons
     const int G = counts ? n_groups : 1;
     UMOE_REQUIRE(G >= 1 && G <= 65535, "umoe_transpose_slots: bad group count");
     dim3 grid((unsigned)ceil_div(((max_rows + 7) & ~7), TR_TS), (unsigned)ceil_div(C, 64), (unsigned)G);
-    transpose_slots_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, ld_src, C, rows, counts, offsets, max_rows, dst, ld_dst);
+    transpose_slots_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, ld_src, C, rows, counts, offsets, max_rows, dst, ld_dst, 0);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int umoe_transpose_slots_compact(const uint16_t* src, int ld_src, int C, const int32_t* rows, const int32_t* counts,
+                                            const int32_t* offsets, int n_groups, int max_rows, uint16_t* dst, umoe_stream_t stream) {
+    UMOE_REQUIRE(src && dst && counts && offsets && C > 0 && max_rows >= 0 && n_groups >= 1 && n_groups <= 65535,
+                 "umoe_transpose_slots_compact: bad argument (counts and offsets are required)");
+    if (max_rows == 0) return 0;
+    dim3 grid((unsigned)ceil_div(((max_rows + 7) & ~7), TR_TS), (unsigned)ceil_div(C, 64), (unsigned)n_groups);
+    transpose_slots_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, ld_src, C, rows, counts, offsets, max_rows, dst, 0, 1);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -880,7 +893,7 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     // transposed slot buffers for the weight gradients
     const int Sp = r8(S);
     auto slots_t = [&](const uint16_t* src, int ld, int C, uint16_t* dst) -> int {
-        if (ragged) return umoe_transpose_slots(src, ld, C, nullptr, a->counts, a->offsets, G, S, dst, ldT, stream);
+        if (ragged) return umoe_transpose_slots_compact(src, ld, C, nullptr, a->counts, a->offsets, G, S, dst, stream);   // per-expert blocks
         for (int g = 0; g < G; ++g) {
             const size_t r0 = (size_t)a->row_base + (size_t)g * S;
             if (int rc2 = umoe_transpose_slots(src + r0 * ld, ld, C, nullptr, nullptr, nullptr, 1, S, dst + (size_t)g * Sp, ldT, stream)) return rc2;
@@ -891,7 +904,7 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     if ((rc = slots_t(a->h, a->ldh, I, hT))) return rc;
     if ((rc = slots_t(dgu, 2 * I, 2 * I, dguT))) return rc;
     if (ragged) {
-        if ((rc = umoe_transpose_slots(a->x, a->ldx, D, a->slot_token, a->counts, a->offsets, G, S, xeT, ldT, stream))) return rc;
+        if ((rc = umoe_transpose_slots_compact(a->x, a->ldx, D, a->slot_token, a->counts, a->offsets, G, S, xeT, stream))) return rc;
     } else {
         for (int g = 0; g < G; ++g)
             if ((rc = umoe_transpose_slots(a->x, a->ldx, D, nullptr, nullptr, nullptr, 1, S, xeT + (size_t)g * Sp, ldT, stream))) return rc;
@@ -900,8 +913,10 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     // When the caller's gradient buffers of a kind are one stacked allocation ([G][rows][cols], as ops.experts_swiglu_bwd makes
     // them) the G products of that kind are ONE grouped launch (per-group contraction window and output row base): 8 x 88
     // tiles fill the chip with the 256 x 256 variant, one expert's 88 tiles alone run on the small tiles at ~400 TFLOP/s.
-    auto window = [&](umoe_tgroup_t& t, int g) {
-        if (ragged) { t.k_off = a->offsets + g; t.k_count = a->counts + g; t.k = 8; }
+    // ragged: the transposed buffers are per-expert COMPACT blocks (rows roundup8(count) apart instead of the whole slot range:
+    // scripts/wgrad_bench.py, 296 -> 239 us per launch); a_total / w_total = total rows of the two operands
+    auto window = [&](umoe_tgroup_t& t, int g, int a_total, int w_total) {
+        if (ragged) { t.k_off = a->offsets + g; t.k_count = a->counts + g; t.k = 8; t.k_compact_a = a_total; t.k_compact_w = w_total; }
         else { t.k = Sp; t.a_col_off = g * Sp; }       // zero-padded private column range
     };
     auto stacked = [&](uint16_t* const* ptrs, size_t elems) {
@@ -909,7 +924,7 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
             if (ptrs[g] != ptrs[0] + (size_t)g * elems) return false;
         return true;
     };
-    auto products = [&](const uint16_t* wT, int n, int rows, const uint16_t* aT, int a_row_base, uint16_t* const* outs) -> int {
+    auto products = [&](const uint16_t* wT, int n, int rows, const uint16_t* aT, int a_row_base, int a_total, uint16_t* const* outs) -> int {
         // out_g [rows][n] = aT[a_row_base + r][cols_g] . wT[c][cols_g]
         umoe_tgemm_args b{};
         b.max_rows = rows; b.a = aT; b.lda = ldT; b.ldo = n; b.epilogue = UMOE_EPI_BF16;
@@ -918,7 +933,7 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
             for (int g = 0; g < G; ++g) {
                 tg[g].w = wT + (ragged ? 0 : g * Sp); tg[g].n = n; tg[g].ldw = ldT; tg[g].static_count = rows; tg[g].a_row_base = a_row_base;
                 tg[g].out_row_base = g * rows;
-                window(tg[g], g);
+                window(tg[g], g, a_total, n);
             }
             b.groups = tg; b.num_groups = G; b.out = outs[0];
             return umoe_tiled_gemm(&b, stream);
@@ -926,15 +941,15 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
         for (int g = 0; g < G; ++g) {
             umoe_tgroup_t t1{};
             t1.w = wT + (ragged ? 0 : g * Sp); t1.n = n; t1.ldw = ldT; t1.static_count = rows; t1.a_row_base = a_row_base;
-            window(t1, g);
+            window(t1, g, a_total, n);
             b.groups = &t1; b.num_groups = 1; b.out = outs[g];
             if (int rc2 = umoe_tiled_gemm(&b, stream)) return rc2;
         }
         return 0;
     };
-    if ((rc = products(hT, I, D, dyT, 0, a->dw_down))) return rc;
-    if ((rc = products(xeT, D, I, dguT, 0, a->dw_gate))) return rc;
-    if ((rc = products(xeT, D, I, dguT, I, a->dw_up))) return rc;
+    if ((rc = products(hT, I, D, dyT, 0, D, a->dw_down))) return rc;
+    if ((rc = products(xeT, D, I, dguT, 0, 2 * I, a->dw_gate))) return rc;
+    if ((rc = products(xeT, D, I, dguT, I, 2 * I, a->dw_up))) return rc;
     return 0;
 }
 

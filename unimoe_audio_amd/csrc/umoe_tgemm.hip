@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
         aok[ps] = r < count;
         long arow = 0;
         if (aok[ps]) arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
-        ap[ps] = p.a + arow * (long)p.lda + g.a_col_off + koff + ch * 8;
+        ap[ps] = p.a + (g.k_compact_a > 0 ? (long)koff * g.k_compact_a + arow * (long)K : arow * (long)p.lda + koff) + g.a_col_off + ch * 8;
     }
 #pragma unroll
     for (int ps = 0; ps < WPS; ++ps) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
             n = n0 + tr;
         }
         wok[ps] = n < g.n;
-        wp[ps] = wb + (long)(wok[ps] ? n : 0) * g.ldw + koff + ch * 8;
+        wp[ps] = wb + (g.k_compact_w > 0 ? (long)koff * g.k_compact_w + (long)(wok[ps] ? n : 0) * K : (long)(wok[ps] ? n : 0) * g.ldw + koff) + ch * 8;
     }
     uint4 ra[APS], rw[WPS];
     auto gload = [&](int k0) {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
             gad[j] = 0;
             if (r < count) {
                 const long arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
-                gad[j] = reinterpret_cast<const char*>(p.a + arow * (long)p.lda + g.a_col_off + koff + c * 8) - zero_b;
+                gad[j] = reinterpret_cast<const char*>(p.a + (g.k_compact_a > 0 ? (long)koff * g.k_compact_a + arow * (long)K : arow * (long)p.lda + koff) + g.a_col_off + c * 8) - zero_b;
             }
         }
 #pragma unroll
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(const umoe_tgemm_args p, 
             } else {
                 n = n0 + tr;
             }
-            gwd[j] = n < g.n ? reinterpret_cast<const char*>(wb + (long)n * g.ldw + koff + c * 8) - zero_b : 0;
+            gwd[j] = n < g.n ? reinterpret_cast<const char*>(wb + (g.k_compact_w > 0 ? (long)koff * g.k_compact_w + (long)n * K : (long)n * g.ldw + koff) + c * 8) - zero_b : 0;
         }
     }
     auto stage = [&](int buf, int k0) {
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
         tdel[q] = 0;
         if (r < count) {
             const long arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
-            tdel[q] = reinterpret_cast<const char*>(p.a + arow * (long)p.lda + g.a_col_off + koff + gch * 8) - zero;
+            tdel[q] = reinterpret_cast<const char*>(p.a + (g.k_compact_a > 0 ? (long)koff * g.k_compact_a + arow * (long)K : arow * (long)p.lda + koff) + g.a_col_off + gch * 8) - zero;
         }
         int n;
         const uint16_t* wb = g.w;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
         } else {
             n = n0 + tr;
         }
-        wdel[q] = n < g.n ? reinterpret_cast<const char*>(wb + (long)n * g.ldw + koff + gch * 8) - zero : 0;
+        wdel[q] = n < g.n ? reinterpret_cast<const char*>(wb + (g.k_compact_w > 0 ? (long)koff * g.k_compact_w + (long)n * K : (long)n * g.ldw + koff) + gch * 8) - zero : 0;
     }
     auto stage = [&](const long (&del)[2], const int unit_off, const int tile) {
         const int k0 = tile * 32;
