@@ -60,9 +60,11 @@ class EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, table):
+        # ids < 0: rows the caller overwrites afterwards (codec placeholders): they read row 0 and contribute no gradient -- without this
+        # the ~6 000 placeholder rows of a training batch all belong to ONE id, whose owner workgroup would add 25 MB of zeros alone
         ctx.save_for_backward(ids)
         ctx.V = table.shape[0]
-        return table[ids]
+        return table[ids.clamp(min=0)]
 
     @staticmethod
     def backward(ctx, dy):
@@ -212,7 +214,10 @@ def forward_train(model, input_ids, codec_input_ids, attention_mask, codec_label
                   return_routing: bool = False):
     """loss = sum_c CE_c(shifted codec logits) + cur_aux_weight * mean(layer aux)  (model.py:817-854), differentiable."""
     dev = model.device
-    x = EmbedFn.apply(input_ids.to(dev), model.language_model.embed_tokens.weight)
+    ids_dev = input_ids.to(dev)
+    if codec_input_ids is not None:      # placeholder positions are replaced below: their text-table rows get no gradient (exact zeros anyway)
+        ids_dev = torch.where(ids_dev == model.codec_placeholder_value, torch.full_like(ids_dev, -1), ids_dev)
+    x = EmbedFn.apply(ids_dev, model.language_model.embed_tokens.weight)
     if codec_input_ids is not None:
         ci = codec_input_ids.to(dev)
         # model.py:655-661 (sum of the per-channel embedding gathers; ids are clamped into the table like the decode kernel does)
