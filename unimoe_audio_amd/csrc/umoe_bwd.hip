@@ -276,6 +276,52 @@ __global__ __launch_bounds__(256) void permute_bwd_kernel(const uint16_t* __rest
                                                           int n_real, const uint16_t* __restrict__ dxsh, int n_fix, int S, int D,
                                                           const uint16_t* __restrict__ extra, uint16_t* __restrict__ dx) {
     const int s = blockIdx.x;
+    if ((D >> 3) == 256 && n_real <= 12 && n_fix <= 4) {
+        // D = 2048: every row of the token requested at once (the loop below reads slot -> row one dependent round trip at a time);
+        // the same additions in the same order
+        const int tid = threadIdx.x, lane = tid & 63, c = tid;
+        int slot_l = -1;
+        if (lane < n_real) slot_l = slot_of[(size_t)s * n_real + lane];
+        uint4 v[16];
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+            if (e < n_real) {
+                const int slot = __builtin_amdgcn_readlane(slot_l, e);
+                v[e] = ld16(dxe + (size_t)(slot >= 0 ? slot : 0) * D + c * 8);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n_fix) v[12 + i] = ld16(dxsh + ((size_t)i * S + s) * D + c * 8);
+        uint4 xv = make_uint4(0, 0, 0, 0);
+        if (extra) xv = ld16(extra + (size_t)s * D + c * 8);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 12; ++e)
+            if (e < n_real && __builtin_amdgcn_readlane(slot_l, e) >= 0) {
+                float f[8];
+                unpack8(v[e], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n_fix) {
+                float f[8];
+                unpack8(v[12 + i], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += f[j];
+            }
+        if (extra) {
+            float f[8];
+            unpack8(xv, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+        st16(dx + (size_t)s * D + c * 8, pack8(acc));
+        return;
+    }
     for (int c = threadIdx.x; c < (D >> 3); c += 256) {
         float acc[8];
 #pragma unroll
