@@ -380,6 +380,9 @@ typedef struct {
     uint16_t* const* dw_up;
     uint16_t* const* dw_down;
     void* ws; size_t ws_bytes;       /* umoe_swiglu_bwd_workspace_bytes() */
+    const uint16_t* w_down_T;        /* optional, both or neither: transposed weight copies kept by the caller while the weights are */
+    const uint16_t* w_gateup_T;      /* unchanged (gradient accumulation): group g's Wd^T [I][roundup8(D)] at w_down_T + g*I*roundup8(D),
+                                      * (Wg^T | Wu^T) [D][2I] at w_gateup_T + g*D*2I -- the layout the composite builds itself otherwise */
 } umoe_swiglu_bwd_args;
 size_t umoe_swiglu_bwd_workspace_bytes(const umoe_swiglu_bwd_args* a);
 int umoe_grouped_swiglu_bwd(const umoe_swiglu_bwd_args* a, umoe_stream_t stream);

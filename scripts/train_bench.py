@@ -62,4 +62,8 @@ with torch.no_grad():
 print(json.dumps({"workload": f"BASELINE configs[2]: fwd+bwd, {layers} layers, batch {B} x {T} tokens", "tokens_per_step": B * T,
                   "step_ms": round(dt * 1e3, 1), "tokens_per_s": round(B * T / dt, 1), "first_step_ms": round(t_first * 1e3, 1),
                   "forward_only_ms": round(min(tf) * 1e3, 1), "loss": round(l0, 4),
-                  "max_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}))
+                  "max_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                  "weights_unchanged_between_steps": True,
+                  "note": "layer math only, no optimizer step (SURVEY 8d config 3): the weights keep their versions, so from the third step on "
+                          "the transposed weight copies of the input-gradient GEMMs are reused (ops._WT_CACHE, the gradient-accumulation "
+                          "case); UMOE_WT_CACHE=0 rebuilds them every step as a trainer stepping after every backward would"}))

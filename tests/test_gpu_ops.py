@@ -839,6 +839,46 @@ def test_aux_loss_two_launch_form_vs_oracle(dev, weighted, bf16):
     assert torch.allclose(got.cpu().float(), one.cpu()[0].float(), rtol=1e-4, atol=1e-6)
 
 
+def test_backward_with_kept_weight_transposes_is_bit_identical(dev):
+    """Three backward passes over unchanged weights: the third reuses the transposed weight copies built during the second
+    (ops._WT_CACHE, umoe_swiglu_bwd_args.w_down_T / w_gateup_T) and must give the gradients of the first, bit for bit; an in-place
+    weight update drops the copies."""
+    from unimoe_audio_amd import ops
+    from unimoe_audio_amd.config import UniMoEAudioConfig
+    from unimoe_audio_amd.dcmoe import UniMoEAudioSparseMoeBlock
+    ops._WT_CACHE.clear()
+    torch.manual_seed(4)
+    cfg = UniMoEAudioConfig(hidden_size=256, dynamic_intermediate_size=128, shared_intermediate_size=64, input_jitter_noise=0.0)
+    blk = UniMoEAudioSparseMoeBlock(cfg)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.normal_(0, 0.05)
+    blk = blk.to(dev, torch.bfloat16).train()
+    for p in blk.parameters():
+        p.requires_grad_(True)
+    x0 = torch.randn(1, 160, 256).to(torch.bfloat16).to(dev)
+    G = torch.randn(1, 160, 256).to(torch.bfloat16).to(dev)
+
+    def run():
+        for p in blk.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        out = blk(x, None, None)
+        (out[0].float() * G.float()).sum().backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+    a, b, c = run(), run(), run()
+    built = [e for e in ops._WT_CACHE.values() if e["t"] is not None]
+    assert len(built) >= 2                       # routed and shared experts of the block
+    for u, v, w in zip(a, b, c):
+        assert torch.equal(u, v) and torch.equal(u, w)
+    with torch.no_grad():
+        next(iter(blk._experts()[0].parameters())).mul_(1.5)
+    d = run()
+    assert not torch.equal(d[0], a[0])           # the new weights were used, not the stale copies
+    e = run()
+    assert all(torch.equal(p, q) for p, q in zip(d, e))
+
+
 def test_mul_noise_is_the_three_torch_ops(dev):
     """umoe_mul_noise == (x.float() * noise).to(bfloat16), bit for bit (core.py:240-244 input jitter on the gate's copy)."""
     from unimoe_audio_amd import ops

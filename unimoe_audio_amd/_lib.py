@@ -65,7 +65,7 @@ class SwigluBwdArgs(C.Structure):
                 ("counts", vp), ("offsets", vp), ("slot_token", vp), ("max_rows", i32), ("slot_rows", i32), ("row_base", i32),
                 ("x", vp), ("ldx", i32), ("h", vp), ("ldh", i32), ("gu", vp), ("ldgu", i32), ("dy", vp), ("lddy", i32),
                 ("dx_slots", vp), ("lddx", i32), ("dw_gate", C.POINTER(vp)), ("dw_up", C.POINTER(vp)), ("dw_down", C.POINTER(vp)),
-                ("ws", vp), ("ws_bytes", C.c_size_t)]
+                ("ws", vp), ("ws_bytes", C.c_size_t), ("w_down_T", vp), ("w_gateup_T", vp)]
 
 
 class AttnBwdArgs(C.Structure):

@@ -950,8 +950,12 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     UMOE_REQUIRE(a->ws_bytes >= need, "umoe_*_swiglu_bwd: workspace too small (%zu < %zu bytes)", a->ws_bytes, need);
     const int G = a->num_groups, D = a->D, I = a->I, S = a->max_rows;
     int rc;
-    // transposed weight copies: Wd^T [I][r8(D)], (Wg^T | Wu^T) [D][2I]
-    {
+    // transposed weight copies: Wd^T [I][r8(D)], (Wg^T | Wu^T) [D][2I] -- the caller's, when it kept them (unchanged weights)
+    UMOE_REQUIRE((a->w_down_T == nullptr) == (a->w_gateup_T == nullptr), "umoe_*_swiglu_bwd: w_down_T and w_gateup_T come together");
+    if (a->w_down_T) {
+        wdT = const_cast<uint16_t*>(a->w_down_T);
+        wguT = const_cast<uint16_t*>(a->w_gateup_T);
+    } else {
         uint16_t* d1[12];
         uint16_t* d2[12];
         uint16_t* d3[12];

@@ -540,6 +540,54 @@ def rmsnorm_bwd(h: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, 
     return dh, dw
 
 
+# Transposed expert-weight copies kept across calls while the weights are unchanged (gradient accumulation: several backward passes
+# per optimizer step).  Keyed by the first weight's storage; an entry is BUILT only when two consecutive calls saw the same parameter
+# versions (a trainer that steps the optimizer after every backward never pays for a copy it cannot reuse) and replaced when they change.
+_WT_CACHE: dict = {}
+
+
+def _wt_cache_on() -> bool:
+    import os
+    return os.environ.get("UMOE_WT_CACHE", "1") != "0"
+
+
+def _cached_weight_transposes(ws_list, D: int, I: int):
+    if not _wt_cache_on():
+        return None
+    key = ws_list[0][0].data_ptr()
+    ver = tuple((t.data_ptr(), t._version) for w in ws_list for t in w)
+    ent = _WT_CACHE.get(key)
+    if ent is not None and ent["ver"] == ver:
+        if ent["t"] is None:                         # second call with these versions: worth keeping the copies
+            G, Dp = len(ws_list), _r8(D)
+            dev = ws_list[0][0].device
+            wdT = torch.zeros((G, I, Dp), dtype=torch.bfloat16, device=dev)
+            wguT = torch.empty((G, D, 2 * I), dtype=torch.bfloat16, device=dev)
+            for g, (wg, wu, wd) in enumerate(ws_list):
+                wdT[g, :, :D] = wd.detach().t()
+                wguT[g, :, :I] = wg.detach().t()
+                wguT[g, :, I:] = wu.detach().t()
+            ent["t"] = (wdT, wguT)
+        return ent["t"]
+    _WT_CACHE[key] = dict(ver=ver, t=None)
+    return None
+
+
+def transpose_weight_cached(w: torch.Tensor) -> torch.Tensor:
+    """transpose(w) for an input-gradient GEMM; a PARAMETER's copy is kept while its version is unchanged (same two-call rule)."""
+    if not (w.is_leaf and w.requires_grad and _wt_cache_on()):
+        return transpose(w)
+    key = ("lin", w.data_ptr())
+    ver = (w.data_ptr(), w._version, tuple(w.shape))
+    ent = _WT_CACHE.get(key)
+    if ent is not None and ent["ver"] == ver:
+        if ent["t"] is None:
+            ent["t"] = transpose(w.detach())
+        return ent["t"]
+    _WT_CACHE[key] = dict(ver=ver, t=None)
+    return transpose(w)
+
+
 def experts_swiglu_bwd(ws_list, *, x, h, gu, dy, dx_slots, D: int, I: int, max_rows: int, counts=None, offsets=None, slot_token=None,
                        row_base: int = 0):
     """umoe_grouped_swiglu_bwd (counts/offsets given: routed experts) or umoe_shared_swiglu_bwd (static groups).
@@ -559,6 +607,9 @@ def experts_swiglu_bwd(ws_list, *, x, h, gu, dy, dx_slots, D: int, I: int, max_r
     nbytes = L.lib().umoe_swiglu_bwd_workspace_bytes(C.byref(a))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     a.ws, a.ws_bytes = ws.data_ptr(), nbytes
+    kept = _cached_weight_transposes(ws_list, D, I)
+    if kept is not None:
+        a.w_down_T, a.w_gateup_T = kept[0].data_ptr(), kept[1].data_ptr()
     fn = L.lib().umoe_grouped_swiglu_bwd if counts is not None else L.lib().umoe_shared_swiglu_bwd
     L.check(fn(C.byref(a), _stream()), "umoe_swiglu_bwd (composite)")
     return dwg, dwu, dwd

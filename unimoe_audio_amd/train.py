@@ -45,7 +45,7 @@ class LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = dy.to(torch.bfloat16).contiguous()
         S = x.shape[0]
-        dx = ops.tlinear(_pad8(dy), ops.transpose(w)) if ctx.needs_input_grad[0] else None   # [S][N] x [K][N]^T
+        dx = ops.tlinear(_pad8(dy), ops.transpose_weight_cached(w)) if ctx.needs_input_grad[0] else None   # [S][N] x [K][N]^T
         dw = None
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -255,7 +255,7 @@ class _HeadFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dyb = dy.to(torch.bfloat16).contiguous()
-        dx = ops.tlinear(_pad8(dyb), ops.transpose(w))
+        dx = ops.tlinear(_pad8(dyb), ops.transpose_weight_cached(w))
         dw = torch.empty_like(w)
         ops.tiled_gemm([dict(w=ops.transpose(x), static_count=w.shape[0])], ops.transpose(dyb), dw, max_rows=w.shape[0])
         return dx, dw
