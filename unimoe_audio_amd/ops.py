@@ -554,10 +554,13 @@ def _wt_cache_on() -> bool:
 def _cached_weight_transposes(ws_list, D: int, I: int):
     if not _wt_cache_on():
         return None
+    import weakref
     key = ws_list[0][0].data_ptr()
     ver = tuple((t.data_ptr(), t._version) for w in ws_list for t in w)
     ent = _WT_CACHE.get(key)
-    if ent is not None and ent["ver"] == ver:
+    # (address + version can repeat when a model is freed and another one lands on the same memory: the entry also has to be about
+    #  the very same tensor OBJECTS, which the weak references can only return while those are alive)
+    if ent is not None and ent["ver"] == ver and all(r() is t for r, t in zip(ent["refs"], (t for w in ws_list for t in w))):
         if ent["t"] is None:                         # second call with these versions: worth keeping the copies
             G, Dp = len(ws_list), _r8(D)
             dev = ws_list[0][0].device
@@ -569,7 +572,7 @@ def _cached_weight_transposes(ws_list, D: int, I: int):
                 wguT[g, :, I:] = wu.detach().t()
             ent["t"] = (wdT, wguT)
         return ent["t"]
-    _WT_CACHE[key] = dict(ver=ver, t=None)
+    _WT_CACHE[key] = dict(ver=ver, t=None, refs=[weakref.ref(t) for w in ws_list for t in w])
     return None
 
 
@@ -577,14 +580,15 @@ def transpose_weight_cached(w: torch.Tensor) -> torch.Tensor:
     """transpose(w) for an input-gradient GEMM; a PARAMETER's copy is kept while its version is unchanged (same two-call rule)."""
     if not (w.is_leaf and w.requires_grad and _wt_cache_on()):
         return transpose(w)
+    import weakref
     key = ("lin", w.data_ptr())
     ver = (w.data_ptr(), w._version, tuple(w.shape))
     ent = _WT_CACHE.get(key)
-    if ent is not None and ent["ver"] == ver:
+    if ent is not None and ent["ver"] == ver and ent["refs"][0]() is w:
         if ent["t"] is None:
             ent["t"] = transpose(w.detach())
         return ent["t"]
-    _WT_CACHE[key] = dict(ver=ver, t=None)
+    _WT_CACHE[key] = dict(ver=ver, t=None, refs=[weakref.ref(w)])
     return transpose(w)
 
 
