@@ -425,6 +425,34 @@ def test_checkpoint_round_trip_generates_identical_codes(dev, tmp_path):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("B", [1, 3, 5])
+def test_fused_launches_with_fewer_than_16_rows_are_bit_identical(dev, monkeypatch, B):
+    """2, 6 and 10 decode rows (batch 1, 3, 5): the dense layout with the fused expert launch, the riders' hand-off and the combine riding
+    in the QKV launch against the launch-per-kernel form (UMOE_RIDER_PUB=0 switches all three off) and against the ragged dispatch path
+    where it still exists (UMOE_DENSE_MIN_ROWS=17): identical codes -- the partial-tile guards of every hand-off."""
+    from unimoe_audio_amd.codec_utils import DecoderOutput, prepare_audio_prompt
+    cfg = small_cfg(hidden_size=2048, num_attention_heads=16, num_key_value_heads=2, num_hidden_layers=2,
+                    dynamic_intermediate_size=2752, shared_intermediate_size=1376)
+    T, max_tokens = 12, 8
+    ids, am, codec = prompt(cfg, B, T, 4, [1] + [0] * (2 * B - 1))
+    pre, psteps = prepare_audio_prompt(cfg, [None] * B)
+    outs = []
+    for pub, dense_min in (("1", "2"), ("0", "2"), ("1", "17")):
+        monkeypatch.setenv("UMOE_RIDER_PUB", pub)
+        monkeypatch.setenv("UMOE_DENSE_MIN_ROWS", dense_min)
+        m, _ = build(cfg, 31, 0.03)
+        m = m.to(dev)
+        dec = DecoderOutput(pre.clone(), psteps, dev)
+        codes, lengths = m.generate(ids, am, dec, max_tokens, 4, codec_input_ids=codec, cfg_scale=2.0, do_sample=True, temperature=1.0,
+                                    top_p=0.9, eos_prob_mul_factor=0.8, seed=3)
+        outs.append((codes.cpu(), lengths.cpu()))
+        del m
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # the ragged path computes the same products per (expert, row) with the same kernels' K split: identical too
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+
+
 def test_router_riding_in_the_gate_up_launch_is_bit_identical(dev, monkeypatch):
     """Dense decode runs the Top-P router as rider workgroups inside the gate/up launch (umoe_gemm_args.fused_router) behind an
     RMSNorm-only launch (umoe_router_args.norm_only).  Same arithmetic, same order: the generated codes and the per-layer router
