@@ -211,8 +211,12 @@ int umoe_router_norm_push(const umoe_router_args* a, const umoe_ep_xfer& x, hipS
 int umoe_ep_rccl_allgather(void* comm, const void* send, void* recv, size_t bytes, hipStream_t s);
 
 // ---- riders publish the normalised rows inside the gate/up launch (umoe_gemm_args.rider_pub -> this, host side) ------------
+// The row flags are REPLICATED: UMOE_FLAG_REPL copies of the 16-word line, 64 bytes apart; a rider stores its epoch into every copy,
+// a polling workgroup reads copy (its id % UMOE_FLAG_REPL) -- 226 workgroups polling ONE line serialised at that line's home
+// (scripts/timeline_wgs.py: 3 us from flag store to detection).
+#define UMOE_FLAG_REPL 8
 struct umoe_rider_pub {
-    uint32_t* flags;           // device [S] words, one per token row, monotonic epochs
+    uint32_t* flags;           // device [UMOE_FLAG_REPL][16] words, one per token row and replica, monotonic epochs
     const uint32_t* step;      // device word: decode steps taken so far
     int layer, layers;         // epoch = *step * layers + layer + 1
     uint32_t* err;             // device word, sticky: 2 = a workgroup gave up waiting for the riders

@@ -312,7 +312,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
         return -2;
     }
     // [0] decode steps taken, [1] sticky hand-off error, [16..32) row flags of the rider hand-off (umoe_gemm_args.rider_pub)
-    if (hipMalloc(&e->ep_words, 4096) != hipSuccess || hipMemset(e->ep_words, 0, 4096) != hipSuccess) {
+    if (hipMalloc(&e->ep_words, 16384) != hipSuccess || hipMemset(e->ep_words, 0, 16384) != hipSuccess) {
         umoe_set_error("umoe_engine_create: hipMalloc failed (state words)");
         umoe_engine_destroy(e);
         return -2;
@@ -717,7 +717,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
             umoe_rider2 r2{};
             r2.n_riders = n_tok; r2.cb = e->cb_stash;
             umoe_rider_pub cpub{};
-            cpub.flags = e->ep_words + 32; cpub.step = e->ep_words; cpub.layer = l; cpub.layers = c.layers; cpub.err = e->ep_words + 1;
+            cpub.flags = e->ep_words + 1024 + 16 * UMOE_FLAG_REPL; cpub.step = e->ep_words; cpub.layer = l; cpub.layers = c.layers; cpub.err = e->ep_words + 1;
             rc = umoe_gemm_riders(&a, 2, &r2, &cpub, s);
             if (rc == 1 && (rc = umoe_unpermute_combine_fwd(&e->cb_stash, s)) == 0) rc = 1;     // shapes do not fit: the two launches
         }
@@ -767,7 +767,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         umoe_rider2 r2{};
         r2.n_riders = n_tok; r2.part_o = e->part_o; r2.part_ml = e->part_ml; r2.attn_out = e->attn_out; r2.H = c.heads; r2.splits = splits;
         umoe_rider_pub apub{};
-        apub.flags = e->ep_words + 48; apub.step = e->ep_words; apub.layer = l; apub.layers = c.layers; apub.err = e->ep_words + 1;
+        apub.flags = e->ep_words + 1024 + 32 * UMOE_FLAG_REPL; apub.step = e->ep_words; apub.layer = l; apub.layers = c.layers; apub.err = e->ep_words + 1;
         rc = umoe_gemm_riders(&o, 3, &r2, &apub, s);
         if (rc == 1) {       // shapes do not fit the riders: merge in a launch of its own, then the plain o_proj
             umoe_attn_args m = t;
@@ -838,7 +838,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     if (rc) return rc;
     PROF(K_ROUTER);
     umoe_rider_pub rpub{};
-    rpub.flags = e->ep_words + 16; rpub.step = e->ep_words; rpub.layer = l; rpub.layers = c.layers; rpub.err = e->ep_words + 1;
+    rpub.flags = e->ep_words + 1024; rpub.step = e->ep_words; rpub.layer = l; rpub.layers = c.layers; rpub.err = e->ep_words + 1;
     rpub.rs = reinterpret_cast<unsigned long long*>(e->ep_words + 512);
     // 7./8. experts.  The shared experts need no routing: with `overlap_shared` they run on a second stream from the
     // residual stream x1 (their own RMSNorm prologue) BESIDE the latency-bound router + dispatch (forked after o_proj,

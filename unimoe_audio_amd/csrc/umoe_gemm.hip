@@ -281,7 +281,7 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
         if (UMOE_POLLER_WAVE ? (poller && lane < count) : (tid < count)) {
             const int tid = lane;      // (row of this lane)
             const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
-            umoe_gu32* f = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.flags + row0 + tid));
+            umoe_gu32* f = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.flags + ((blk.x + blk.z * blk.gx) % UMOE_FLAG_REPL) * 16 + row0 + tid));
             umoe_gu32* err = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.err));
             const unsigned long long t0 = wall_clock64();
             for (unsigned spins = 0;; ++spins) {

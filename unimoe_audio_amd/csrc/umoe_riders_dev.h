@@ -20,8 +20,8 @@ struct umoe_rider2 {
 __device__ __forceinline__ void rider_publish(uint32_t* flag, uint32_t epoch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
     __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(flag)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < UMOE_FLAG_REPL)      // `flag` = this row's word in replica 0; the replicas are 16 words apart
+        __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(flag + threadIdx.x * 16)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void st16_sc1(uint16_t* base, long elem_off, uint4 v, long bytes) {

@@ -472,8 +472,8 @@ __device__ __forceinline__ void router4_body(const umoe_router_args& a, const in
     if (lane < UMOE_MAXE) lg_part[wave][lane] = mine;
     if (pub_flag) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its sc1 stores
     __syncthreads();
-    if (pub_flag && tid == 0)
-        __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub_flag + s)), pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pub_flag && tid < UMOE_FLAG_REPL)       // one store per replica of the flag line (umoe_common.h)
+        __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub_flag + tid * 16 + s)), pub_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wave != 0) return;
     float full = -INFINITY;
     if (lane < NEc) full = round_t(((lg_part[0][lane] + lg_part[1][lane]) + lg_part[2][lane]) + lg_part[3][lane], T);
