@@ -84,6 +84,10 @@ typedef struct {
     const float* rand_u;      /* [S][n_dyn] fp32 uniform [0,1) draws, one per (token, round); required with gumbel */
     float* round_factor;      /* optional out [S][n_dyn]: mask_for_one of round j as 1 / 0.3333 (T-rounded), 0 beyond k; kept for
                                * umoe_router_bwd_ex (AudioMoERoutingFunction.backward, core.py:64-91) */
+    /* training-time input jitter with the fp32 gate (core.py:240-249: `hidden_states.float()` times U(1-eps, 1+eps) noise, then the
+     * fp32 gate GEMM): the gate sees float(x[s][d]) * x_noise[s][d] with NO rounding to bf16 in between.  The noise is an INPUT like
+     * the mixer's.  Needs x / gate_w, excludes norm_w / h_out / logits_in. */
+    const float* x_noise;     /* optional [S][D] fp32 */
 } umoe_router_args;
 int umoe_router_fwd(const umoe_router_args* a, umoe_stream_t stream);
 

@@ -119,13 +119,20 @@ class DCMoEOracle:
         return torch.einsum("se,sem->sm", weight, out_dense)    # :488
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                aux_balance_weight: Optional[torch.Tensor] = None, training: bool = False):
+                aux_balance_weight: Optional[torch.Tensor] = None, training: bool = False,
+                input_noise: Optional[torch.Tensor] = None):
+        """input_noise [B,T,D]: the samples of the input jitter (:243-244), required when training and input_jitter_noise > 0."""
         cfg = self.cfg
         B, T, D = hidden_states.shape
         orig = hidden_states
         h = hidden_states
         if training and cfg.fp32_gate:
             h = h.float()                                        # :240-241
+        if training and float(getattr(cfg, "input_jitter_noise", 0.0)) > 0:
+            assert input_noise is not None, "training with input_jitter_noise > 0: pass the samples (input_noise)"
+            h = h * input_noise.to(h.dtype)                      # :243-244
+            if not cfg.fp32_gate:
+                orig = h                                         # in place on the tensor `original_hidden_states` aliases (:238)
         h = h.reshape(-1, D)
         gate_w = self._w("gate.weight")
         if training and cfg.fp32_gate:

@@ -126,17 +126,28 @@ def aux_loss(mask: torch.Tensor, n_dyn: int, logits: torch.Tensor, aux_balance_w
 
 
 def forward(cfg, weights: Dict[str, torch.Tensor], hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-            aux_balance_weight: Optional[torch.Tensor] = None, training: bool = True, forced=None, noise=None):
+            aux_balance_weight: Optional[torch.Tensor] = None, training: bool = True, forced=None, noise=None, input_noise=None):
     """-> (out [B,T,D], logits, top_k, expert_mask, global_weight, aux); differentiable in hidden_states and weights.
-    noise = (gumbel, rand): required when the mixer's training branch runs (training and not ignore_differentiable_router)."""
+    noise = (gumbel, rand): required when the mixer's training branch runs (training and not ignore_differentiable_router).
+    input_noise [B,T,D]: the samples of the input jitter (core.py:243-244; required when training and input_jitter_noise > 0): on the
+    float copy the gate reads with the fp32 gate, on the rows themselves (bf16, experts included: the reference's in-place product
+    works on the tensor `original_hidden_states` aliases) without it."""
     B, T, D = hidden_states.shape
     n_real, n_fix = cfg.mlp_dynamic_expert_num, cfg.mlp_fixed_expert_num
     n_dyn = n_real + cfg.mlp_dynamic_null_expert_num
     x = hidden_states.reshape(-1, D)
     gate_w = weights["gate.weight"]
+    jitter = training and float(getattr(cfg, "input_jitter_noise", 0.0)) > 0
+    if jitter:
+        assert input_noise is not None, "training with input_jitter_noise > 0: pass the samples (input_noise)"
     if training and cfg.fp32_gate:
-        logits = F.linear(x.float(), gate_w.float())
+        xg = x.float()
+        if jitter:
+            xg = xg * input_noise.reshape(-1, D).float()
+        logits = F.linear(xg, gate_w.float())
     else:
+        if jitter:
+            x = x * input_noise.reshape(-1, D).to(x.dtype)
         logits = F.linear(x, gate_w)
     dyn = logits[:, :n_dyn]
     if cfg.mlp_dynamic_top_p != 0:

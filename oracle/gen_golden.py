@@ -138,6 +138,37 @@ class NoiseInjector:
             self.o_sel, self.o_mix, self.o_gum, self.o_rand)
 
 
+class InputNoiseInjector:
+    """Replaces the draw of the block's input jitter (core.py:243-244: `torch.empty_like(hidden_states).uniform_(1 - eps, 1 + eps)`) by a
+    fixed tensor: `Tensor.uniform_` on a tensor of the noise's shape copies the fixed samples in (cast to that tensor's dtype -- fp32
+    with the fp32 gate, bf16 without); every other `uniform_` call is left alone."""
+
+    def __init__(self, noise):
+        self.noise, self.served = noise, 0
+
+    def __enter__(self):
+        self.orig = torch.Tensor.uniform_
+        inj = self
+
+        def uni(t, *a, **k):
+            if tuple(t.shape) == tuple(inj.noise.shape):
+                inj.served += 1
+                return t.copy_(inj.noise)
+            return inj.orig(t, *a, **k)
+
+        torch.Tensor.uniform_ = uni
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.uniform_ = self.orig
+
+
+def _input_noise(c, B, T, seed):
+    gn = torch.Generator().manual_seed(seed)
+    eps = c.input_jitter_noise
+    return (1.0 - eps) + 2.0 * eps * torch.rand((B, T, c.hidden_size), generator=gn)
+
+
 def gen_router_ids(ref, out):
     core = ref.core
     torch.manual_seed(100)
@@ -198,6 +229,10 @@ def gen_dcmoe(ref, out):
         bf16_d128=dict(hidden_size=128, dynamic_intermediate_size=160, shared_intermediate_size=96),
         bf16_nonull=dict(mlp_dynamic_null_expert_num=0),
         bf16_noshared=dict(mlp_fixed_expert_num=0),
+        # input jitter (core.py:243-244) with its noise injected (in_input_noise): on the fp32 copy the gate reads (fp32 gate), or in
+        # place on the bf16 rows that `original_hidden_states` aliases, so that the experts see them too (bf16 gate)
+        bf16_train_inputjitter=dict(_train=True, _xnoise=True, input_jitter_noise=0.01),
+        bf16_train_inputjitter_bf16gate=dict(_train=True, _xnoise=True, input_jitter_noise=0.01, fp32_gate=False),
     )
     for vi, (name, over) in enumerate(variants.items()):
         over = dict(over)
@@ -205,6 +240,7 @@ def gen_dcmoe(ref, out):
         dt = over.pop("_dtype", torch.bfloat16)
         auxw = over.pop("_auxw", False)
         train = over.pop("_train", False)
+        xnoise = over.pop("_xnoise", False)
         c = block_cfg(**over)
         torch.manual_seed(200 + vi)
         blk = core.UniMoEAudioSparseMoeBlock(c)
@@ -223,14 +259,22 @@ def gen_dcmoe(ref, out):
         aw = None
         if auxw:
             aw = torch.rand(B, T)
+        xinj = InputNoiseInjector(_input_noise(c, B, T, 5000 + vi)) if xnoise else None
+        if xinj is not None:
+            xinj.__enter__()
         with MixerRecorder(core) as rec, torch.no_grad():
             o = blk(x.clone(), am, aw)
+        if xinj is not None:
+            xinj.__exit__()
+            assert xinj.served == 1
         d = {"in_x": x, "out_hidden": o[0], "out_logits": o[1], "out_top_k": o[2], "out_mask": o[3],
              "out_weight": o[4], "out_aux": o[5], "out_sel": rec.selection(o[2].long(), c.mlp_dynamic_expert_num + c.mlp_dynamic_null_expert_num)}
         if am is not None:
             d["in_attention_mask"] = am
         if aw is not None:
             d["in_aux_balance_weight"] = aw
+        if xinj is not None:
+            d["in_input_noise"] = xinj.noise
         for n, p in blk.state_dict().items():
             d["w." + n] = p
         d["cfg_json"] = np.frombuffer(__import__("json").dumps(
@@ -256,6 +300,10 @@ def gen_dcmoe_bwd(ref, out):
         # tensors, saved in the fixture: in_gumbel [S, n_dyn(round), n_dyn], in_rand [S, n_dyn(round)]
         train_diffrouter=dict(_train=True, _noise=True, ignore_differentiable_router=False),
         train_diffrouter_bf16gate=dict(_train=True, _noise=True, ignore_differentiable_router=False, fp32_gate=False),
+        # input jitter with injected noise (see gen_dcmoe); bf16 gate: the in-place product needs a non-leaf input (a clone), as in
+        # the model, where the rows are the output of the post-attention RMSNorm
+        train_inputjitter=dict(_train=True, _xnoise=True, input_jitter_noise=0.01),
+        train_inputjitter_bf16gate=dict(_train=True, _xnoise=True, input_jitter_noise=0.01, fp32_gate=False),
     )
     for vi, (name, over) in enumerate(variants.items()):
         over = dict(over)
@@ -263,6 +311,7 @@ def gen_dcmoe_bwd(ref, out):
         pad = over.pop("_pad", False)
         auxw = over.pop("_auxw", False)
         noise = over.pop("_noise", False)
+        xnoise = over.pop("_xnoise", False)
         c = block_cfg(**over)
         torch.manual_seed(900 + vi)
         blk = core.UniMoEAudioSparseMoeBlock(c)
@@ -289,8 +338,14 @@ def gen_dcmoe_bwd(ref, out):
             u = torch.rand((B * T, n_dyn_, n_dyn_), generator=gn).clamp_(1e-20, 1.0 - 1e-7)
             inj = NoiseInjector(core, -torch.log(-torch.log(u)), torch.rand((B * T, n_dyn_), generator=gn))
             inj.__enter__()
+        xinj = InputNoiseInjector(_input_noise(c, B, T, 5100 + vi)) if xnoise else None
+        if xinj is not None:
+            xinj.__enter__()
         with MixerRecorder(core) as rec:
-            o = blk(x, am, aw)
+            o = blk(x.clone() if xnoise else x, am, aw)
+        if xinj is not None:
+            xinj.__exit__()
+            assert xinj.served == 1
         if inj is not None:
             inj.__exit__()
         loss = (o[0].float() * G.float()).sum() + aux_coef * o[5].float()
@@ -313,6 +368,8 @@ def gen_dcmoe_bwd(ref, out):
         if inj is not None:
             d["in_gumbel"], d["in_rand"] = inj.gumbel, inj.rand
             assert inj.rounds_served > 0
+        if xinj is not None:
+            d["in_input_noise"] = xinj.noise
         for n, p in blk.named_parameters():
             d["w." + n] = p.detach()
             d["g." + n] = p.grad if p.grad is not None else torch.zeros_like(p)

@@ -276,6 +276,8 @@ def test_dcmoe_block_vs_reference_goldens(dev, path):
     w = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
     blk = _mk_block(cfgd, w, dev)
     blk.train(bool(int(g["train"])))
+    if "in_input_noise" in g:     # input jitter (core.py:243-244): the samples the reference run was given, injected
+        blk._input_noise_inject = g["in_input_noise"]
     am = g.get("in_attention_mask")
     aw = g.get("in_aux_balance_weight")
     with torch.no_grad():
@@ -336,6 +338,8 @@ def test_dcmoe_block_backward_vs_reference_autograd(dev, path):
     blk.train(bool(int(g["train"])))
     if "in_gumbel" in g:          # the mixer's training branch (core.py:111-137): the reference's own noise draws, injected
         blk._router_noise = (g["in_gumbel"], g["in_rand"])
+    if "in_input_noise" in g:     # input jitter (core.py:243-244): on the gate's fp32 copy (fp32 gate) / on the rows themselves (bf16 gate)
+        blk._input_noise_inject = g["in_input_noise"]
     for p_ in blk.parameters():
         p_.requires_grad_(True)
     am, aw = g.get("in_attention_mask"), g.get("in_aux_balance_weight")

@@ -36,7 +36,7 @@ class RouterArgs(C.Structure):
                 ("S", i32), ("D", i32), ("n_dyn", i32), ("n_real", i32), ("n_fix", i32), ("logits_bf16", i32),
                 ("top_p", f32), ("fixed_top_k", i32), ("jitter_eps", f64), ("rms_eps", f32),
                 ("logits_out", vp), ("top_k", vp), ("sel", vp), ("expert_mask", vp), ("routing_w", vp),
-                ("global_w", vp), ("moe_w", vp), ("norm_only", i32), ("gumbel", vp), ("rand_u", vp), ("round_factor", vp)]
+                ("global_w", vp), ("moe_w", vp), ("norm_only", i32), ("gumbel", vp), ("rand_u", vp), ("round_factor", vp), ("x_noise", vp)]
 
 
 class Group(C.Structure):

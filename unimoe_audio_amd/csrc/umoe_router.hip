@@ -98,7 +98,7 @@ template <int ND, int NF>
 static void launch_router(const umoe_router_args* a, dim3 grid, hipStream_t st) {
     (void)grid;
     if constexpr (ND > 0) {
-        if (a->S <= 256 && !a->logits_in && (a->D == 2048 || a->D == 4096)) {
+        if (a->S <= 256 && !a->logits_in && !a->x_noise && (a->D == 2048 || a->D == 4096)) {
             if (a->logits_bf16) router_kernel4<ND, NF, 1><<<dim3((unsigned)a->S), 256, 0, st>>>(*a);
             else router_kernel4<ND, NF, 0><<<dim3((unsigned)a->S), 256, 0, st>>>(*a);
             return;
@@ -119,6 +119,8 @@ static int router_check(const umoe_router_args* a) {
     UMOE_REQUIRE(a->logits_in || (a->x && a->gate_w && a->D > 0 && a->D % 8 == 0),
                  "umoe_router_fwd: need logits_in or (x, gate_w, D %% 8 == 0)");
     UMOE_REQUIRE(!a->gumbel || a->rand_u, "umoe_router_fwd: the training branch of the mixer needs both noise tensors (gumbel, rand_u)");
+    UMOE_REQUIRE(!a->x_noise || (a->x && !a->logits_in && !a->norm_w && !a->h_out && !a->norm_only),
+                 "umoe_router_fwd: x_noise (input jitter) goes with (x, gate_w) only: no logits_in / norm_w / h_out / norm_only");
     return 0;
 }
 

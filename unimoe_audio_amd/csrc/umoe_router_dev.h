@@ -101,7 +101,7 @@ __device__ __forceinline__ int route_token(const umoe_router_args& a, const int 
         if (lane < E)
             full = T ? bf2f(reinterpret_cast<const uint16_t*>(a.logits_in)[(size_t)s * E + lane])
                      : reinterpret_cast<const float*>(a.logits_in)[(size_t)s * E + lane];
-    } else if (ND > 0 && a.D <= 2048 && (a.D & 511) == 0) {
+    } else if (ND > 0 && a.D <= 2048 && (a.D & 511) == 0 && !a.x_noise) {
         // decode fast path: EVERY load of this token (row, norm weights, all E gate rows) is in flight before the
         // first use -- one memory latency instead of one per chunk (the gate weights are cold in HBM every layer)
         constexpr int NEc = ND > 0 ? ND + NF : 1;  // (the generic instantiation never takes this branch)
@@ -191,6 +191,12 @@ __device__ __forceinline__ int route_token(const umoe_router_args& a, const int 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = rbf(w[j] * rbf(f[j] * rs));
                 u = pack8(f);
+            }
+            if (a.x_noise) {   // input jitter in front of the fp32 gate (core.py:240-249): the product stays fp32
+                const float4* nz = reinterpret_cast<const float4*>(a.x_noise + (size_t)s * a.D + c * 8);
+                const float4 n0 = nz[0], n1 = nz[1];
+                f[0] *= n0.x; f[1] *= n0.y; f[2] *= n0.z; f[3] *= n0.w;
+                f[4] *= n1.x; f[5] *= n1.y; f[6] *= n1.z; f[7] *= n1.w;
             }
             if (a.h_out) st16(a.h_out + (size_t)s * a.D + c * 8, u);
 #pragma unroll

@@ -164,6 +164,25 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         u = torch.rand((S, n, n), device=device).clamp_(1e-20, 1.0 - 1e-7)
         return -torch.log(-torch.log(u)), torch.rand((S, n), device=device)
 
+    def _input_noise(self, S: int, D: int, device):
+        """Input jitter (core.py:243-244, `training and input_jitter_noise > 0`): U(1 - eps, 1 + eps) per element, fp32 [S, D].
+        With the fp32 gate (core.py:240-241) the reference multiplies the FLOAT copy of the rows, which only the gate reads: the noise
+        goes to the router kernel (`umoe_router_args.x_noise`), the product is never rounded to bf16.  Without it the reference's
+        in-place `hidden_states *= noise` works on the caller's bf16 tensor, which `original_hidden_states` aliases: noise drawn in
+        bf16, rows rounded to bf16, and the EXPERTS see the jittered rows too -- mirrored by the callers of this method.
+        `self._input_noise_inject` [S, D] overrides the draw (tests inject fixed samples)."""
+        if not (self.training and self.input_jitter_noise > 0):
+            return None
+        inj = getattr(self, "_input_noise_inject", None)
+        if inj is not None:
+            noise = inj.to(device=device, dtype=torch.float32).reshape(S, D).contiguous()
+        else:
+            noise = torch.empty((S, D), dtype=torch.float32, device=device).uniform_(1.0 - self.input_jitter_noise,
+                                                                                     1.0 + self.input_jitter_noise)
+        if not self.fp32_gate:
+            noise = noise.to(torch.bfloat16).float()
+        return noise
+
     # ---- forward ------------------------------------------------------------------------------------------
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 aux_balance_weight: Optional[torch.Tensor] = None):
@@ -185,15 +204,14 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
             return out.reshape(B, T, D), logits, top_k, expert_mask, gw, aux
         pk = self.prepare()
         fp32_gate = bool(self.training and self.fp32_gate)                     # core.py:240-249
-        xg = x
-        if self.training and self.input_jitter_noise > 0:                      # core.py:243-244: the gate's copy only
-            xg = (x.float() * torch.empty((S, D), dtype=torch.float32, device=x.device).uniform_(
-                1.0 - self.input_jitter_noise, 1.0 + self.input_jitter_noise)).to(torch.bfloat16)
+        noise = self._input_noise(S, D, x.device)                              # core.py:243-244
+        if noise is not None and not fp32_gate:
+            x = _jitter_rows(x, noise)                                         # in place on the aliased bf16 rows: experts see them too
         gmb, ru = self._mixer_noise(S, x.device)
-        r = ops.router_fwd(xg, self.gate.weight.data, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix,
+        r = ops.router_fwd(x, self.gate.weight.data, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix,
                            top_p=float(self.mlp_dynamic_top_p), fixed_top_k=int(self.mlp_dynamic_top_k),
                            jitter_eps=float(self.router_jitter_noise), attn_mask=attention_mask,
-                           logits_bf16=not fp32_gate, gumbel=gmb, rand_u=ru)
+                           logits_bf16=not fp32_gate, gumbel=gmb, rand_u=ru, x_noise=noise if fp32_gate else None)
         logits, expert_mask = r["logits"], r["expert_mask"]
         top_k = r["top_k"] if self.mlp_dynamic_top_p != 0 else r["top_k"].to(torch.int32)
         aux = aux_loss(expert_mask, n_dyn, logits, aux_balance_weight)         # core.py:293
@@ -302,6 +320,13 @@ def aux_loss(expert_mask, n_dyn, full_logits, aux_balance_weight=None):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def _jitter_rows(t: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """bf16(float(t) * noise) for bf16 rows t [S, D] and fp32 noise [S, D] (one kernel: umoe_mul_noise)."""
+    if t.numel() % 8 == 0 and t.is_contiguous():
+        return ops.mul_noise(t, noise)
+    return (t.float() * noise).to(torch.bfloat16)
+
+
 # Training path: forward + backward of the block on the HIP kernels (torch.autograd.Function).
 # Shipped configuration only (ignore_differentiable_router, no token drop, ep_size 1): gradients reach the gate through
 # the softmax multipliers of the mixer's eval branch, the renormalisation and the global routing weight
@@ -317,18 +342,18 @@ class _DCMoETrainFn(torch.autograd.Function):
         ex = [params[1 + 3 * e: 4 + 3 * e] for e in range(n_real)]
         sh = [params[1 + 3 * n_real + 3 * i: 4 + 3 * n_real + 3 * i] for i in range(n_fix)]
         fp32_gate = bool(blk.training and blk.fp32_gate)
-        # input jitter (core.py:243-244): multiplicative uniform noise on the GATE's copy of the input only; the noise
-        # tensor is drawn with torch's device RNG (a stochastic regulariser: no bit parity with the CPU generator exists)
-        noise = None
-        xg = x
-        if blk.training and blk.input_jitter_noise > 0:
-            noise = torch.empty((S, D), dtype=torch.float32, device=x.device).uniform_(1.0 - blk.input_jitter_noise,
-                                                                                       1.0 + blk.input_jitter_noise)
-            xg = ops.mul_noise(x, noise) if (S * D) % 8 == 0 else (x.float() * noise).to(torch.bfloat16)
+        # input jitter (core.py:243-244): multiplicative uniform noise, drawn with torch's device RNG (a stochastic regulariser: no
+        # bit parity with the CPU generator exists; tests inject the samples).  fp32 gate: on the gate's float copy only, multiplied
+        # inside the router kernel (x_noise); bf16 gate: on the aliased bf16 rows, so the experts see the jittered rows as well
+        noise = blk._input_noise(S, D, x.device)
+        ctx.jitter_all = noise is not None and not fp32_gate
+        if ctx.jitter_all:
+            x = _jitter_rows(x, noise)
         gmb, ru = blk._mixer_noise(S, x.device)
-        r = ops.router_fwd(xg, gate_w, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, top_p=float(blk.mlp_dynamic_top_p),
+        r = ops.router_fwd(x, gate_w, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, top_p=float(blk.mlp_dynamic_top_p),
                            fixed_top_k=int(blk.mlp_dynamic_top_k), jitter_eps=float(blk.router_jitter_noise),
-                           attn_mask=attention_mask, logits_bf16=not fp32_gate, gumbel=gmb, rand_u=ru)
+                           attn_mask=attention_mask, logits_bf16=not fp32_gate, gumbel=gmb, rand_u=ru,
+                           x_noise=noise if fp32_gate else None)
         logits, mask, moe_w, global_w = r["logits"], r["expert_mask"], r["moe_weight"], r["global_weight"]
         tw = None
         if aux_balance_weight is not None:
@@ -426,17 +451,20 @@ class _DCMoETrainFn(torch.autograd.Function):
         dl16 = torch.zeros((S, 16), dtype=bf, device=dev)
         dl16[:, :E] = d_lg.to(bf)
         noise = ctx.noise
-        jit = (lambda t: ops.mul_noise(t, noise)) if (noise is not None and noise.numel() % 8 == 0) else (lambda t: (t.float() * noise).to(bf))
-        xT = ops.transpose(jit(x) if noise is not None else x)              # [D][Sp]; the gate saw the jittered input
+        gate_only = noise is not None and not ctx.jitter_all               # fp32 gate: only the gate's copy was jittered
+        jit = lambda t: _jitter_rows(t, noise)
+        xT = ops.transpose(jit(x) if gate_only else x)                      # [D][Sp]; the gate saw the jittered input
         dlT = ops.transpose(dl16)                                            # [16][Sp]
         dWgate = torch.empty((16, D), dtype=bf, device=dev)
         ops.tiled_gemm([dict(w=xT, static_count=16)], dlT, dWgate, max_rows=16)
         grads[0] = dWgate[:E]
         dx_router = ops.tlinear(dl16, ops.transpose(params[0]))              # [S][16] x [D][16]^T
-        if noise is not None:
+        if gate_only:
             dx_router = jit(dx_router)
         # 7. input gradient: slot rows back to tokens + shared experts + router
         dx = ops.permute_bwd(dxe, disp["slot_of"], dxe[cap:] if n_fix else None, n_fix, extra=dx_router)
+        if ctx.jitter_all:
+            dx = jit(dx)                                                    # every consumer read x * noise
         return (None, dx, None, None, *[gr.contiguous() if gr is not None else None for gr in grads])
 
 

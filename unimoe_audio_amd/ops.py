@@ -70,9 +70,10 @@ def router_fwd(x: Optional[torch.Tensor], gate_w: Optional[torch.Tensor], *, n_d
                top_p: float, fixed_top_k: int = 0, jitter_eps: float = 0.01, logits_in: Optional[torch.Tensor] = None,
                attn_mask: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None, rms_eps: float = 1e-6,
                want_h: bool = False, logits_bf16: Optional[bool] = None, gumbel: Optional[torch.Tensor] = None,
-               rand_u: Optional[torch.Tensor] = None) -> dict:
+               rand_u: Optional[torch.Tensor] = None, x_noise: Optional[torch.Tensor] = None) -> dict:
     """gumbel [S, n_dyn, n_dyn] / rand_u [S, n_dyn] fp32: the training branch of the mixer (core.py:111-137) with its noise as an
-    input; the result then carries `round_factor` [S, n_dyn] (mask_for_one per round) for router_bwd."""
+    input; the result then carries `round_factor` [S, n_dyn] (mask_for_one per round) for router_bwd.
+    x_noise [S, D] fp32: the input jitter in front of the fp32 gate (core.py:240-249) -- the gate sees float(x) * x_noise unrounded."""
     E = n_dyn + n_fix
     if logits_in is not None:
         S = logits_in.shape[0]
@@ -102,6 +103,9 @@ def router_fwd(x: Optional[torch.Tensor], gate_w: Optional[torch.Tensor], *, n_d
         jitter_eps=jitter_eps, rms_eps=rms_eps, logits_out=_p(o["logits"]), top_k=_p(o["top_k"]), sel=_p(o["sel"]),
         expert_mask=_p(o["expert_mask"]), routing_w=_p(o["routing_weights"]), global_w=_p(o["global_weight"]),
         moe_w=_p(o["moe_weight"]))
+    if x_noise is not None:
+        assert x is not None and x_noise.dtype == torch.float32 and tuple(x_noise.shape) == (S, D) and x_noise.is_contiguous()
+        a.x_noise = x_noise.data_ptr()
     if gumbel is not None:
         assert rand_u is not None and tuple(gumbel.shape) == (S, n_dyn, n_dyn) and tuple(rand_u.shape) == (S, n_dyn)
         gk, uk = gumbel.float().contiguous(), rand_u.float().contiguous()
