@@ -20,8 +20,10 @@ from . import decode as OD
 
 
 def forward_loss(cfg, w: Dict[str, torch.Tensor], input_ids, codec_input_ids, attention_mask, codec_labels, aux_weight: float,
-                 aux_balance_weight: Optional[torch.Tensor] = None, training: bool = True, forced=None):
-    """-> (loss, codec_loss, aux_mean, last_hidden); differentiable in every tensor of `w` that requires grad."""
+                 aux_balance_weight: Optional[torch.Tensor] = None, training: bool = True, forced=None, input_noise=None):
+    """-> (loss, codec_loss, aux_mean, last_hidden); differentiable in every tensor of `w` that requires grad.
+    input_noise: one [B, T, D] tensor per layer, the samples of the DCMoE input jitter (core.py:243-244; required when training with
+    input_jitter_noise > 0: the same samples are injected into the product's blocks)."""
     B, T = input_ids.shape
     D = cfg.hidden_size
     x = w["language_model.embed_tokens.weight"][input_ids]
@@ -47,7 +49,8 @@ def forward_loss(cfg, w: Dict[str, torch.Tensor], input_ids, codec_input_ids, at
         x = x + a
         h = OD.rmsnorm(x, w[lp + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
         sub = {k[len(lp + "mlp."):]: v for k, v in w.items() if k.startswith(lp + "mlp.")}
-        out = OA.forward(cfg, sub, h, pm, abw, training=training, forced=None if forced is None else forced[l])
+        out = OA.forward(cfg, sub, h, pm, abw, training=training, forced=None if forced is None else forced[l],
+                         input_noise=None if input_noise is None else input_noise[l])
         auxes.append(out[5])
         x = x + out[0]
     hs = OD.rmsnorm(x, w["language_model.norm.weight"], cfg.rms_norm_eps)

@@ -19,12 +19,12 @@ gm = m.to(dev).train()
 for p_ in gm.parameters():
     p_.requires_grad_(True)
 auxw = float(gm.cur_aux_weight)
-x = None
+xnoise = TE.inject_input_jitter(cfg, gm, B, T, 77)
 loss, closs, auxm, routing = TR.forward_train(gm, ids, codec, am, labels, return_routing=True)
 loss.backward()
 wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
 forced = [(k_.cpu(), m_.cpu()) for k_, m_ in routing]
-lo, clo, auxo, hs = OT.forward_loss(cfg, wo, ids, codec, am, labels, auxw, training=True, forced=forced)
+lo, clo, auxo, hs = OT.forward_loss(cfg, wo, ids, codec, am, labels, auxw, training=True, forced=forced, input_noise=xnoise)
 lo.backward()
 print("loss", float(loss), float(lo), "aux", float(auxm), float(auxo))
 rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))

@@ -27,6 +27,17 @@ def small_cfg(**over):
     return UniMoEAudioConfig(**kw)
 
 
+def inject_input_jitter(cfg, model, B, T, seed):
+    """Fixed samples of the DCMoE input jitter (core.py:243-244), one [B, T, D] tensor per layer, injected into the product's blocks
+    (`_input_noise_inject`) and handed to the oracle (`input_noise=`): both sides multiply by the SAME noise."""
+    gn = torch.Generator().manual_seed(seed)
+    eps = float(cfg.input_jitter_noise)
+    noise = [(1.0 - eps) + 2.0 * eps * torch.rand((B, T, cfg.hidden_size), generator=gn) for _ in range(cfg.num_hidden_layers)]
+    for layer, nz in zip(model.language_model.layers, noise):
+        layer.mlp._input_noise_inject = nz
+    return noise
+
+
 def build(cfg, seed, std):
     from unimoe_audio_amd.model import UniAudioRVQQwen2_5VLMoEForConditionalGeneration
     torch.manual_seed(seed)
@@ -270,6 +281,7 @@ def test_training_step_vs_autograd_oracle(dev):
     for p_ in gm.parameters():
         p_.requires_grad_(True)
     auxw = float(gm.cur_aux_weight)
+    xnoise = inject_input_jitter(cfg, gm, B, T, 77)
     loss, closs, auxm, routing = TR.forward_train(gm, ids, codec, am, labels, return_routing=True)
     loss.backward()
     wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
@@ -277,9 +289,9 @@ def test_training_step_vs_autograd_oracle(dev):
     # flips between two experts on a near-tie changes whole gradient tensors of small experts -- integers are compared
     # separately (bit-exact given identical logits, test_gpu_ops.py), here they are forced so that the FLOAT path is compared
     forced = [(k_.cpu(), m_.cpu()) for k_, m_ in routing]
-    lo, clo, auxo, _ = OT.forward_loss(cfg, wo, ids, codec, am, labels, auxw, training=True, forced=forced)
+    lo, clo, auxo, _ = OT.forward_loss(cfg, wo, ids, codec, am, labels, auxw, training=True, forced=forced, input_noise=xnoise)
     lo.backward()
-    lo_free, _, _, _ = OT.forward_loss(cfg, {k: v for k, v in w.items()}, ids, codec, am, labels, auxw, training=True)
+    lo_free, _, _, _ = OT.forward_loss(cfg, {k: v for k, v in w.items()}, ids, codec, am, labels, auxw, training=True, input_noise=xnoise)
     assert abs(float(loss) - float(lo_free)) < 0.01 * abs(float(lo_free))       # free-running loss agrees too
     assert abs(float(loss) - float(lo)) < 0.01 * abs(float(lo)), (float(loss), float(lo))
     assert abs(float(auxm) - float(auxo)) < 0.03 * abs(float(auxo)) + 1e-3
@@ -330,12 +342,13 @@ def test_training_step_full_width_layer_at_6240_tokens_vs_autograd_oracle(dev, j
     for p_ in gm.parameters():
         p_.requires_grad_(True)
     auxw = float(gm.cur_aux_weight)
+    xnoise = inject_input_jitter(cfg, gm, B, T, 78)
     loss, closs, auxm, routing = TR.forward_train(gm, ids, codec, am, labels, return_routing=True)
     loss.backward()
     assert gm.training_steps == 1
     wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
     forced = [(k_.cpu(), m_.cpu()) for k_, m_ in routing]
-    lo, clo, auxo, _ = OT.forward_loss(cfg, wo, ids, codec, am, labels, auxw, training=True, forced=forced)
+    lo, clo, auxo, _ = OT.forward_loss(cfg, wo, ids, codec, am, labels, auxw, training=True, forced=forced, input_noise=xnoise)
     lo.backward()
     rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
     errs = []
