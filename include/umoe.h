@@ -497,6 +497,9 @@ typedef struct {
                                * launch disappears; the counters are zero again when the call completes */
     int defer_merge;          /* umoe_attn_decode: 1 = leave the split partials (part_o / part_ml) unmerged -- the caller merges them
                                * (decode engine: the merge rides in the o_proj launch) */
+    int wide;                 /* umoe_attn_decode with qkv_raw (nq == 1, GQA group of 8): 1 = 8-wave workgroups, two per (row, kv head) with
+                               * four query heads each, split the keys over their WAVES and write `out` themselves (splits / part_o /
+                               * part_ml unused, no key split across workgroups, no merge launch) */
 } umoe_attn_args;
 int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream);
 /* causal prefill (nq = T queries per row) over keys already appended by umoe_qkv_mrope_kvappend */

@@ -542,6 +542,49 @@ def test_attention_decode_single_launch_merge(dev, rows, H, KVH, L, splits):
         assert int(sync.abs().sum()) == 0          # the counters are zero again after every call
 
 
+@pytest.mark.parametrize("rows,L", [(16, 315), (16, 814), (3, 37), (5, 130), (2, 1), (4, 16), (16, 3300)])
+def test_attention_decode_wide_vs_split_path(dev, rows, L):
+    """umoe_attn_args.wide: 8-wave workgroups (two per (row, kv head), four query heads each) split the keys over their WAVES and write
+    the output row themselves -- no partials, no merge launch.  Checked against the 8-split attention + combine pair on the same raw
+    QKV rows (fused mRoPE + KV append in both): the appended K / V are bit-identical, the outputs agree to fp32 summation order
+    (different partition of the softmax), and both sit equally close to an fp64 softmax over the same cache."""
+    from unimoe_audio_amd import ops
+    H, KVH, hd = 16, 2, 128
+    Lmax = ((L + 80) // 64) * 64
+    g = torch.Generator().manual_seed(31 + rows + L)
+    kc = (torch.randn(rows, KVH, Lmax, hd, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    vc = (torch.randn(rows, KVH, Lmax, hd, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    qkv = (torch.randn(rows, (H + 2 * KVH) * hd, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    kv_start = torch.randint(0, max(L // 3, 1), (rows,), generator=g).to(torch.int32).to(dev)
+    q0 = torch.full((rows,), L - 1, dtype=torch.int32, device=dev)          # slot of the new token: L - 1 cached keys before it
+    cos_tab, sin_tab = ops.rope_tables(Lmax + 8, hd, 1e6, dev)
+    p3 = torch.stack([q0, q0 + 1, q0 - torch.minimum(q0, torch.tensor(2, device=dev, dtype=torch.int32))]).to(torch.int32).contiguous()
+    kw = dict(qkv_raw=qkv, cos_tab=cos_tab, sin_tab=sin_tab, pos3=p3, sections=(16, 24, 24))
+    k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    ref = ops.attention(None, k1, v1, kv_start, q0, 1, H, splits=8, **kw)
+    got = ops.attention(None, k2, v2, kv_start, q0, 1, H, splits=1, wide=1, **kw)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)                       # the same roped K / raw V landed in slot L - 1
+    assert not torch.equal(k1, kc)
+    assert torch.allclose(got.float(), ref.float(), rtol=2 ** -7, atol=2 ** -9)
+    # fp64 softmax over the cache the kernels produced (the query = the roped q of the split path's separate rope kernel)
+    kvp = q0.clone()
+    k3, v3 = kc.clone(), vc.clone()
+    q = ops.qkv_mrope_kvappend(qkv, cos_tab, sin_tab, p3, kvp, 1, H, KVH, hd, (16, 24, 24), k3, v3)
+    assert torch.equal(k3, k1)
+    qd = q.double().reshape(rows, KVH, H // KVH, hd).cpu()
+    kd, vd = k1.double().cpu(), v1.double().cpu()
+    exact = torch.zeros(rows, KVH, H // KVH, hd, dtype=torch.float64)
+    for r in range(rows):
+        lo = int(kv_start[r])
+        sc = torch.einsum("kgd,kld->kgl", qd[r], kd[r, :, lo:L]) * hd ** -0.5
+        exact[r] = torch.einsum("kgl,kld->kgd", torch.softmax(sc, -1), vd[r, :, lo:L])
+    exact = exact.reshape(rows, H * hd)
+    e_w = float((got.double().cpu() - exact).norm() / exact.norm())
+    e_s = float((ref.double().cpu() - exact).norm() / exact.norm())
+    print(f"\nWIDE ATTENTION rows {rows} L {L}: rel. error vs fp64 softmax wide {e_w:.2e} split {e_s:.2e}")
+    assert e_w < 2 ** -8 and e_w < 1.5 * e_s + 1e-4
+
+
 def test_gemm256_forced_in_child_process():
     """The 256 x 256 ping-pong GEMM is chosen by size; UMOE_TGEMM_PP=1 forces it for EVERY tiled GEMM.  Re-run the GEMM,
     ragged / SwiGLU, block-backward and backward-kernel tests with it forced (small and odd shapes: partial tiles, K tails,

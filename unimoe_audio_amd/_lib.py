@@ -91,7 +91,7 @@ class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("k_cache", vp), ("v_cache", vp), ("kv_start", vp), ("q_pos0", vp), ("rows", i32),
                 ("nq", i32), ("H", i32), ("KVH", i32), ("hd", i32), ("Lmax", i32), ("splits", i32), ("scale", f32),
                 ("part_o", vp), ("part_ml", vp), ("out", vp), ("qkv_raw", vp), ("cos_tab", vp), ("sin_tab", vp), ("pos3", vp),
-                ("sec0", i32), ("sec1", i32), ("sec2", i32), ("lse_out", vp), ("sync", vp), ("defer_merge", i32)]
+                ("sec0", i32), ("sec1", i32), ("sec2", i32), ("lse_out", vp), ("sync", vp), ("defer_merge", i32), ("wide", i32)]
 
 
 class SampleArgs(C.Structure):

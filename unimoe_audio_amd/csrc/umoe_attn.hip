@@ -456,6 +456,205 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
     TL_EXIT(7);
 }
 
+// ---- decode attention without a key split across workgroups (umoe_attn_args.wide) ---------------------------------------------------
+// ONE 8-wave workgroup per (row, kv head, slice of GPW query heads): the key range is split over the WAVES of the workgroup (wave w
+// takes the 16-key tiles w, w + 8, ...; two or three tiles in flight per wave: 256 / 384 keys requested in one round trip), the waves'
+// partial softmaxes meet in LDS, and the output row is written by the launch itself -- no partials in memory and no merge launch
+// (attn_kernel + attn_combine_kernel: two dependent launches and 1 MB of fp32 partials per layer for ~5 MB of K / V).  What bounds
+// it instead is the K / V intake of one CU (161 KB per kv head at 315 cached tokens), so every K / V load is a 16-byte load: a lane
+// holds 8 value columns of 4 keys (the 4-byte column loads of attn_kernel take ~3x the address-path time per byte), its partial
+// output covers those 4 keys only, and the sum over the four key quarters of a tile is folded into the cross-wave merge.
+// GPW = 4 query heads per workgroup: two workgroups per kv head of the 8-head GQA group (K / V requested twice -- 10 MB instead of 5 MB
+// per layer beside 304 MB of expert weights -- and half the P.V work each; GPW = 8 spills: see umoe_attn_decode).
+// Decode only: nq == 1, fused mRoPE + KV append (qkv_raw), G == 8, hd == 128.
+template <int GPW>
+__global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) {
+    constexpr int HD = 128, NW = 8, PS = 20;              // PS: p_lds row stride in floats (80 B: the four key quarters hit disjoint banks)
+    constexpr int ND = GPW == 8 ? 2 : 3;                  // register tiles in flight per wave
+    extern __shared__ __attribute__((aligned(16))) char smem_w[];
+    float* red_o = reinterpret_cast<float*>(smem_w);      // [NW][4 key quarters][GPW][HD]
+    float* p_lds = red_o + NW * 4 * GPW * HD;             // [NW][16 keys][PS]
+    float* al_lds = p_lds + NW * 16 * PS;                 // [NW][16]
+    float* red_ml = al_lds + NW * 16;                     // [NW][16][2]
+    TL_ENTER(7);
+    const int G = a.H / a.KVH;
+    const int hsn = G / GPW;
+    const int kvh = (int)blockIdx.x / hsn, hs = (int)blockIdx.x - kvh * hsn;
+    const int qi = blockIdx.y, row = qi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (guards around MFMAs must be scalar branches)
+    const int h4 = lane >> 4, c = lane & 15;
+    const int head0 = kvh * G + hs * GPW;
+    const int ntok = a.rows;
+    const int p0 = a.pos3[qi], p1 = a.pos3[ntok + qi], p2 = a.pos3[2 * ntok + qi];
+    const int kbeg = a.kv_start[row];
+    const int kend = a.q_pos0[row];                       // exclusive: slot of the new token, which is taken from the raw QKV row
+    const int ntile = __builtin_amdgcn_readfirstlane((max(kend - kbeg, 0) + 15) >> 4);
+    const uint16_t* Kc = a.k_cache + ((size_t)row * a.KVH + kvh) * a.Lmax * HD;
+    const uint16_t* Vc = a.v_cache + ((size_t)row * a.KVH + kvh) * a.Lmax * HD;
+    const int QKV_LD = (a.H + 2 * a.KVH) * HD;
+    struct tile_t { uint4 k[4], v[4]; };
+    // unconditional, clamped loads (a tile past the range re-reads the last key: cache hits, masked below) -- straight-line code, so
+    // the compiler counts the loads and a tile is consumed while the younger ones are still in flight
+    auto load_tile = [&](tile_t& t, const int j) {
+        const int k0 = kbeg + 16 * j;
+        const uint16_t* kp = Kc + (size_t)max(min(k0 + c, kend - 1), 0) * HD + h4 * 32;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) t.k[kb] = ld16(kp + kb * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.v[r] = ld16(Vc + (size_t)max(min(k0 + 4 * h4 + r, kend - 1), 0) * HD + c * 8);
+    };
+    tile_t t0, t1, t2;
+    bf16x8_t qf[4];
+    {
+        uint4 u[4];
+        rope_regs rr;
+        rope32_load(a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(head0 + (c < GPW ? c : 0)) * HD, h4, a, p0, p1, p2, rr);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(t0, wave);
+        load_tile(t1, wave + NW);
+        if constexpr (ND == 3) load_tile(t2, wave + 2 * NW);
+        __builtin_amdgcn_sched_barrier(0);
+        rope32_math(rr, h4, u);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) qf[kb] = __builtin_bit_cast(bf16x8_t, c < GPW ? u[kb] : make_uint4(0, 0, 0, 0));
+    }
+    TL_MARK(7, 4);
+    float m_run = -INFINITY, l_run = 0.f;                 // of head c (replicated over the key quarters)
+    float o[GPW][8];                                      // heads x this lane's 8 value columns, over this lane's key quarter
+#pragma unroll
+    for (int g = 0; g < GPW; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
+    float* pw = p_lds + wave * 16 * PS;
+    float* aw = al_lds + wave * 16;
+    auto process_tile = [&](const tile_t& t, const int k0, const int kend_t) {
+        f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};              // S[key = 4 h4 + r][head = c]
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, t.k[kb]), qf[kb], sacc, 0, 0, 0);
+        float sv[4];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sv[r] = (k0 + 4 * h4 + r < kend_t) ? sacc[r] * a.scale : -INFINITY;
+            tmax = fmaxf(tmax, sv[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = (sv[r] == -INFINITY) ? 0.f : __expf(sv[r] - m_new);
+            psum += pv;
+            pw[(4 * h4 + r) * PS + c] = pv;
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (h4 == 0) aw[c] = alpha;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < GPW; ++g) {
+            const float al = aw[g];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[g][j] *= al;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v[8], pv[GPW];
+            unpack8(t.v[r], v);
+            const float4* pr4 = reinterpret_cast<const float4*>(pw + (4 * h4 + r) * PS);
+#pragma unroll
+            for (int q4 = 0; q4 < GPW / 4; ++q4) {
+                const float4 t4 = pr4[q4];
+                pv[4 * q4] = t4.x; pv[4 * q4 + 1] = t4.y; pv[4 * q4 + 2] = t4.z; pv[4 * q4 + 3] = t4.w;
+            }
+#pragma unroll
+            for (int g = 0; g < GPW; ++g)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[g][j] += pv[g] * v[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // ring of ND register tiles; `j` and `ntile` are wave-uniform scalars
+    for (int j = wave; j < ntile; j += ND * NW) {
+        process_tile(t0, kbeg + 16 * j, kend);
+        load_tile(t0, j + ND * NW);
+        if (j + NW < ntile) process_tile(t1, kbeg + 16 * (j + NW), kend);
+        load_tile(t1, j + (ND + 1) * NW);
+        if constexpr (ND == 3) {
+            if (j + 2 * NW < ntile) process_tile(t2, kbeg + 16 * (j + 2 * NW), kend);
+            load_tile(t2, j + 5 * NW);
+        }
+    }
+    if (wave == NW - 1) {
+        // the new token (one extra 1-key tile): K roped from the raw QKV row (lanes c == 0 hold its 4 x 32 dims), V raw; the first head
+        // slice's workgroup is the single writer of cache slot q_pos0 of (row, kv head)
+        const int slot = kend;
+        const uint16_t* kraw = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + kvh) * HD;
+        const uint16_t* vrow = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + a.KVH + kvh) * HD;
+        tile_t tn;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) tn.k[kb] = make_uint4(0, 0, 0, 0);
+        if (c == 0) {
+            rope32(kraw, h4, a, p0, p1, p2, tn.k);
+            if (hs == 0) {
+                uint16_t* kd = const_cast<uint16_t*>(a.k_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + h4 * 32;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) st16(kd + kb * 8, tn.k[kb]);
+            }
+        }
+        const uint4 vnew = ld16(vrow + c * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tn.v[r] = vnew;
+        if (hs == 0 && h4 == 0)
+            st16(const_cast<uint16_t*>(a.v_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + c * 8, vnew);
+        process_tile(tn, slot, slot + 1);                 // keys slot + 1 .. are masked (p = 0)
+    }
+    TL_MARK(7, 5);
+    // ---- merge: 8 waves x 4 key quarters -> one output row per head -------------------------------------------------------------
+    if (h4 == 0) {
+        red_ml[(wave * 16 + c) * 2] = m_run;
+        red_ml[(wave * 16 + c) * 2 + 1] = l_run;
+    }
+#pragma unroll
+    for (int g = 0; g < GPW; ++g) {
+        float* d = red_o + ((size_t)((wave * 4 + h4) * GPW + g)) * HD + c * 8;
+        *reinterpret_cast<float4*>(d) = make_float4(o[g][0], o[g][1], o[g][2], o[g][3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(o[g][4], o[g][5], o[g][6], o[g][7]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < GPW * (HD / 2); idx += 512) {
+        const int g = idx >> 6, col = (idx & 63) * 2;
+        float mm = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mm = fmaxf(mm, red_ml[(w * 16 + g) * 2]);
+        float L = 0.f, acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float mw = red_ml[(w * 16 + g) * 2];
+            const float sc = (mw == -INFINITY) ? 0.f : __expf(mw - mm);
+            L += sc * red_ml[(w * 16 + g) * 2 + 1];
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int kq = 0; kq < 4; ++kq) {
+                const float2 v2 = *reinterpret_cast<const float2*>(red_o + ((size_t)((w * 4 + kq) * GPW + g)) * HD + col);
+                s0 += v2.x;
+                s1 += v2.y;
+            }
+            acc0 += sc * s0;
+            acc1 += sc * s1;
+        }
+        const uint16_t y0 = f2bf(L > 0.f ? acc0 / L : 0.f), y1 = f2bf(L > 0.f ? acc1 / L : 0.f);
+        *reinterpret_cast<uint32_t*>(a.out + ((size_t)qi * a.H + head0 + g) * HD + col) = (uint32_t)y0 | ((uint32_t)y1 << 16);
+    }
+    TL_EXIT(7);
+}
+
 // SP > 0: the split count is a compile-time constant and EVERY partial is requested before the first use
 // (the partials were written by other XCDs: each dependent load is a trip to the Infinity Cache)
 template <int SP>
@@ -539,6 +738,23 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     UMOE_REQUIRE((long)a->rows * a->nq <= 65535 * 1L * 65535, "umoe_attn_decode: too many queries");
     hipStream_t s = (hipStream_t)stream;
     const unsigned nqi = (unsigned)(a->rows * a->nq);
+    if (a->wide) {
+        // one workgroup per (row, kv head[, half of the GQA group]): no key split across workgroups, no partials, no merge launch
+        UMOE_REQUIRE(a->qkv_raw && a->nq == 1 && a->H / a->KVH == 8 && a->rows <= 65535 && !a->sync && !a->defer_merge && !a->lse_out,
+                     "umoe_attn_decode: wide = decode with fused rope (qkv_raw, nq == 1), GQA group of 8, no sync / defer_merge (H=%d KVH=%d nq=%d)",
+                     a->H, a->KVH, a->nq);
+        // (a workgroup takes FOUR of the eight query heads: with all eight the 64 fp32 accumulators beside two register tiles spill,
+        //  and a scratch reload in front of every MFMA waits for the whole load queue)
+        constexpr int lds4 = (8 * 4 * 4 * 128 + 8 * 16 * 20 + 8 * 16 + 8 * 16 * 2) * 4;
+        static bool configured = false;
+        if (!configured) {
+            UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
+            configured = true;
+        }
+        attn_wide_kernel<4><<<dim3((unsigned)a->KVH * 2u, nqi), 512, lds4, s>>>(*a);
+        UMOE_LAUNCH_CHECK();
+        return 0;
+    }
     // grid.z <= 65535: fold large query counts
     UMOE_REQUIRE(nqi <= 65535u * 32u, "umoe_attn_decode: too many query tokens (%u)", nqi);
     if (nqi <= 65535u) {

@@ -96,6 +96,8 @@ struct umoe_engine {
     bool gu_norm = false;        // UMOE_GU_NORM: the gate/up workgroups normalise x1 in their staging prologue (no hand-off, no norm launch)
     bool rider_pub = true;       // UMOE_RIDER_PUB: the riders also produce the normalised rows and hand them to the GEMM workgroups of the
                                  // same launch (umoe_gemm_args.rider_pub): no RMSNorm launch in front of gate/up
+    int attn_wide = 0;           // UMOE_ATTN_WIDE: decode attention as 8-wave workgroups (two per (row, kv head)) that split the keys over their
+                                 // waves and write the output themselves (umoe_attn_args.wide): no partials, no combine launch
     bool attn_single = false;    // UMOE_ATTN_SINGLE: decode attention merges its key splits in the same launch (umoe_attn_args.sync);
                                  // measured 3.644 vs 3.585 ms/step: ticket + coherent re-read cost more than the combine launch
     int flat_wgs = 0;            // UMOE_FLAT_WGS: workgroups of the flat gate/up launch; measured 42.4 us (256 slices of 6-7
@@ -345,6 +347,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     if (const char* v = getenv("UMOE_TILED_PREFILL")) e->tiled_prefill = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FLAT_WGS")) e->flat_wgs = atoi(v);
     if (const char* v = getenv("UMOE_ATTN_SINGLE")) e->attn_single = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_ATTN_WIDE")) e->attn_wide = atoi(v);
     if (const char* v = getenv("UMOE_FUSE_ROUTER")) e->fuse_router = atoi(v) != 0;
     if (const char* v = getenv("UMOE_RIDER_PUB")) e->rider_pub = atoi(v) != 0;
     if (const char* v = getenv("UMOE_GU_NORM")) e->gu_norm = atoi(v) != 0;
@@ -741,9 +744,11 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     t.q = e->q_r; t.k_cache = r.k_cache; t.v_cache = r.v_cache; t.kv_start = e->kv_start; t.q_pos0 = e->q_pos0;
     t.rows = c.rows; t.nq = T; t.H = c.heads; t.KVH = c.kv_heads; t.hd = c.head_dim; t.Lmax = c.Lmax; t.splits = splits;
     t.scale = 1.0f / sqrtf((float)c.head_dim); t.part_o = e->part_o; t.part_ml = e->part_ml; t.out = e->attn_out;
-    if (T == 1 && e->attn_single) t.sync = e->attn_sync;   // decode: the last key split merges, no combine launch
+    const bool wide = T == 1 && e->attn_wide > 0 && c.heads == 8 * c.kv_heads && c.head_dim == 128 && (c.mrope0 % 8 == 0) && ((c.mrope0 + c.mrope1) % 8 == 0);
+    if (wide) t.wide = 1;                                  // decode: keys split over the WAVES of a workgroup, output written by the launch
+    if (T == 1 && e->attn_single && !wide) t.sync = e->attn_sync;   // decode: the last key split merges, no combine launch
     // decode: the merge of the key splits rides in the o_proj launch (16 rider workgroups hand the merged rows over)
-    const bool merge_rides = T == 1 && !tiled && e->fuse_ao && e->rider_pub && !t.sync && splits == 8 && c.heads == 16 && c.head_dim == 128 && n_tok <= 16;
+    const bool merge_rides = T == 1 && !tiled && !wide && e->fuse_ao && e->rider_pub && !t.sync && splits == 8 && c.heads == 16 && c.head_dim == 128 && n_tok <= 16;
     if (merge_rides) t.defer_merge = 1;
     if (fuse_rope) {
         t.qkv_raw = e->qkv; t.cos_tab = e->cos_tab; t.sin_tab = e->sin_tab; t.pos3 = e->pos3;

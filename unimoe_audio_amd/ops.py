@@ -308,9 +308,11 @@ def qkv_mrope_kvappend(qkv, cos_tab, sin_tab, pos3, kv_pos, T, H, KVH, hd, secti
 
 
 def attention(q, k_cache, v_cache, kv_start, q_pos0, nq, H, splits=1, qkv_raw=None, cos_tab=None, sin_tab=None, pos3=None,
-              sections=(16, 24, 24), lse_out=None, single_launch=False):
+              sections=(16, 24, 24), lse_out=None, single_launch=False, wide=0):
     """q: rotated queries [rows*nq, H*hd]; or pass qkv_raw (decode, nq == 1) to fuse mRoPE + KV append into the kernel.
-    single_launch: the last key split to finish merges the partials (umoe_attn_args.sync) -- no combine launch."""
+    single_launch: the last key split to finish merges the partials (umoe_attn_args.sync) -- no combine launch.
+    wide (with qkv_raw, GQA group of 8): 8-wave workgroups, two per (row, kv head), split the keys over their waves and write the
+    output themselves (umoe_attn_args.wide): no key split across workgroups, no merge launch."""
     rows, KVH, Lmax, hd = k_cache.shape
     n = (q if q is not None else qkv_raw).shape[0]
     dev0 = (q if q is not None else qkv_raw).device
@@ -325,7 +327,7 @@ def attention(q, k_cache, v_cache, kv_start, q_pos0, nq, H, splits=1, qkv_raw=No
     a = L.AttnArgs(q=_p(q), k_cache=_p(k_cache), v_cache=_p(v_cache), kv_start=_p(kv_start), q_pos0=_p(q_pos0), rows=rows,
                    nq=nq, H=H, KVH=KVH, hd=hd, Lmax=Lmax, splits=splits, scale=float(hd) ** -0.5, part_o=_p(po),
                    part_ml=_p(pm), out=_p(out), qkv_raw=_p(qkv_raw), cos_tab=_p(cos_tab), sin_tab=_p(sin_tab), pos3=_p(pos3),
-                   sec0=sections[0], sec1=sections[1], sec2=sections[2], lse_out=_p(lse_out), sync=_p(sync))
+                   sec0=sections[0], sec1=sections[1], sec2=sections[2], lse_out=_p(lse_out), sync=_p(sync), wide=int(wide))
     if nq >= 16 and qkv_raw is None:       # many queries per row: MFMA flash-attention kernel (umoe_attn_prefill_fwd)
         L.check(L.lib().umoe_attn_prefill_fwd(C.byref(a), _stream()), "umoe_attn_prefill_fwd")
     else:
