@@ -457,8 +457,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
 }
 
 // ---- decode attention without a key split across workgroups (umoe_attn_args.wide) ---------------------------------------------------
-// ONE 8-wave workgroup per (row, kv head, slice of GPW query heads): the key range is split over the WAVES of the workgroup (wave w
-// takes the 16-key tiles w, w + 8, ...; two or three tiles in flight per wave: 256 / 384 keys requested in one round trip), the waves'
+// ONE 8-wave workgroup per (row, kv head, slice of GPW query heads): the key range is split over the WAVES of the workgroup (wave w < 7
+// takes the 16-key tiles w, w + 7, ..., wave 7 the new token; two or three tiles in flight per wave: 256 / 384 keys requested in one round trip), the waves'
 // partial softmaxes meet in LDS, and the output row is written by the launch itself -- no partials in memory and no merge launch
 // (attn_kernel + attn_combine_kernel: two dependent launches and 1 MB of fp32 partials per layer for ~5 MB of K / V).  What bounds
 // it instead is the K / V intake of one CU (161 KB per kv head at 315 cached tokens), so every K / V load is a 16-byte load: a lane
@@ -506,20 +506,6 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
     };
     tile_t t0, t1, t2;
     bf16x8_t qf[4];
-    {
-        uint4 u[4];
-        rope_regs rr;
-        rope32_load(a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(head0 + (c < GPW ? c : 0)) * HD, h4, a, p0, p1, p2, rr);
-        __builtin_amdgcn_sched_barrier(0);
-        load_tile(t0, wave);
-        load_tile(t1, wave + NW);
-        if constexpr (ND == 3) load_tile(t2, wave + 2 * NW);
-        __builtin_amdgcn_sched_barrier(0);
-        rope32_math(rr, h4, u);
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) qf[kb] = __builtin_bit_cast(bf16x8_t, c < GPW ? u[kb] : make_uint4(0, 0, 0, 0));
-    }
-    TL_MARK(7, 4);
     float m_run = -INFINITY, l_run = 0.f;                 // of head c (replicated over the key quarters)
     float o[GPW][8];                                      // heads x this lane's 8 value columns, over this lane's key quarter
 #pragma unroll
@@ -580,40 +566,69 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
         }
         __builtin_amdgcn_wave_barrier();
     };
-    // ring of ND register tiles; `j` and `ntile` are wave-uniform scalars
-    for (int j = wave; j < ntile; j += ND * NW) {
-        process_tile(t0, kbeg + 16 * j, kend);
-        load_tile(t0, j + ND * NW);
-        if (j + NW < ntile) process_tile(t1, kbeg + 16 * (j + NW), kend);
-        load_tile(t1, j + (ND + 1) * NW);
-        if constexpr (ND == 3) {
-            if (j + 2 * NW < ntile) process_tile(t2, kbeg + 16 * (j + 2 * NW), kend);
-            load_tile(t2, j + 5 * NW);
-        }
-    }
+    const uint16_t* qraw = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(head0 + (c < GPW ? c : 0)) * HD;
     if (wave == NW - 1) {
-        // the new token (one extra 1-key tile): K roped from the raw QKV row (lanes c == 0 hold its 4 x 32 dims), V raw; the first head
-        // slice's workgroup is the single writer of cache slot q_pos0 of (row, kv head)
+        // The LAST wave takes the new token only (one 1-key tile): its K is roped from the raw QKV row, its V is raw, and every
+        // operand is requested at kernel entry beside the query's -- behind a cache-tile loop this wave would start the dependent
+        // rope loads when the others are done (measured: 3.5 us of tail).  The first head slice's workgroup is the single writer of
+        // cache slot q_pos0 of (row, kv head).
         const int slot = kend;
         const uint16_t* kraw = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + kvh) * HD;
         const uint16_t* vrow = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + a.KVH + kvh) * HD;
+        rope_regs rr, rk;
+        rope32_load(qraw, h4, a, p0, p1, p2, rr);
+        rope32_load(kraw, h4, a, p0, p1, p2, rk);          // (every lane: the lanes c != 0 re-read the same row and drop it)
+        const uint4 vnew = ld16(vrow + c * 8);
+        uint4 u[4], kn[4];
+        rope32_math(rr, h4, u);
+        rope32_math(rk, h4, kn);
         tile_t tn;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) tn.k[kb] = make_uint4(0, 0, 0, 0);
-        if (c == 0) {
-            rope32(kraw, h4, a, p0, p1, p2, tn.k);
-            if (hs == 0) {
-                uint16_t* kd = const_cast<uint16_t*>(a.k_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + h4 * 32;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) st16(kd + kb * 8, tn.k[kb]);
-            }
+        for (int kb = 0; kb < 4; ++kb) {
+            qf[kb] = __builtin_bit_cast(bf16x8_t, c < GPW ? u[kb] : make_uint4(0, 0, 0, 0));
+            tn.k[kb] = c == 0 ? kn[kb] : make_uint4(0, 0, 0, 0);
         }
-        const uint4 vnew = ld16(vrow + c * 8);
 #pragma unroll
         for (int r = 0; r < 4; ++r) tn.v[r] = vnew;
-        if (hs == 0 && h4 == 0)
-            st16(const_cast<uint16_t*>(a.v_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + c * 8, vnew);
+        if (hs == 0) {
+            if (c == 0) {
+                uint16_t* kd = const_cast<uint16_t*>(a.k_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + h4 * 32;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) st16(kd + kb * 8, kn[kb]);
+            }
+            if (h4 == 0)
+                st16(const_cast<uint16_t*>(a.v_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + c * 8, vnew);
+        }
+        TL_MARK(7, 4);
         process_tile(tn, slot, slot + 1);                 // keys slot + 1 .. are masked (p = 0)
+    } else {
+        constexpr int NWT = NW - 1;                       // waves that walk the cache tiles
+        {
+            uint4 u[4];
+            rope_regs rr;
+            rope32_load(qraw, h4, a, p0, p1, p2, rr);
+            __builtin_amdgcn_sched_barrier(0);
+            load_tile(t0, wave);
+            load_tile(t1, wave + NWT);
+            if constexpr (ND == 3) load_tile(t2, wave + 2 * NWT);
+            __builtin_amdgcn_sched_barrier(0);
+            rope32_math(rr, h4, u);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) qf[kb] = __builtin_bit_cast(bf16x8_t, c < GPW ? u[kb] : make_uint4(0, 0, 0, 0));
+        }
+        TL_MARK(7, 4);
+        // ring of ND register tiles; `j` and `ntile` are wave-uniform scalars
+        for (int j = wave; j < ntile; j += ND * NWT) {
+            process_tile(t0, kbeg + 16 * j, kend);
+            load_tile(t0, j + ND * NWT);
+            if (j + NWT < ntile) process_tile(t1, kbeg + 16 * (j + NWT), kend);
+            load_tile(t1, j + (ND + 1) * NWT);
+            if constexpr (ND == 3) {
+                if (j + 2 * NWT < ntile) process_tile(t2, kbeg + 16 * (j + 2 * NWT), kend);
+                load_tile(t2, j + 5 * NWT);
+            }
+        }
+        TL_MARK(7, 6);
     }
     TL_MARK(7, 5);
     // ---- merge: 8 waves x 4 key quarters -> one output row per head -------------------------------------------------------------
@@ -628,6 +643,7 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
         *reinterpret_cast<float4*>(d + 4) = make_float4(o[g][4], o[g][5], o[g][6], o[g][7]);
     }
     __syncthreads();
+    TL_MARK(7, 8);
     for (int idx = tid; idx < GPW * (HD / 2); idx += 512) {
         const int g = idx >> 6, col = (idx & 63) * 2;
         float mm = -INFINITY;
