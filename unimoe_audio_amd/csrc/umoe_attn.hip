@@ -470,11 +470,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
 template <int GPW>
 __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) {
     constexpr int HD = 128, NW = 8, PS = 20;              // PS: p_lds row stride in floats (80 B: the four key quarters hit disjoint banks)
-    constexpr int ND = GPW == 8 ? 2 : 3;                  // register tiles in flight per wave
+    constexpr int ND = 2, NWT = NW - 1;                   // register tiles per wave = one softmax batch of ND * 16 keys (3 tiles spill: 104
+                                                          // registers to scratch, reloaded around the MFMAs); waves that walk the cache
     extern __shared__ __attribute__((aligned(16))) char smem_w[];
     float* red_o = reinterpret_cast<float*>(smem_w);      // [NW][4 key quarters][GPW][HD]
-    float* p_lds = red_o + NW * 4 * GPW * HD;             // [NW][16 keys][PS]
-    float* al_lds = p_lds + NW * 16 * PS;                 // [NW][16]
+    float* p_lds = red_o + NW * 4 * GPW * HD;             // [NW][48 keys of a batch][PS]
+    float* al_lds = p_lds + NW * 48 * PS;                 // [NW][16]
     float* red_ml = al_lds + NW * 16;                     // [NW][16][2]
     TL_ENTER(7);
     const int G = a.H / a.KVH;
@@ -496,13 +497,18 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
     struct tile_t { uint4 k[4], v[4]; };
     // unconditional, clamped loads (a tile past the range re-reads the last key: cache hits, masked below) -- straight-line code, so
     // the compiler counts the loads and a tile is consumed while the younger ones are still in flight
-    auto load_tile = [&](tile_t& t, const int j) {
-        const int k0 = kbeg + 16 * j;
-        const uint16_t* kp = Kc + (size_t)max(min(k0 + c, kend - 1), 0) * HD + h4 * 32;
+    auto load_tile_k = [&](tile_t& t, const int j) {
+        const uint16_t* kp = Kc + (size_t)max(min(kbeg + 16 * j + c, kend - 1), 0) * HD + h4 * 32;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) t.k[kb] = ld16(kp + kb * 8);
+    };
+    auto load_tile_v = [&](tile_t& t, const int j) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t.v[r] = ld16(Vc + (size_t)max(min(k0 + 4 * h4 + r, kend - 1), 0) * HD + c * 8);
+        for (int r = 0; r < 4; ++r) t.v[r] = ld16(Vc + (size_t)max(min(kbeg + 16 * j + 4 * h4 + r, kend - 1), 0) * HD + c * 8);
+    };
+    auto load_tile = [&](tile_t& t, const int j) {
+        load_tile_k(t, j);
+        load_tile_v(t, j);
     };
     tile_t t0, t1, t2;
     bf16x8_t qf[4];
@@ -512,19 +518,34 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
     for (int g = 0; g < GPW; ++g)
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
-    float* pw = p_lds + wave * 16 * PS;
+    float* pw = p_lds + wave * (ND * 16) * PS;
     float* aw = al_lds + wave * 16;
-    auto process_tile = [&](const tile_t& t, const int k0, const int kend_t) {
-        f32x4_t sacc = {0.f, 0.f, 0.f, 0.f};              // S[key = 4 h4 + r][head = c]
+    // ONE online-softmax step over the three register tiles (48 keys): three independent MFMA chains, one max / sum reduction, one
+    // trip through LDS for the probabilities, one rescale of the accumulators -- per 16-key tile that serial chain (4 dependent
+    // MFMAs, 4 cross-row shuffles, LDS write -> read) cost ~1.4 us per tile and wave, which made the launch slower than the
+    // key-split pair from 300 keys on (scripts/attn_bench.py).  Tiles past the key range are masked (p = 0) and carry finite values.
+    // `refill`: the next batch's K is requested right behind the MFMAs, each tile's V right behind its P.V.
+    auto process_batch = [&](const int k0a, const int k0b, const int k0c, const int kend_t, const bool refill, const int jn) {
+        f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sc = sa;     // S[key = 4 h4 + r][head = c] of the three tiles
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, t.k[kb]), qf[kb], sacc, 0, 0, 0);
-        float sv[4];
+        for (int kb = 0; kb < 4; ++kb) {
+            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, t0.k[kb]), qf[kb], sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, t1.k[kb]), qf[kb], sb, 0, 0, 0);
+            if constexpr (ND == 3) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, t2.k[kb]), qf[kb], sc, 0, 0, 0);
+        }
+        float sv[3][4];
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            sv[r] = (k0 + 4 * h4 + r < kend_t) ? sacc[r] * a.scale : -INFINITY;
-            tmax = fmaxf(tmax, sv[r]);
+            sv[0][r] = (k0a + 4 * h4 + r < kend_t) ? sa[r] * a.scale : -INFINITY;
+            sv[1][r] = (k0b + 4 * h4 + r < kend_t) ? sb[r] * a.scale : -INFINITY;
+            sv[2][r] = (ND == 3 && k0c + 4 * h4 + r < kend_t) ? sc[r] * a.scale : -INFINITY;
+            tmax = fmaxf(tmax, fmaxf(sv[0][r], fmaxf(sv[1][r], sv[2][r])));
+        }
+        if (refill) {
+            load_tile_k(t0, jn);
+            load_tile_k(t1, jn + NWT);
+            if constexpr (ND == 3) load_tile_k(t2, jn + 2 * NWT);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -532,11 +553,13 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
         const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float pv = (sv[r] == -INFINITY) ? 0.f : __expf(sv[r] - m_new);
-            psum += pv;
-            pw[(4 * h4 + r) * PS + c] = pv;
-        }
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = (sv[i][r] == -INFINITY) ? 0.f : __expf(sv[i][r] - m_new);
+                psum += pv;
+                pw[(16 * i + 4 * h4 + r) * PS + c] = pv;
+            }
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
@@ -549,47 +572,75 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[g][j] *= al;
         }
+        auto pv_tile = [&](const tile_t& t, const int i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v[8], pv[GPW];
-            unpack8(t.v[r], v);
-            const float4* pr4 = reinterpret_cast<const float4*>(pw + (4 * h4 + r) * PS);
+            for (int r = 0; r < 4; ++r) {
+                float v[8], pv[GPW];
+                unpack8(t.v[r], v);
+                const float4* pr4 = reinterpret_cast<const float4*>(pw + (16 * i + 4 * h4 + r) * PS);
 #pragma unroll
-            for (int q4 = 0; q4 < GPW / 4; ++q4) {
-                const float4 t4 = pr4[q4];
-                pv[4 * q4] = t4.x; pv[4 * q4 + 1] = t4.y; pv[4 * q4 + 2] = t4.z; pv[4 * q4 + 3] = t4.w;
+                for (int q4 = 0; q4 < GPW / 4; ++q4) {
+                    const float4 t4 = pr4[q4];
+                    pv[4 * q4] = t4.x; pv[4 * q4 + 1] = t4.y; pv[4 * q4 + 2] = t4.z; pv[4 * q4 + 3] = t4.w;
+                }
+#pragma unroll
+                for (int g = 0; g < GPW; ++g)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[g][j] += pv[g] * v[j];
             }
-#pragma unroll
-            for (int g = 0; g < GPW; ++g)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[g][j] += pv[g] * v[j];
+        };
+        pv_tile(t0, 0);
+        if (refill) load_tile_v(t0, jn);
+        pv_tile(t1, 1);
+        if (refill) load_tile_v(t1, jn + NWT);
+        if constexpr (ND == 3) {
+            pv_tile(t2, 2);
+            if (refill) load_tile_v(t2, jn + 2 * NWT);
         }
         __builtin_amdgcn_wave_barrier();
     };
     const uint16_t* qraw = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(head0 + (c < GPW ? c : 0)) * HD;
     if (wave == NW - 1) {
-        // The LAST wave takes the new token only (one 1-key tile): its K is roped from the raw QKV row, its V is raw, and every
-        // operand is requested at kernel entry beside the query's -- behind a cache-tile loop this wave would start the dependent
-        // rope loads when the others are done (measured: 3.5 us of tail).  The first head slice's workgroup is the single writer of
-        // cache slot q_pos0 of (row, kv head).
+        // The LAST wave takes the new token only: its K is roped from the raw QKV row, its V is raw, and every operand is requested
+        // at kernel entry beside the query's -- behind a cache-tile loop this wave would start the dependent rope loads when the
+        // others are done (measured: 3.5 us of tail).  The first head slice's workgroup is the single writer of cache slot q_pos0
+        // of (row, kv head).  The batch's other two tiles are copies of the token's, masked.
         const int slot = kend;
         const uint16_t* kraw = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + kvh) * HD;
         const uint16_t* vrow = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + a.KVH + kvh) * HD;
-        rope_regs rr, rk;
+        rope_regs rr;
         rope32_load(qraw, h4, a, p0, p1, p2, rr);
-        rope32_load(kraw, h4, a, p0, p1, p2, rk);          // (every lane: the lanes c != 0 re-read the same row and drop it)
+        // the key's rope shares the query's cos / sin operands (same position, same 32 dims per lane): 8 more loads, not 16
+        // (every lane loads: the lanes c != 0 re-read the same row and drop it)
+        uint4 kx[4], ky[4];
+        {
+            const bool first = h4 < 2;
+            const uint16_t* own = kraw + h4 * 32;
+            const uint16_t* par = kraw + (first ? h4 * 32 + 64 : h4 * 32 - 64);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                kx[kb] = ld16(own + kb * 8);
+                ky[kb] = ld16(par + kb * 8);
+            }
+        }
         const uint4 vnew = ld16(vrow + c * 8);
         uint4 u[4], kn[4];
         rope32_math(rr, h4, u);
-        rope32_math(rk, h4, kn);
-        tile_t tn;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            rr.x[kb] = kx[kb];
+            rr.y[kb] = ky[kb];
+        }
+        rope32_math(rr, h4, kn);
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             qf[kb] = __builtin_bit_cast(bf16x8_t, c < GPW ? u[kb] : make_uint4(0, 0, 0, 0));
-            tn.k[kb] = c == 0 ? kn[kb] : make_uint4(0, 0, 0, 0);
+            t0.k[kb] = c == 0 ? kn[kb] : make_uint4(0, 0, 0, 0);
+            t1.k[kb] = t0.k[kb];
+            t2.k[kb] = t0.k[kb];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tn.v[r] = vnew;
+        for (int r = 0; r < 4; ++r) t0.v[r] = t1.v[r] = t2.v[r] = vnew;
         if (hs == 0) {
             if (c == 0) {
                 uint16_t* kd = const_cast<uint16_t*>(a.k_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + h4 * 32;
@@ -600,9 +651,8 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
                 st16(const_cast<uint16_t*>(a.v_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + c * 8, vnew);
         }
         TL_MARK(7, 4);
-        process_tile(tn, slot, slot + 1);                 // keys slot + 1 .. are masked (p = 0)
+        process_batch(slot, slot + 16, slot + 32, slot + 1, false, 0);      // keys slot + 1 .. are masked (p = 0)
     } else {
-        constexpr int NWT = NW - 1;                       // waves that walk the cache tiles
         {
             uint4 u[4];
             rope_regs rr;
@@ -617,17 +667,9 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
             for (int kb = 0; kb < 4; ++kb) qf[kb] = __builtin_bit_cast(bf16x8_t, c < GPW ? u[kb] : make_uint4(0, 0, 0, 0));
         }
         TL_MARK(7, 4);
-        // ring of ND register tiles; `j` and `ntile` are wave-uniform scalars
-        for (int j = wave; j < ntile; j += ND * NWT) {
-            process_tile(t0, kbeg + 16 * j, kend);
-            load_tile(t0, j + ND * NWT);
-            if (j + NWT < ntile) process_tile(t1, kbeg + 16 * (j + NWT), kend);
-            load_tile(t1, j + (ND + 1) * NWT);
-            if constexpr (ND == 3) {
-                if (j + 2 * NWT < ntile) process_tile(t2, kbeg + 16 * (j + 2 * NWT), kend);
-                load_tile(t2, j + 5 * NWT);
-            }
-        }
+        // `j` and `ntile` are wave-uniform scalars; the refill loads are unconditional (clamped) so that the compiler counts them
+        for (int j = wave; j < ntile; j += ND * NWT)
+            process_batch(kbeg + 16 * j, kbeg + 16 * (j + NWT), kbeg + 16 * (j + 2 * NWT), kend, true, j + ND * NWT);
         TL_MARK(7, 6);
     }
     TL_MARK(7, 5);
@@ -642,7 +684,9 @@ __global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) 
         *reinterpret_cast<float4*>(d) = make_float4(o[g][0], o[g][1], o[g][2], o[g][3]);
         *reinterpret_cast<float4*>(d + 4) = make_float4(o[g][4], o[g][5], o[g][6], o[g][7]);
     }
-    __syncthreads();
+    // (the last batch's refill loads are still in flight and never consumed: wait for the LDS writes only)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     TL_MARK(7, 8);
     for (int idx = tid; idx < GPW * (HD / 2); idx += 512) {
         const int g = idx >> 6, col = (idx & 63) * 2;
@@ -761,7 +805,7 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
                      a->H, a->KVH, a->nq);
         // (a workgroup takes FOUR of the eight query heads: with all eight the 64 fp32 accumulators beside two register tiles spill,
         //  and a scratch reload in front of every MFMA waits for the whole load queue)
-        constexpr int lds4 = (8 * 4 * 4 * 128 + 8 * 16 * 20 + 8 * 16 + 8 * 16 * 2) * 4;
+        constexpr int lds4 = (8 * 4 * 4 * 128 + 8 * 48 * 20 + 8 * 16 + 8 * 16 * 2) * 4;
         static bool configured = false;
         if (!configured) {
             UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
