@@ -197,7 +197,10 @@ def roofline(cfg, info, args, ep=1):
         # expert parallel: two gate/up launches per layer (shared experts beside the exchange, then the local experts over the
         # ep*16 gathered rows); algorithmic bytes = each weight once
         bytes_per_launch = ((n_real / ep) * 2 * Id * D + n_fix * 2 * Is * D) * 2.0 / 2
-        kname = "wstream_gemm<14, 1, 0, 2, 8, true> + wstream_gemm<2, 1, 0, 2, 8, false>"
+        # (peer / loopback exchange: the local experts run in the multi-tile launch wstream_mt over all ranks' rows; the RCCL
+        #  fallback keeps the single-tile grouped launch)
+        local = "wstream_gemm<14, 1, 0, 2, 8, true>" if info.get("backend") == "rccl" else "wstream_mt (local experts over every rank's rows)"
+        kname = local + " + wstream_gemm<2, 1, 0, 2, 8, false>"
         what = f" (expert parallel x{ep}: local experts' and shared experts' gate/up launches, averaged)"
     achieved = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     K = info["steps"]
