@@ -451,6 +451,130 @@ def test_dcmoe_block_fullsize_vs_oracle(dev):
         assert torch.allclose(out[0].float()[0][same], ref[0].float()[0][same], rtol=2 ** -5, atol=2 ** -9)
 
 
+@pytest.mark.parametrize("case", ["all_padded", "null_expert_only", "every_expert", "one_expert_takes_all", "single_token", "seventeen_tokens",
+                                  "half_padded_ragged"])
+def test_dcmoe_block_edge_cases_vs_oracle(dev, case):
+    """The block at the edges of its routing domain (small width, every size ragged on purpose), against the CPU oracle (itself pinned
+    to the reference's fixtures): every token padded (no routed rows at all, shared experts only), every token on the NULL expert only
+    (all eight real experts idle: empty groups in the grouped launches), every token on all nine columns (maximum fan-out, top-p close
+    to 1), one expert taking every row while seven stay empty, one token, 17 tokens (one past a 16-row tile), a padded half."""
+    from oracle import router as OR
+    from oracle.dcmoe import DCMoEOracle
+    cfgd = dict(hidden_size=64, mlp_dynamic_expert_num=8, mlp_dynamic_null_expert_num=1, mlp_dynamic_top_p=0.7, mlp_dynamic_top_k=2,
+                mlp_fixed_expert_num=2, ignore_differentiable_router=True, ep_size=1, router_jitter_noise=0.01, input_jitter_noise=0.0,
+                min_capacity=8, capacity_factor=6.0, token_drop=False, drop_policy="probs", avg_hidden_states_last=False,
+                drop_token_num_print=False, fp32_gate=True, dynamic_intermediate_size=96, shared_intermediate_size=64, hidden_act="silu",
+                enable_expert_tensor_parallelism=False)
+    B, T = 3, 11
+    if case == "every_expert":
+        cfgd["mlp_dynamic_top_p"] = 0.9999
+    if case == "single_token":
+        B, T = 1, 1
+    if case == "seventeen_tokens":
+        B, T = 1, 17
+    cfg = types.SimpleNamespace(**cfgd)
+    torch.manual_seed({"all_padded": 1, "null_expert_only": 2, "every_expert": 3, "one_expert_takes_all": 4, "single_token": 5,
+                       "seventeen_tokens": 6, "half_padded_ragged": 7}[case])
+    from unimoe_audio_amd.dcmoe import UniMoEAudioSparseMoeBlock
+    blk = UniMoEAudioSparseMoeBlock(cfg)
+    with torch.no_grad():
+        for n, p_ in blk.named_parameters():
+            p_.normal_(0, 0.35 if n == "gate.weight" else 0.08)
+        x = torch.randn(B, T, 64)
+        if case in ("null_expert_only", "one_expert_takes_all"):
+            # a gate row aligned with a direction every input carries: that column wins by a wide margin (softmax mass > top-p alone)
+            col = 8 if case == "null_expert_only" else 3
+            x[..., 0] = 6.0
+            blk.gate.weight.zero_()
+            blk.gate.weight[col, 0] = 2.0
+        if case == "every_expert":
+            blk.gate.weight[:9].mul_(0.02)               # nearly flat dynamic logits: the cumulative mass passes 0.9999 only at the last column
+    blk = blk.to(torch.bfloat16).eval()
+    x = x.to(torch.bfloat16)
+    am = None
+    if case == "all_padded":
+        am = torch.zeros(B, T, dtype=torch.bool)
+    if case == "half_padded_ragged":
+        am = torch.ones(B, T, dtype=torch.bool)
+        am[0, :7] = False
+        am[1, :] = False
+        am[2, :1] = False
+    w = {k: v.clone() for k, v in blk.state_dict().items()}
+    ref = DCMoEOracle(cfg, w)(x, am, None)
+    with torch.no_grad():
+        out = [o.cpu() for o in blk.to(dev)(x.to(dev), None if am is None else am.to(dev), None)]
+    hid, logits, top_k, mask, weight, aux = out
+    o = OR.route(logits, 9, 8, 2, float(cfg.mlp_dynamic_top_p), 2, 0.01, None if am is None else am.reshape(-1))
+    assert torch.equal(top_k.long(), o["top_k"]) and torch.equal(mask, o["expert_mask"])       # ints exact on the GPU's own logits
+    same = (logits.float() == ref[1].float()).all(-1)
+    assert torch.equal(top_k.long()[same], ref[2].long()[same]) and torch.equal(mask[same], ref[3][same])
+    routed = mask[:, :8].sum(0)
+    if case == "all_padded":
+        assert int(mask[:, :9].sum()) == 0 and bool((mask[:, 9:] == 1).all())
+    if case == "null_expert_only":
+        assert int(routed.sum()) == 0 and bool((mask[:, 8] == 1).all()) and bool((top_k == 1).all())
+    if case == "every_expert":
+        assert bool((top_k == 9).all()) and bool((mask[:, :9] == 1).all())
+    if case == "one_expert_takes_all":
+        assert int(routed[3]) == B * T and int(routed.sum()) == B * T
+    agree = (mask == ref[3]).all(-1)
+    assert agree.float().mean() > 0.8
+    assert torch.isfinite(hid.float()).all()
+    ok = agree.reshape(B, T)
+    assert torch.allclose(hid.float()[ok], ref[0].float()[ok], rtol=2 ** -5, atol=2 ** -7)
+    assert torch.allclose(weight.float()[agree], ref[4].float()[agree], rtol=2 ** -6, atol=2 ** -8)
+
+
+@pytest.mark.parametrize("case", ["null_expert_only", "one_expert_takes_all"])
+def test_dcmoe_block_backward_with_idle_experts(dev, case):
+    """Training step of the block when real experts receive NO row (every token on the null expert / on expert 3 only): the grouped
+    forward and weight-gradient launches see empty groups.  Against the differentiable CPU oracle: idle experts' weight gradients are
+    exactly zero, everything else within the block-level tolerance."""
+    from oracle import dcmoe_autograd as OA
+    from unimoe_audio_amd.dcmoe import UniMoEAudioSparseMoeBlock
+    cfg = types.SimpleNamespace(hidden_size=64, mlp_dynamic_expert_num=8, mlp_dynamic_null_expert_num=1, mlp_dynamic_top_p=0.7, mlp_dynamic_top_k=2,
+                                mlp_fixed_expert_num=2, ignore_differentiable_router=True, ep_size=1, router_jitter_noise=0.01,
+                                input_jitter_noise=0.0, min_capacity=8, capacity_factor=6.0, token_drop=False, drop_policy="probs",
+                                avg_hidden_states_last=False, drop_token_num_print=False, fp32_gate=True, dynamic_intermediate_size=96,
+                                shared_intermediate_size=64, hidden_act="silu", enable_expert_tensor_parallelism=False)
+    torch.manual_seed(21 if case == "null_expert_only" else 22)
+    B, T = 3, 24
+    blk = UniMoEAudioSparseMoeBlock(cfg)
+    col = 8 if case == "null_expert_only" else 3
+    with torch.no_grad():
+        for n, p_ in blk.named_parameters():
+            p_.normal_(0, 0.08)
+        x = torch.randn(B, T, 64)
+        x[..., 0] = 6.0
+        blk.gate.weight.zero_()
+        blk.gate.weight[col, 0] = 2.0
+    blk = blk.to(torch.bfloat16).train()
+    x = x.to(torch.bfloat16)
+    G = torch.randn(B, T, 64).to(torch.bfloat16)
+    w = {k: v.clone() for k, v in blk.state_dict().items()}
+    wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    xo = x.clone().requires_grad_(True)
+    ro = OA.forward(cfg, wo, xo, None, None, training=True)
+    ((ro[0].float() * G.float()).sum() + 0.3 * ro[5].float()).backward()
+    gm = blk.to(dev)
+    for p_ in gm.parameters():
+        p_.requires_grad_(True)
+    xg = x.to(dev).requires_grad_(True)
+    out = gm(xg, None, None)
+    assert torch.equal(out[3].cpu(), ro[3])
+    ((out[0].float() * G.to(dev).float()).sum() + 0.3 * out[5].float()).backward()
+    assert torch.allclose(out[0].detach().cpu().float(), ro[0].detach().float(), rtol=2 ** -5, atol=2 ** -6)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+    assert rel(xg.grad.cpu(), xo.grad) < 0.03
+    for n, p_ in gm.named_parameters():
+        ref = wo[n].grad
+        idle = "deepspeed_experts" in n and not (case == "one_expert_takes_all" and ".3." in n)
+        if idle or ref is None or float(ref.float().norm()) == 0.0:
+            assert p_.grad is None or float(p_.grad.float().abs().max()) == 0.0, n         # no row, no gradient: exactly zero
+        else:
+            assert p_.grad is not None and rel(p_.grad.cpu(), ref) < 0.03, (n, rel(p_.grad.cpu(), ref))
+
+
 # ----------------------------------------------------------------------------- rope / attention
 def _attn_setup(rows, T, H, KVH, hd, Lmax, pads, seed):
     from oracle import decode as OD
