@@ -30,6 +30,18 @@ def test_transpose_slots_plain_and_grouped(dev):
     t = ops.transpose(src.to(dev)).cpu()
     assert t.shape == (130, 208)
     assert torch.equal(t[:, :203], src.t()) and float(t[:, 203:].abs().sum()) == 0.0          # zero padded to 8
+    # whole 16-byte chunks (C % 8 == 0): the register-transpose kernel (8 x 8 blocks per thread, 128 x 128 per workgroup); ragged row
+    # counts around its block / workgroup edges, a column view of a wider source
+    for R, Cc in ((203, 136), (1, 8), (8, 8), (129, 128), (257, 264), (1560, 2048)):
+        src = torch.randn(R, Cc, generator=g).to(torch.bfloat16)
+        t = ops.transpose(src.to(dev)).cpu()
+        assert t.shape == (Cc, (R + 7) // 8 * 8)
+        assert torch.equal(t[:, :R], src.t()) and float(t[:, R:].abs().sum()) == 0.0, (R, Cc)
+    wide = torch.randn(77, 200, generator=g).to(torch.bfloat16).to(dev)
+    view = wide[:, 40:168]                                                # 128 columns starting at a multiple of 8, row stride 200
+    t = torch.empty((128, 80), dtype=torch.bfloat16, device=dev)
+    ops.transpose_slots(view, t)
+    assert torch.equal(t.cpu()[:, :77], view.cpu().t()) and float(t.cpu()[:, 77:].abs().sum()) == 0.0
     # grouped: 3 experts, 8-aligned slot ranges, gather list
     mask = (torch.rand(90, 5, generator=g) < 0.4).to(torch.int32)
     mask[:, 1] = 0
