@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[0] (single prompt) legs")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=7, help="timed CPU-oracle decode steps (median; two warm-up steps before them)")
     return ap.parse_args()
 
 
@@ -282,7 +282,7 @@ def cpu_baseline(args, batch=None, steps=None):
     tok = torch.randint(0, 1024, (B, 1, cfg.codec_channels))
     times = []
     with torch.no_grad():
-        for s in range(n_steps + 1):
+        for s in range(n_steps + 2):
             t0 = time.perf_counter()
             key_valid = torch.cat([key_valid, torch.ones(rows, 1, dtype=torch.bool)], -1)
             pos = (key_valid.long().cumsum(-1) - 1)[:, -1:]
@@ -292,10 +292,10 @@ def cpu_baseline(args, batch=None, steps=None):
             pred = OD.sample_next_token(guided.reshape(B * cfg.codec_channels, -1), 1.2, 0.95, 45, cfg.codec_eos_value)
             tok = pred.view(B, 1, cfg.codec_channels)
             times.append(time.perf_counter() - t0)
-    steady = sorted(times[1:])                           # first step = warm-up
+    steady = sorted(times[2:])                           # first two steps = warm-up (thread pool, page faults of the 14 GB of weights)
     sec = steady[len(steady) // 2]                       # median
     return {"value": round(B / sec, 3), "unit": "audio-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"median of {len(steady)} decode steps (after 1 warm-up) of the full {cfg.num_hidden_layers}-layer model, batch {B} "
+            "sample": f"median of {len(steady)} decode steps (after 2 warm-up steps) of the full {cfg.num_hidden_layers}-layer model, batch {B} "
                       f"({2 * B} CFG rows), synthetic KV cache of {L} tokens, torch-CPU bf16 oracle (oracle/decode.py), "
                       f"{sec * 1e3:.0f} ms/step"}
 
