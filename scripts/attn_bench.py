@@ -15,6 +15,7 @@ from unimoe_audio_amd import ops
 dev = torch.device("cuda:0")
 rows, H, KVH, hd, NSET = 16, 16, 2, 128, 40
 Ls = [int(v) for v in sys.argv[1:]] or [305, 460, 610, 814, 1600]
+SPLITS = [int(v) for v in os.environ.get("AB_SPLITS", "8").split(",")]
 for L in Ls:
     Lmax = ((L + 80) // 64) * 64
     g = torch.Generator().manual_seed(L)
@@ -27,7 +28,8 @@ for L in Ls:
     cos_tab, sin_tab = ops.rope_tables(Lmax + 8, hd, 1e6, dev)
     p3 = torch.stack([q0, q0, q0]).to(torch.int32).contiguous()
     kw = dict(qkv_raw=qkv, cos_tab=cos_tab, sin_tab=sin_tab, pos3=p3, sections=(16, 24, 24))
-    for name, akw in (("split8+merge", dict(splits=8)), ("wide", dict(splits=1, wide=1))):
+    forms = [(f"split{n}+merge", dict(splits=n)) for n in SPLITS] + [("wide", dict(splits=1, wide=1))]
+    for name, akw in forms:
         def run(n):
             for i in range(n):
                 ops.attention(None, kcs[i % NSET], vcs[i % NSET], kv_start, q0, 1, H, **akw, **kw)
