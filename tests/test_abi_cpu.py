@@ -118,3 +118,14 @@ def test_restaging_barriers_behind_transposing_reads_are_pinned():
             assert ("TR_PIN8(" in tail[:sync]) or ('"+v"(acc_o[0])' in tail[:sync]), (f, src[: m.start()].count("\n") + 1)
             found += 1
     assert found >= 3
+
+
+def test_integration_doc_router_stub_mirrors_the_whole_struct():
+    """INTEGRATION.md shows the binding a reference maintainer would write; a mirror SHORTER than umoe_router_args would let the library
+    read past it (trailing pointer fields), so the documented field list must be the one of unimoe_audio_amd/_lib.py, in order."""
+    import re
+    from unimoe_audio_amd import _lib as L
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class RouterArgs(C.Structure)"):doc.index("def router(hidden_states")]
+    names = re.findall(r'\("(\w+)",\s*C\.c_', block)
+    assert names == [n for n, _ in L.RouterArgs._fields_], (names, [n for n, _ in L.RouterArgs._fields_])
