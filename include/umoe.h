@@ -29,6 +29,10 @@ typedef void* umoe_stream_t;
 
 const char* umoe_last_error(void);
 int umoe_abi_version(void);
+/* sizeof of an argument struct of this header AS THE LIBRARY WAS BUILT ("umoe_router_args", "umoe_gemm_args", ...; 0 = unknown name).
+ * Every struct here is passed by pointer and read whole, and they grow at the end between versions: a binding checks its mirrors
+ * against this at load time (unimoe_audio_amd/_lib.py does) instead of letting a stale build read past a shorter struct. */
+size_t umoe_struct_size(const char* name);
 
 /* ------------------------------------------------------------------ weight layout
  * nn.Linear weights W[N][K] (bf16) are re-laid once at load time into the MFMA operand

@@ -79,11 +79,11 @@ def test_ctypes_mirrors_have_the_size_and_offsets_of_the_c_structs(tmp_path):
     import ctypes as C
     import subprocess
     from unimoe_audio_amd import _lib as L
-    pairs = {"umoe_router_args": L.RouterArgs, "umoe_group_t": L.Group, "umoe_gemm_args": L.GemmArgs, "umoe_tgroup_t": L.TGroup,
-             "umoe_tgemm_args": L.TGemmArgs, "umoe_swiglu_bwd_args": L.SwigluBwdArgs, "umoe_attn_bwd_args": L.AttnBwdArgs,
-             "umoe_combine_args": L.CombineArgs, "umoe_rope_args": L.RopeArgs, "umoe_attn_args": L.AttnArgs,
-             "umoe_sample_args": L.SampleArgs, "umoe_engine_cfg": L.EngineCfg, "umoe_layer_weights": L.LayerWeights,
-             "umoe_decode_io": L.DecodeIO}
+    pairs = L.STRUCT_MIRRORS
+    assert len(pairs) == 14
+    for cname, cls in pairs.items():                       # the built library agrees too (checked again at every load)
+        assert int(L.lib().umoe_struct_size(cname.encode())) == C.sizeof(cls), cname
+    assert int(L.lib().umoe_struct_size(b"no_such_struct")) == 0
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "umoe.h"', 'int main(void) {']
     for cname, cls in pairs.items():
         src.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

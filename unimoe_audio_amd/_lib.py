@@ -142,6 +142,16 @@ EP_PEER, EP_LOOPBACK, EP_RCCL = 0, 1, 2
 MAX_EP = 8
 
 
+def _mirrors():
+    return {"umoe_router_args": RouterArgs, "umoe_group_t": Group, "umoe_gemm_args": GemmArgs, "umoe_tgroup_t": TGroup,
+            "umoe_tgemm_args": TGemmArgs, "umoe_swiglu_bwd_args": SwigluBwdArgs, "umoe_attn_bwd_args": AttnBwdArgs,
+            "umoe_combine_args": CombineArgs, "umoe_rope_args": RopeArgs, "umoe_attn_args": AttnArgs, "umoe_sample_args": SampleArgs,
+            "umoe_engine_cfg": EngineCfg, "umoe_layer_weights": LayerWeights, "umoe_decode_io": DecodeIO}
+
+
+STRUCT_MIRRORS = _mirrors()          # C struct name -> ctypes mirror (tests/test_abi_cpu.py compares offsets field by field)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -231,6 +241,17 @@ def lib():
         L.umoe_engine_capture.argtypes = [vp, C.POINTER(DecodeIO), vp]
         L.umoe_engine_replay.argtypes = [vp, vp]
         L.umoe_engine_profile_step.argtypes = [vp, C.POINTER(DecodeIO), vp, C.POINTER(f32), C.POINTER(i32), i32]
+        # the mirrors above against the structs the library was BUILT with: a stale libumoe_hip.so (or a stale mirror) must fail here,
+        # not read past a shorter struct
+        if not hasattr(L, "umoe_struct_size"):
+            raise UmoeError(f"{_SO} predates this package (no umoe_struct_size): rebuild it (`make -C unimoe_audio_amd/csrc`)")
+        L.umoe_struct_size.restype = C.c_size_t
+        L.umoe_struct_size.argtypes = [C.c_char_p]
+        for cname, cls in STRUCT_MIRRORS.items():
+            built = int(L.umoe_struct_size(cname.encode()))
+            if built != C.sizeof(cls):
+                raise UmoeError(f"{_SO}: sizeof({cname}) is {built} in the library and {C.sizeof(cls)} in unimoe_audio_amd/_lib.py: "
+                                "the library and the package are of different versions -- rebuild (`make -C unimoe_audio_amd/csrc`)")
         _lib = L
     return _lib
 

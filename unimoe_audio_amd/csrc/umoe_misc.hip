@@ -14,6 +14,15 @@ void umoe_set_error(const char* fmt, ...) {
 }
 extern "C" const char* umoe_last_error(void) { return g_err; }
 extern "C" int umoe_abi_version(void) { return 1; }
+extern "C" size_t umoe_struct_size(const char* name) {
+    if (!name) return 0;
+#define UMOE_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
+    UMOE_SZ(umoe_router_args) UMOE_SZ(umoe_group_t) UMOE_SZ(umoe_gemm_args) UMOE_SZ(umoe_tgroup_t) UMOE_SZ(umoe_tgemm_args)
+    UMOE_SZ(umoe_swiglu_bwd_args) UMOE_SZ(umoe_attn_bwd_args) UMOE_SZ(umoe_combine_args) UMOE_SZ(umoe_rope_args) UMOE_SZ(umoe_attn_args)
+    UMOE_SZ(umoe_sample_args) UMOE_SZ(umoe_engine_cfg) UMOE_SZ(umoe_layer_weights) UMOE_SZ(umoe_decode_io)
+#undef UMOE_SZ
+    return 0;
+}
 
 
 // ------------------------------------------------------------------------------------ rmsnorm
