@@ -62,7 +62,7 @@ def test_no_mfma_is_predicated_through_exec(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not found")
     procs = []
-    for f in ("umoe_gemm", "umoe_tgemm", "umoe_attn", "umoe_attn_bwd"):
+    for f in ("umoe_gemm", "umoe_moe_flat", "umoe_tgemm", "umoe_attn", "umoe_attn_bwd"):
         out = str(tmp_path / (f + ".s"))
         procs.append((f, out, subprocess.Popen([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
                                                 "--offload-arch=gfx950", "-I" + os.path.join(root, "include"), "-I" + csrc, "--cuda-device-only", "-S",

@@ -1,0 +1,62 @@
+"""CPU suite: the static schedule of the flat expert launch (unimoe_audio_amd/csrc/umoe_moe_flat.hip, host side only -- no kernel runs).
+
+The launch hands rows between workgroups of ONE launch, so the table must be exact: every gate/up pair and every down block covered
+once, every down slice's producers known, every workgroup within the register variants the kernel has, riders first."""
+import ctypes as C
+
+import pytest
+
+from unimoe_audio_amd import _lib
+
+
+def plan(n_wg, S=16, D=2048, Id=2752, Is=1376, n_real=8, n_fix=2):
+    L = C.CDLL(_lib.build())
+    L.umoe_moe_flat_plan_probe.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double), C.c_int]
+    out = (C.c_double * (3 + 9 * n_wg))()
+    assert L.umoe_moe_flat_plan_probe(n_wg, S, D, Id, Is, n_real, n_fix, out, len(out)) == 0
+    rows = [[int(v) for v in out[3 + 9 * j: 12 + 9 * j]] for j in range(n_wg)]
+    return bool(out[0]), out[1], out[2], rows
+
+
+@pytest.mark.parametrize("n_wg,S", [(256, 16), (256, 2), (256, 10), (248, 16), (240, 16), (224, 16)])
+def test_plan_covers_every_pair_and_block_exactly_once(n_wg, S):
+    ok, makespan, mean, rows = plan(n_wg, S)
+    assert ok
+    Id, Is, D = 2752, 1376, 2048
+    pairs = [Is // 16] * 2 + [Id // 16] * 8                      # engine order of the hand-off launch: shared experts first
+    P = sum(pairs)
+    nxt = 0
+    for j, r in enumerate(rows):
+        fp0, npj, tok = r[0], r[1], r[2]
+        assert fp0 == nxt and 4 <= npj <= 7                       # contiguous flat slices, within the kernel's variants
+        assert tok == (j + 1 if j < S else 0)                     # the riders are the first S workgroups, token j
+        nxt += npj
+    assert nxt == P
+    cover = {g: [] for g in range(10)}
+    for r in rows:
+        seen_none = False
+        for k in range(2):
+            g, nb0, nd = r[3 + 3 * k: 6 + 3 * k]
+            if nd == 0:
+                seen_none = True
+                continue
+            assert not seen_none                                   # slices are packed: no second slice without a first
+            assert nd <= (10 if g < 2 else 6)                      # odd k-step count (shared): 1-step variants up to 10; else up to 6
+            cover[g].append((nb0, nd))
+    for g, sl in cover.items():
+        at = 0
+        for nb0, nd in sorted(sl):
+            assert nb0 == at
+            at += nd
+        assert at == D // 16
+    # balance: the heaviest workgroup carries at most 8 % more bytes than the mean (the box grid of round 2: 1412 of 1161 KiB = +22 %)
+    kib = [r[1] * 128 + sum(r[5 + 3 * k] * (43 if r[3 + 3 * k] < 2 else 86) for k in range(2)) for r in rows]
+    assert sum(kib) == P * 128 + 2 * 128 * 43 + 8 * 128 * 86
+    if n_wg == 256:
+        assert max(kib) <= 1.08 * sum(kib) / n_wg, (max(kib), sum(kib) / n_wg)
+    assert makespan >= mean
+
+
+def test_no_plan_when_the_device_is_too_small_for_seven_pairs_per_workgroup():
+    ok, *_ = plan(200)
+    assert not ok                                                   # 1548 pairs / 200 > 7: the engine falls back to launch-per-kernel

@@ -507,3 +507,39 @@ def test_router_riding_in_the_gate_up_launch_is_bit_identical(dev, monkeypatch):
         if o[2] is not None and outs[0][2] is not None:
             for a, b in zip(o[2], outs[0][2]):
                 assert torch.equal(a.cpu(), b.cpu())
+
+
+def test_flat_expert_launch_is_bit_identical_and_respects_the_cu_count(dev, monkeypatch):
+    """The byte-balanced flat expert launch (umoe_moe_flat.hip: one workgroup per CU, static schedule, riders inside, two down slices)
+    against the box-grid launch of round 2 (UMOE_FLAT_MOE=0), on a device that claims 240 CUs (another schedule, 240 workgroups) and
+    on one that claims 200 (no schedule, and the 250-workgroup box would not be resident either: the engine must take the
+    launch-per-kernel path by itself instead of timing out in a hand-off): identical codes and router integers everywhere."""
+    from unimoe_audio_amd.codec_utils import DecoderOutput, prepare_audio_prompt
+    cfg = small_cfg(hidden_size=2048, num_attention_heads=16, num_key_value_heads=2, num_hidden_layers=2,
+                    dynamic_intermediate_size=2752, shared_intermediate_size=1376)
+    B, T, max_tokens = 8, 12, 10
+    ids, am, codec = prompt(cfg, B, T, 4, [1] + [0] * (2 * B - 1))
+    pre, psteps = prepare_audio_prompt(cfg, [None] * B)
+    outs = []
+    for flat, cus in (("1", None), ("0", None), ("1", "240"), ("1", "200"), ("1", "100")):
+        monkeypatch.setenv("UMOE_FLAT_MOE", flat)
+        if cus is None:
+            monkeypatch.delenv("UMOE_FAKE_CUS", raising=False)
+        else:
+            monkeypatch.setenv("UMOE_FAKE_CUS", cus)
+        m, _ = build(cfg, 31, 0.03)
+        m = m.to(dev)
+        dec = DecoderOutput(pre.clone(), psteps, dev)
+        codes, lengths = m.generate(ids, am, dec, max_tokens, 4, codec_input_ids=codec, cfg_scale=2.0, do_sample=True, temperature=1.0,
+                                    top_p=0.9, eos_prob_mul_factor=0.8, seed=3)
+        eng = m._engine
+        assert eng.handoff_error() == 0
+        stats = eng.router_stats() if hasattr(eng, "router_stats") else None
+        outs.append((codes.cpu(), lengths.cpu(), stats))
+        del m
+        torch.cuda.empty_cache()
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+        if o[2] is not None and outs[0][2] is not None:
+            for a, b in zip(o[2], outs[0][2]):
+                assert torch.equal(a.cpu(), b.cpu())

@@ -228,6 +228,11 @@ struct umoe_rider_pub {
 // with nt 6, dn->a == gu->out; `flags`: device words, one per gate/up workgroup of the launch box (>= num_groups * ceil(max pairs / 7)).
 // Returns 1 (nothing launched) when the shapes do not allow the fusion: the caller then issues the two launches.
 int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* flags, int flag_words, hipStream_t s);
+// The same two GEMMs as ONE workgroup per CU with a static, byte-balanced schedule (umoe_moe_flat.hip): `n_wg` workgroups (<= the
+// device's CU count: every workgroup must be resident), the riders are the first S of them.  `gu` / `dn` as for umoe_moe_fused (any
+// nt); `flags`: >= n_wg device words.  Returns 1 (nothing launched) when the shapes or n_wg do not allow a schedule.
+int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* flags, int flag_words, int n_wg, hipStream_t s);
+bool umoe_moe_flat_feasible(int n_wg, int S, int D, int I_dyn, int I_sh, int n_real, int n_fix);
 
 // A small decode GEMM with row riders in front (umoe_gemm.hip wstream_gemm_rk, umoe_riders_dev.h; decode engine only).  kind 2: the
 // MoE combine of the previous layer rides in the QKV launch; kind 3: the attention split merge rides in the o_proj launch.

@@ -92,6 +92,9 @@ struct umoe_engine {
     int dense_min_rows = 2;      // UMOE_DENSE_MIN_ROWS: fewest decode rows that take the dense-expert layout (below: ragged dispatch).  Batch 1
                                  // (2 CFG rows, BASELINE configs[0]) hits 5-6 of the 8 experts: streaming all 8 in the fused launches costs
                                  // fewer microseconds than the ragged path's four extra launches -- 2.91 vs 3.33 ms/step
+    int n_cu = 0;                // compute units of the device (UMOE_FAKE_CUS overrides: tests of the co-residency guards)
+    bool flat_moe = true;        // UMOE_FLAT_MOE: both expert GEMMs as ONE workgroup per CU with a byte-balanced static schedule
+                                 // (umoe_moe_flat.hip); 0 / shapes that do not fit: the box-grid launch below
     bool fuse_moe = true;        // UMOE_FUSE_MOE: gate/up and down projections of a dense decode layer in ONE launch (umoe_moe_fused)
     bool gu_norm = false;        // UMOE_GU_NORM: the gate/up workgroups normalise x1 in their staging prologue (no hand-off, no norm launch)
     bool rider_pub = true;       // UMOE_RIDER_PUB: the riders also produce the normalised rows and hand them to the GEMM workgroups of the
@@ -342,6 +345,12 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
         umoe_engine_destroy(e);
         return -2;
     }
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) e->n_cu = cus;
+        if (const char* v = getenv("UMOE_FAKE_CUS")) e->n_cu = atoi(v);
+    }
+    if (const char* v = getenv("UMOE_FLAT_MOE")) e->flat_moe = atoi(v) != 0;
     if (const char* v = getenv("UMOE_OVERLAP_SHARED")) e->overlap_shared = atoi(v) != 0;
     if (const char* v = getenv("UMOE_DENSE_EXPERTS")) e->dense_experts = atoi(v) != 0;
     if (const char* v = getenv("UMOE_TILED_PREFILL")) e->tiled_prefill = atoi(v) != 0;
@@ -821,7 +830,14 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // gu_norm: the gate/up workgroups normalise x1 themselves in their staging prologue (the router body's summation tree: the same
     // bits), so that launch waits for nobody -- no norm launch, no hand-off
     const bool gu_norm = fuse_router && e->gu_norm && D == 2048;
-    const bool pub_riders = fuse_router && e->rider_pub && !gu_norm;
+    // In-launch hand-offs need every workgroup of the launch RESIDENT at once (a waiting workgroup never yields its CU): the gate/up box
+    // of 8-wave, 256-register workgroups admits ONE per CU, the flat launch is sized to the CU count itself.  A device that exposes
+    // fewer CUs (partition, CU mask) takes the launch-per-kernel path instead of discovering it by a timeout.
+    const int gu_box = G * ceil_div(2 * Imax / 16, 14);
+    const bool box_fits = e->n_cu <= 0 || gu_box <= e->n_cu;
+    const bool flat_ok = dense && e->flat_moe && e->fuse_moe && e->n_cu > 0 && c.n_dyn == 9 && c.n_fix == 2 &&
+                         umoe_moe_flat_feasible(e->n_cu < 256 ? e->n_cu : 256, n_tok, D, c.inter_dyn, c.inter_shared, c.n_real, c.n_fix);
+    const bool pub_riders = fuse_router && e->rider_pub && !gu_norm && (box_fits || flat_ok);
     // fused expert launch, second hand-off form: the riders hand over the rows' SCALES only ({rs, epoch} granules); the GEMM
     // workgroups load the raw rows x1 at launch and finish the norm themselves
     const bool rs_handoff = pub_riders && e->fuse_moe && e->rs_handoff && D == 2048 && !tiled;
@@ -920,7 +936,15 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     } else if (pub_riders && e->fuse_moe) {
         // both expert GEMMs in one launch (words 64.. of ep_words: one flag per gate/up workgroup); shapes that do not allow it
         // fall back to the two launches
-        rc = umoe_moe_fused(&gu, &dn, e->ep_words + 64, 512 - 64, s);
+        rc = 1;
+        {
+            const char* fv = getenv("UMOE_FLAT_MOE");      // (read per enqueue: the step graph captures the choice; A/B scripts toggle it)
+            const bool flat = fv ? atoi(fv) != 0 : e->flat_moe;
+            const int n_wg = e->n_cu < 256 ? e->n_cu : 256;
+            if (flat && !rs_handoff && n_wg > 0) rc = umoe_moe_flat(&gu, &dn, e->ep_words + 64, 512 - 64, n_wg, s);
+        }
+        if (rc == 1 && box_fits) rc = umoe_moe_fused(&gu, &dn, e->ep_words + 64, 512 - 64, s);
+        UMOE_REQUIRE(!(rc == 1 && !box_fits), "umoe_engine: no expert launch with in-launch hand-offs fits %d compute units (UMOE_RIDER_PUB=0 selects the launch-per-kernel path)", e->n_cu);
         UMOE_REQUIRE(!(rc == 1 && rs_handoff), "umoe_engine: the fused expert launch refused the shapes it was configured for (UMOE_RS_HANDOFF=0 selects the other form)");
         if (rc == 1) {
             if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
@@ -942,7 +966,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
     // fused RMSNorm for the consumer of x: the next layer's input_layernorm, or the final norm in front of the head
     cb.norm_w = (l + 1 < c.layers) ? e->layers[l + 1].w.in_norm : e->final_norm; cb.norm_out = e->hin; cb.rms_eps = c.rms_eps;
-    if (dense && T == 1 && !tiled && e->fuse_cq && e->rider_pub && l + 1 < c.layers && D == 2048 && n_tok <= 16 && c.n_fix >= 1) {
+    const bool cq_fits = e->n_cu <= 0 || n_tok + QKV / 16 <= 2 * e->n_cu;      // riders + QKV tiles resident at once (two 4-wave workgroups per CU)
+    if (dense && T == 1 && !tiled && e->fuse_cq && e->rider_pub && cq_fits && l + 1 < c.layers && D == 2048 && n_tok <= 16 && c.n_fix >= 1) {
         e->cb_stash = cb;        // issued by the next layer's QKV launch (run_layer(l + 1) follows immediately)
         e->cb_pending = true;
         return 0;
