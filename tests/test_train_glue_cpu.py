@@ -119,3 +119,24 @@ def test_weight_transpose_cache_rule_is_version_keyed(monkeypatch):
     assert ops._cached_weight_transposes(ws, D, I) is None
     again = ops._cached_weight_transposes(ws, D, I)
     assert again is not None and torch.equal(again[0][1], ws[1][2].t())
+
+
+def test_weight_transpose_cache_gives_the_copies_back_when_the_parameters_die():
+    """An entry lives as long as the tensors it describes (the module-level cache never evicted -- a deleted model kept
+    10 GB of transposed copies): deleting the weights drops the entry, and clear_weight_transpose_cache() empties it on demand."""
+    import gc
+    import torch
+    from unimoe_audio_amd import ops
+    ops.clear_weight_transpose_cache()
+    D, I = 16, 8
+    ws = [(torch.randn(I, D).to(torch.bfloat16), torch.randn(I, D).to(torch.bfloat16), torch.randn(D, I).to(torch.bfloat16))]
+    assert ops._cached_weight_transposes(ws, D, I) is None and ops._cached_weight_transposes(ws, D, I) is not None
+    assert len(ops._WT_CACHE) == 1
+    other = [(torch.randn(I, D).to(torch.bfloat16), torch.randn(I, D).to(torch.bfloat16), torch.randn(D, I).to(torch.bfloat16))]
+    ops._cached_weight_transposes(other, D, I)
+    assert len(ops._WT_CACHE) == 2
+    del ws
+    gc.collect()
+    assert len(ops._WT_CACHE) == 1                     # the dead model's entry (and its copies) are gone
+    ops.clear_weight_transpose_cache()
+    assert len(ops._WT_CACHE) == 0

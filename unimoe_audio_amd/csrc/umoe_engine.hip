@@ -978,6 +978,14 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
 }
 
 // ------------------------------------------------------------------------------------ prefill
+// The in-launch hand-offs derive their epoch from the step word (ep_words[0]), which only step_prep_kernel advances.  A prefill whose
+// token count equals the decode rows (T == 1) takes the same rider / fused paths as a decode step: it gets an epoch of its own, or
+// its waiters would pass at once on the flags of the last decode step of a re-used engine.  Every expert-parallel rank prefills, so
+// the ranks' counters stay equal.
+__global__ void epoch_bump_kernel(uint32_t* ep_step) {
+    if (threadIdx.x == 0) ep_step[0] += 1u;
+}
+
 extern "C" int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T,
                                    umoe_stream_t stream) {
     return umoe_engine_prefill_pos(e, x, valid_host, T, nullptr, nullptr, stream);
@@ -1029,6 +1037,8 @@ extern "C" int umoe_engine_prefill_pos(umoe_engine* e, const uint16_t* x, const 
     if ((rc = umoe_rmsnorm_residual_fwd(e->x, nullptr, e->layers[0].w.in_norm, c.rms_eps, n_tok, c.hidden, nullptr, e->hin, s)))
         return rc;
     e->cb_pending = false;
+    epoch_bump_kernel<<<1, 64, 0, s>>>(e->ep_words);
+    UMOE_LAUNCH_CHECK();
     for (int l = 0; l < c.layers; ++l)
         if ((rc = run_layer(e, l, n_tok, T, 1, s))) return rc;
     e->T_prompt = T;

@@ -266,9 +266,13 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
             for (unsigned spins = 0;; ++spins) {
                 if ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0) break;
                 __builtin_amdgcn_s_sleep(1);
-                if ((spins & 1023u) == 1023u && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 200000000ull)) {
-                    __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                if ((spins & 1023u) == 1023u) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;      // an earlier cause (kept) ends every wait
+                    if (wall_clock64() - t0 > 200000000ull) {      // this lane's OWN timeout: first cause wins
+                        uint32_t zero = 0u;
+                        __hip_atomic_compare_exchange_strong(err, &zero, 3u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
             }
         }
@@ -287,9 +291,13 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
             for (unsigned spins = 0;; ++spins) {
                 if ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0) break;
                 __builtin_amdgcn_s_sleep(1);
-                if ((spins & 1023u) == 1023u && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 200000000ull)) {
-                    __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                if ((spins & 1023u) == 1023u) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;      // an earlier cause (kept) ends every wait
+                    if (wall_clock64() - t0 > 200000000ull) {      // this lane's OWN timeout: first cause wins
+                        uint32_t zero = 0u;
+                        __hip_atomic_compare_exchange_strong(err, &zero, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
             }
         }
@@ -376,9 +384,13 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
                     gr = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (valid ? r : row0) * 8, 0, 16);
                     if ((int32_t)(gr[1] - epoch) >= 0) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if ((spins & 1023u) == 1023u && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || wall_clock64() - t0 > 200000000ull)) {
-                        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
+                    if ((spins & 1023u) == 1023u) {
+                        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;      // an earlier cause (kept) ends every wait
+                        if (wall_clock64() - t0 > 200000000ull) {      // this lane's OWN timeout: first cause wins
+                            uint32_t zero = 0u;
+                            __hip_atomic_compare_exchange_strong(err, &zero, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
                     }
                 }
                 rs = __int_as_float((int)gr[0]);

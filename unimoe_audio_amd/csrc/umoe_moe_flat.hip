@@ -37,6 +37,7 @@ struct flat_args {
     uint16_t* h;                        // silu(g)*u rows [.][ldh]: written by the gate/up phase, read by the down phase of this launch
     uint16_t* y;                        // down-projection outputs [.][ldy]
     uint32_t* flags;                    // one word per workgroup: its gate/up slice is published
+    unsigned long long* dbg;            // diagnostics only (NULL otherwise; UMOE_FLAT_STAMPS=1): [workgroup][16] wall-clock stamps (100 MHz)
     int lda, ldh, ldy;
     int S, G, kb_gu;                    // rows (<= 16), groups, k-steps (K / 32) of the gate/up GEMMs
     const uint16_t* w_gu[FLAT_MAXG];    // WP16 gate/up weights (blocks interleaved) per group
@@ -79,13 +80,23 @@ __device__ __forceinline__ void flat_wait(uint32_t* flag, uint32_t epoch, uint32
     }
 }
 
+// diagnostics: thread 0 keeps up to 16 stamps in registers and stores them at exit (scalar branch on a kernel argument)
+// (the instrumented build only -- make tl, scripts/flat_timeline.py; the product kernel carries no stamp)
+#ifdef UMOE_TIMELINE
+struct flat_stamps { unsigned long long t[16]; };
+#define FSTAMP(k) do { if (A.dbg) st.t[k] = wall_clock64(); } while (0)
+#else
+struct flat_stamps {};
+#define FSTAMP(k) do { } while (0)
+#endif
+
 typedef uint32_t flat_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t flat_u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- gate/up SwiGLU slice: NP pairs of the flat list starting at fp0 (arithmetic of wstream_body<14, 1, PLAIN, SWIGLU, 8> per tile) ----
 template <int NP>
 __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider_pub& pub, const uint32_t epoch, const int fp0, const unsigned b,
-                                            char* smem) {
+                                            char* smem, flat_stamps& st) {
     constexpr int NT = 2 * NP, WV = 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: every guard around an MFMA is a scalar branch
@@ -115,9 +126,11 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
     };
     // weights first: the rows do not exist yet (the riders of this launch write them)
     if (i0 < i1) load_chunk(w0, i0);
+    FSTAMP(1);
     const int count = A.S;
     if (tid < count) flat_wait(pub.flags + (b % UMOE_FLAG_REPL) * 16 + tid, epoch, pub.err, 2u);
     __syncthreads();
+    FSTAMP(2);
     // ---- stage the 16-row tile: every load of a thread in flight before its first LDS write; every load an sc1 load ----
     {
         constexpr int TPR = WV * 4;      // threads per row
@@ -142,6 +155,7 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
         }
     }
     __syncthreads();
+    FSTAMP(3);
     // ---- stream: 1-step chunks, double-buffered in registers, the 8 waves split K ----
     const int h = lane >> 4, mm = lane & 15;
     const char* bbase = smem + mm * RS;
@@ -160,7 +174,9 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
         if (i + 1 < i1) compute_chunk(w1, i + 1);
     }
     // ---- fixed-order cross-wave reduction through the (now free) staging area ----
+    FSTAMP(4);
     __syncthreads();
+    FSTAMP(5);
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
 #pragma unroll
     for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[t];
@@ -198,13 +214,15 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
     __syncthreads();
     if (tid == 0)
         __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(A.flags + b)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FSTAMP(6);
 }
 
 // ---- down-projection slice: blocks [nb0, nb0 + ND) of group grp (arithmetic of wstream_body<6, 2, PLAIN, BF16, 8> per tile) ----
 // U = 2 for an even number of k-steps (whole 2-step chunks per wave), U = 1 for an odd one: the K split of the 2-step launch does not
 // depend on U then, and a 1-step stream has no clamped duplicate step at the end of a wave's slice.
 template <int ND, int U>
-__device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_pub& pub, const uint32_t epoch, const int grp, const int nb0, char* smem) {
+__device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_pub& pub, const uint32_t epoch, const int grp, const int nb0, char* smem,
+                                          flat_stamps& st, const int sb) {
     constexpr int NT = ND, WV = 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -242,6 +260,7 @@ __device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_p
     // wait for the workgroups of THIS launch that produced this group's rows: lane i of wave 0 polls producer i (bounded)
     if (tid < A.prod_n[grp]) flat_wait(A.flags + A.prod_base[grp] + tid, epoch, pub.err, 3u);
     __syncthreads();
+    FSTAMP(sb);
     {
         constexpr int TPR = WV * 4;
         const int m = tid / TPR, sub = tid % TPR;
@@ -270,6 +289,7 @@ __device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_p
         }
     }
     __syncthreads();
+    FSTAMP(sb + 1);
     const int h = lane >> 4, mm = lane & 15;
     const char* bbase = smem + mm * RS;
     auto compute_chunk = [&](const flat_u32x4 (&src)[NT][U], int ibase) {
@@ -291,7 +311,9 @@ __device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_p
         if (i + 2 * U < i1) load_chunk(w0, i + 2 * U);
         if (i + U < i1) compute_chunk(w1, i + U);
     }
+    FSTAMP(sb + 2);
     __syncthreads();
+    FSTAMP(sb + 3);
     f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
 #pragma unroll
     for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[t];
@@ -321,6 +343,14 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
     const unsigned b = blockIdx.x;
     const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
     const unsigned eg = A.gu[b], ed = A.dn[b];
+    flat_stamps st;
+#ifdef UMOE_TIMELINE
+    if (A.dbg) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) st.t[k] = 0;
+        st.t[0] = wall_clock64();
+    }
+#endif
     const int token = (int)(eg >> 16) - 1;
     if (token >= 0) {
         // rider: RMSNorm of row `token` -> write-through store -> flag; then wave 0 alone walks the Top-P chain while the other waves already
@@ -339,41 +369,48 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
     }
     const int fp0 = (int)(eg & 2047u), np = (int)((eg >> 11) & 7u);
     switch (np) {
-        case 4: flat_gateup<4>(A, pub, epoch, fp0, b, smem); break;
-        case 5: flat_gateup<5>(A, pub, epoch, fp0, b, smem); break;
-        case 6: flat_gateup<6>(A, pub, epoch, fp0, b, smem); break;
-        case 7: flat_gateup<7>(A, pub, epoch, fp0, b, smem); break;
+        case 4: flat_gateup<4>(A, pub, epoch, fp0, b, smem, st); break;
+        case 5: flat_gateup<5>(A, pub, epoch, fp0, b, smem, st); break;
+        case 6: flat_gateup<6>(A, pub, epoch, fp0, b, smem, st); break;
+        case 7: flat_gateup<7>(A, pub, epoch, fp0, b, smem, st); break;
         default: break;
     }
     for (int sl = 0; sl < FLAT_SLICES; ++sl) {
         const unsigned e16 = (ed >> (16 * sl)) & 0xffffu;
         const int nd = (int)(e16 >> 12), grp = (int)(e16 & 15u), nb0 = (int)((e16 >> 4) & 255u);
-        if (nd == 0) return;
+        if (nd == 0) break;
         __syncthreads();     // (the reduction slab of the previous GEMM is the staging area of this one)
         if (A.dn_kb[grp] & 1) {
             switch (nd) {
-                case 1: flat_down<1, 1>(A, pub, epoch, grp, nb0, smem); break;
-                case 2: flat_down<2, 1>(A, pub, epoch, grp, nb0, smem); break;
-                case 3: flat_down<3, 1>(A, pub, epoch, grp, nb0, smem); break;
-                case 4: flat_down<4, 1>(A, pub, epoch, grp, nb0, smem); break;
-                case 5: flat_down<5, 1>(A, pub, epoch, grp, nb0, smem); break;
-                case 6: flat_down<6, 1>(A, pub, epoch, grp, nb0, smem); break;
-                case 7: flat_down<7, 1>(A, pub, epoch, grp, nb0, smem); break;
-                case 8: flat_down<8, 1>(A, pub, epoch, grp, nb0, smem); break;
-                case 9: flat_down<9, 1>(A, pub, epoch, grp, nb0, smem); break;
-                default: flat_down<10, 1>(A, pub, epoch, grp, nb0, smem); break;
+                case 1: flat_down<1, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 2: flat_down<2, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 3: flat_down<3, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 4: flat_down<4, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 5: flat_down<5, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 6: flat_down<6, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 7: flat_down<7, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 8: flat_down<8, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 9: flat_down<9, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                default: flat_down<10, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
             }
         } else {
             switch (nd) {
-                case 1: flat_down<1, 2>(A, pub, epoch, grp, nb0, smem); break;
-                case 2: flat_down<2, 2>(A, pub, epoch, grp, nb0, smem); break;
-                case 3: flat_down<3, 2>(A, pub, epoch, grp, nb0, smem); break;
-                case 4: flat_down<4, 2>(A, pub, epoch, grp, nb0, smem); break;
-                case 5: flat_down<5, 2>(A, pub, epoch, grp, nb0, smem); break;
-                default: flat_down<6, 2>(A, pub, epoch, grp, nb0, smem); break;
+                case 1: flat_down<1, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 2: flat_down<2, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 3: flat_down<3, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 4: flat_down<4, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 5: flat_down<5, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                default: flat_down<6, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
             }
         }
     }
+#ifdef UMOE_TIMELINE
+    if (A.dbg && threadIdx.x == 0) {
+        st.t[15] = wall_clock64();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) A.dbg[(size_t)b * 16 + k] = st.t[k];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ host: the static schedule
@@ -528,6 +565,16 @@ static void flat_plan(const FlatShape& sh, FlatPlan& out) {
 }
 
 extern "C" int umoe_moe_flat_plan_probe(int n_wg, int S, int D, int I_dyn, int I_sh, int n_real, int n_fix, double* out, int out_len);
+static unsigned long long* g_flat_dbg = nullptr;
+// diagnostics: copy the stamps of the last stamped launch to the host ([256][16] u64); -1 when none was taken
+extern "C" int umoe_moe_flat_stamps(unsigned long long* host_out) {
+    if (!host_out) {       // enable (outside any stream capture): later launches of the instrumented build write their stamps
+        if (!g_flat_dbg && hipMalloc(&g_flat_dbg, sizeof(unsigned long long) * 16 * FLAT_MAXWG) != hipSuccess) return -2;
+        return hipMemset(g_flat_dbg, 0, sizeof(unsigned long long) * 16 * FLAT_MAXWG) == hipSuccess ? 0 : -2;
+    }
+    if (!g_flat_dbg) return -1;
+    return hipMemcpy(host_out, g_flat_dbg, sizeof(unsigned long long) * 16 * FLAT_MAXWG, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
 static double flat_env(const char* name, double dflt) {
     const char* v = getenv(name);
     return v ? atof(v) : dflt;
@@ -595,6 +642,7 @@ int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* 
     flat_args A;
     memset(&A, 0, sizeof(A));
     A.a = gu->a; A.h = reinterpret_cast<uint16_t*>(gu->out); A.y = reinterpret_cast<uint16_t*>(dn->out); A.flags = flags;
+    A.dbg = g_flat_dbg;      // diagnostics (scripts/flat_timeline.py; NULL unless umoe_moe_flat_stamps(NULL) enabled them): stamps of the LAST launch
     A.lda = gu->lda; A.ldh = gu->ldo; A.ldy = dn->ldo; A.S = r->S; A.G = G; A.kb_gu = sh.kb_gu;
     int P = 0, kb_dn_max = 0;
     for (int i = 0; i < G; ++i) {

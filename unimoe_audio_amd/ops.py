@@ -557,6 +557,29 @@ def _wt_cache_on() -> bool:
     return os.environ.get("UMOE_WT_CACHE", "1") != "0"
 
 
+def clear_weight_transpose_cache() -> None:
+    """Drops every kept transposed weight copy (they come back on the second backward over unchanged parameters)."""
+    _WT_CACHE.clear()
+
+
+def _wt_cache_put(key, ver, tensors) -> None:
+    """New (empty) entry.  An entry lives exactly as long as the parameters it describes: each tensor's finalizer drops it, so a
+    deleted model gives its transposed copies back; a sweep on insert removes entries whose tensors are gone already."""
+    import weakref
+    for k in [k for k, e in _WT_CACHE.items() if any(r() is None for r in e["refs"])]:
+        _WT_CACHE.pop(k, None)
+    ent = dict(ver=ver, t=None, refs=[weakref.ref(t) for t in tensors])
+    _WT_CACHE[key] = ent
+
+    def _drop(key=key, ent_id=id(ent)):
+        cur = _WT_CACHE.get(key)
+        if cur is not None and id(cur) == ent_id:
+            _WT_CACHE.pop(key, None)
+
+    for t in tensors:
+        weakref.finalize(t, _drop)
+
+
 def _cached_weight_transposes(ws_list, D: int, I: int):
     if not _wt_cache_on():
         return None
@@ -578,7 +601,7 @@ def _cached_weight_transposes(ws_list, D: int, I: int):
                 wguT[g, :, I:] = wu.detach().t()
             ent["t"] = (wdT, wguT)
         return ent["t"]
-    _WT_CACHE[key] = dict(ver=ver, t=None, refs=[weakref.ref(t) for w in ws_list for t in w])
+    _wt_cache_put(key, ver, [t for w in ws_list for t in w])
     return None
 
 
@@ -594,7 +617,7 @@ def transpose_weight_cached(w: torch.Tensor) -> torch.Tensor:
         if ent["t"] is None:
             ent["t"] = transpose(w.detach())
         return ent["t"]
-    _WT_CACHE[key] = dict(ver=ver, t=None, refs=[weakref.ref(w)])
+    _wt_cache_put(key, ver, [w])
     return transpose(w)
 
 
