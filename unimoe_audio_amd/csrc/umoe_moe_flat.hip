@@ -11,7 +11,8 @@
 // computes once (flat_plan): the slices are sized so that every workgroup ends at the same time under a small timing model that knows
 // that a down slice can start only when ALL producers of its expert's rows have published (the "seam" of that expert).
 // The router riders (one token each: RMSNorm + gate GEMV + Top-P chain, umoe_router_dev.h) are the first S workgroups themselves:
-// they publish their row, then take a (lighter) slice like everybody else -- no extra workgroups, all n_wg are resident at once.
+// they route their row, then take a (lighter) slice like everybody else -- no extra workgroups, all n_wg are resident at once.  Nobody
+// waits for them: every workgroup normalises the 16 rows itself while its first weight chunk is in flight (flat_gateup).
 //
 // Hand-offs as in moe_fused_kernel (cdna_hip_programming.md Guideline 16 R1): write-through payload, every storing wave drains, one
 // flag per part, relaxed agent-scope poll (bounded, sticky error word), every load of handed-over bytes an sc1 load.
@@ -33,16 +34,19 @@
 #define FLAT_SLICES 2       // down slices per workgroup
 
 struct flat_args {
-    const uint16_t* a;                  // normalised rows [S][lda]: written by the riders of THIS launch
+    // (what the first weight request needs sits at the front: one batch of kernel-argument loads)
+    const uint16_t* a;                  // raw rows x1 [S][lda] (the residual stream after attention); every workgroup normalises them itself
+    const uint16_t* norm_w;             // post-attention RMSNorm weights [D]
+    float rms_eps;
+    int lda, S, G;                      // row stride, rows (<= 16), groups
+    int pair0[FLAT_MAXG + 1];           // first flat pair of gate/up group i (pair0[G] = all pairs)
+    const uint16_t* w_gu[FLAT_MAXG];    // WP16 gate/up weights (blocks interleaved) per group
     uint16_t* h;                        // silu(g)*u rows [.][ldh]: written by the gate/up phase, read by the down phase of this launch
     uint16_t* y;                        // down-projection outputs [.][ldy]
     uint32_t* flags;                    // one word per workgroup: its gate/up slice is published
-    unsigned long long* dbg;            // diagnostics only (NULL otherwise; UMOE_FLAT_STAMPS=1): [workgroup][16] wall-clock stamps (100 MHz)
-    int lda, ldh, ldy;
-    int S, G, kb_gu;                    // rows (<= 16), groups, k-steps (K / 32) of the gate/up GEMMs
-    const uint16_t* w_gu[FLAT_MAXG];    // WP16 gate/up weights (blocks interleaved) per group
+    unsigned long long* dbg;            // diagnostics only (NULL otherwise): [workgroup][16] wall-clock stamps (100 MHz)
+    int ldh, ldy, kb_gu;                // k-steps (K / 32) of the gate/up GEMMs (64: see flat_gateup)
     const uint16_t* w_dn[FLAT_MAXG];    // WP16 down weights per group
-    int pair0[FLAT_MAXG + 1];           // first flat pair of gate/up group i (pair0[G] = all pairs)
     int h_row[FLAT_MAXG];               // gate/up group i writes rows h_row[i] + r of h
     int dn_kb[FLAT_MAXG];               // k-steps of down group i
     int dn_a_row[FLAT_MAXG];            // down group i reads rows dn_a_row[i] + r of h ...
@@ -52,8 +56,7 @@ struct flat_args {
     int prod_n[FLAT_MAXG];
     uint32_t gu[FLAT_MAXWG];            // per workgroup: first flat pair | pairs << 11 | (rider token + 1) << 16 (0: not a rider)
     uint32_t dn[FLAT_MAXWG];            // per workgroup: TWO down slices, 16 bits each (low half first): group | first block << 4 | blocks << 12
-};                                      //   with blocks 0 = none, 1..14 = that many, 15 = sixteen ... (see FLAT_ND_*); first block < 256
-
+};                                      //   (blocks 0 = no slice; see FLAT_ND_*)
 
 __device__ __forceinline__ int flat_lds_chunk_off(int QS, int h, int i, int m) {
     // 16-byte chunk i of K-quarter h, row m: 256-byte segments, slot rotated by the row index (umoe_gemm.hip lds_chunk_off)
@@ -94,29 +97,42 @@ typedef uint32_t flat_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t flat_u32x2 __attribute__((ext_vector_type(2)));
 
 // ---- gate/up SwiGLU slice: NP pairs of the flat list starting at fp0 (arithmetic of wstream_body<14, 1, PLAIN, SWIGLU, 8> per tile) ----
+// The workgroup normalises the 16 rows ITSELF while it stages them (post-attention RMSNorm, model.py:240): the raw rows exist when the
+// launch starts, so nothing is waited for -- rows requested first, the weight stream right behind them, and the ~2 us of row arithmetic
+// hide under the first chunk's flight.  The sum of squares follows the router body's tree (umoe_router_dev.h router4_body: lane l of wave
+// h sums the 8 squares of chunk 64 h + l, xor-butterfly 32 .. 1, the four wave sums added in order), so the rows are bit-identical to
+// the rows the router launches write.  K = 2048 only (one staging round, thread (row m, sub) holds chunks sub and sub + 32 of a quarter).
+__device__ __forceinline__ uint32_t flat_epoch(const umoe_rider_pub& pub) {
+    // the step word lives in device memory: read it where it is first needed (a load the compiler may not hoist in front of the
+    // kernel's first weight request -- it was one more dependent scalar round trip there)
+    asm volatile("" ::: "memory");
+    return __builtin_nontemporal_load(pub.step) * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
+}
+
 template <int NP>
-__device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider_pub& pub, const uint32_t epoch, const int fp0, const unsigned b,
-                                            char* smem, flat_stamps& st) {
-    constexpr int NT = 2 * NP, WV = 8;
+__device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider_pub& pub, const int fp0, const unsigned b, char* smem, flat_stamps& st) {
+    constexpr int NT = 2 * NP, WV = 8, KB = 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: every guard around an MFMA is a scalar branch
-    const int KB = A.kb_gu;
-    const int QS = (KB * 16 + 255) & ~255, RS = QS * 4;
+    constexpr int QS = (KB * 16 + 255) & ~255, RS = QS * 4;
     const int i0 = __builtin_amdgcn_readfirstlane((KB * wave) / WV), i1 = __builtin_amdgcn_readfirstlane((KB * (wave + 1)) / WV);
-    // the slice straddles at most two groups (a group has far more than 7 pairs)
+    // the slice straddles at most two groups (a group has far more than 7 pairs).  Every table read is a kernel-argument read with a
+    // compile-time offset + a scalar select: ONE batch of scalar loads in front of the first request, no dependent second one
     int g0 = 0;
-    for (int i = 1; i < A.G; ++i)
-        if (fp0 >= A.pair0[i]) g0 = i;
-    const int g1 = min(g0 + 1, A.G - 1), cut = A.pair0[g0 + 1];      // pairs >= cut belong to group g1
+#pragma unroll
+    for (int i = 1; i < FLAT_MAXG; ++i) g0 += (fp0 >= A.pair0[i] && i < A.G) ? 1 : 0;      // (pair0 ascends: the count IS the index)
+    const int p0 = A.pair0[g0], cut = A.pair0[g0 + 1];
+    const uint16_t *wg0 = A.w_gu[g0], *wg1 = A.w_gu[g0 + 1 < FLAT_MAXG ? g0 + 1 : g0];
+    const int g1 = min(g0 + 1, A.G - 1);      // pairs >= cut belong to group g1
     f32x4_t acc[NT];
     const flat_u32x4* wp[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const int pp = fp0 + (t >> 1);
-        const int grp = pp >= cut ? g1 : g0;
-        const int lp = pp - A.pair0[grp];
-        wp[t] = reinterpret_cast<const flat_u32x4*>(A.w_gu[grp]) + ((size_t)(2 * lp + (t & 1)) * KB) * 64 + lane;
+        const bool second = pp >= cut;
+        const int lp = pp - (second ? cut : p0);
+        wp[t] = reinterpret_cast<const flat_u32x4*>(second ? wg1 : wg0) + ((size_t)(2 * lp + (t & 1)) * KB) * 64 + lane;
     }
     flat_u32x4 w0[NT], w1[NT];
     auto load_chunk = [&](flat_u32x4 (&dst)[NT], int ii) {
@@ -124,34 +140,62 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
 #pragma unroll
         for (int t = 0; t < NT; ++t) dst[t] = __builtin_nontemporal_load(wp[t] + (size_t)ic * 64);
     };
-    // weights first: the rows do not exist yet (the riders of this launch write them)
-    if (i0 < i1) load_chunk(w0, i0);
-    FSTAMP(1);
     const int count = A.S;
-    if (tid < count) flat_wait(pub.flags + (b % UMOE_FLAG_REPL) * 16 + tid, epoch, pub.err, 2u);
-    __syncthreads();
-    FSTAMP(2);
-    // ---- stage the 16-row tile: every load of a thread in flight before its first LDS write; every load an sc1 load ----
+    // ---- rows first (they exist: the previous launch wrote them), then the weight stream; normalise while the chunk flies ----
     {
         constexpr int TPR = WV * 4;      // threads per row
         const int m = tid / TPR, sub = tid % TPR;
         const bool valid = m < count;
-        const int rl = valid ? m : 0;
+        const uint16_t* src = A.a + (size_t)(valid ? m : 0) * A.lda;
         char* dst = smem + m * RS;
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.a), 0, 16 * A.lda * 2, 0x00020000);
-        for (int ib0 = 0; ib0 < KB; ib0 += 4 * TPR) {
-            uint4 buf[16];
+        char* nw_lds = smem + 16 * RS;
+        uint4 buf[8];
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                const int h = n >> 2, i = min(ib0 + sub + TPR * (n & 3), KB - 1);
-                const flat_u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((long)rl * A.lda + (h * KB + i) * 8) * 2), 0, 16);
-                buf[n] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-            }
+        for (int n = 0; n < 8; ++n) buf[n] = ld16(src + ((n >> 1) * KB + sub + TPR * (n & 1)) * 8);
+        // (straight-line loads only: a branch around a load makes hipcc wait for vmcnt(0), i.e. for the weight chunk behind the rows)
+        const uint4 nw1 = ld16(A.norm_w + (tid & (4 * KB - 1)) * 8);
+        // BOTH register stages are requested here, behind the rows: nothing the prologue waits for queues behind them (a wave's loads
+        // return in issue order), and HBM has 224 KiB per CU to deliver while the rows are normalised
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(w0, i0);
+        load_chunk(w1, i0 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        FSTAMP(1);
+        st16(nw_lds + (tid & (4 * KB - 1)) * 16, nw1);      // (both halves of the workgroup store the same 4 KiB)
+        float q4[4];
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
-                if (valid && i < KB) st16(dst + flat_lds_chunk_off(QS, h, i, m), buf[n]);
+        for (int hq = 0; hq < 4; ++hq) {
+            float c2[2];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                float f[8];
+                unpack8(buf[hq * 2 + k2], f);
+                float cs = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cs += f[j] * f[j];
+                c2[k2] = cs;
             }
+            float v = c2[0] + c2[1];
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            q4[hq] = v;
+        }
+        const float ss = ((q4[0] + q4[1]) + q4[2]) + q4[3];
+        const float rs = rsqrtf(ss / (float)(KB * 32) + A.rms_eps);
+        __syncthreads();
+        FSTAMP(2);
+        // keep the row slice packed (32 registers) between the sum of squares and the scaling
+#pragma unroll
+        for (int n = 0; n < 8; ++n) asm volatile("" : "+v"(buf[n].x), "+v"(buf[n].y), "+v"(buf[n].z), "+v"(buf[n].w));
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int h = n >> 1, i = sub + TPR * (n & 1);
+            float f[8], w[8];
+            unpack8(buf[n], f);
+            unpack8(*reinterpret_cast<const uint4*>(nw_lds + (h * KB + i) * 16), w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
+            if (valid) st16(dst + flat_lds_chunk_off(QS, h, i, m), pack8(f));
         }
     }
     __syncthreads();
@@ -168,7 +212,7 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
         }
     };
     for (int i = i0; i < i1; i += 2) {
-        if (i + 1 < i1) load_chunk(w1, i + 1);
+        if (i + 1 < i1 && i != i0) load_chunk(w1, i + 1);
         compute_chunk(w0, i);
         if (i + 2 < i1) load_chunk(w0, i + 2);
         if (i + 1 < i1) compute_chunk(w1, i + 1);
@@ -213,7 +257,7 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0)
-        __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(A.flags + b)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(A.flags + b)), flat_epoch(pub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     FSTAMP(6);
 }
 
@@ -221,8 +265,8 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
 // U = 2 for an even number of k-steps (whole 2-step chunks per wave), U = 1 for an odd one: the K split of the 2-step launch does not
 // depend on U then, and a 1-step stream has no clamped duplicate step at the end of a wave's slice.
 template <int ND, int U>
-__device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_pub& pub, const uint32_t epoch, const int grp, const int nb0, char* smem,
-                                          flat_stamps& st, const int sb) {
+__device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_pub& pub, const int grp, const int nb0, char* smem, flat_stamps& st,
+                                          const int sb) {
     constexpr int NT = ND, WV = 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -258,7 +302,7 @@ __device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_p
     if (i0 < i1) load_chunk(w0, i0);
     const int count = A.S;
     // wait for the workgroups of THIS launch that produced this group's rows: lane i of wave 0 polls producer i (bounded)
-    if (tid < A.prod_n[grp]) flat_wait(A.flags + A.prod_base[grp] + tid, epoch, pub.err, 3u);
+    if (tid < A.prod_n[grp]) flat_wait(A.flags + A.prod_base[grp] + tid, flat_epoch(pub), pub.err, 3u);
     __syncthreads();
     FSTAMP(sb);
     {
@@ -341,7 +385,6 @@ __device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_p
 __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, const umoe_router_args ra, const umoe_rider_pub pub, const int lds_gemm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned b = blockIdx.x;
-    const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
     const unsigned eg = A.gu[b], ed = A.dn[b];
     flat_stamps st;
 #ifdef UMOE_TIMELINE
@@ -353,15 +396,16 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
 #endif
     const int token = (int)(eg >> 16) - 1;
     if (token >= 0) {
-        // rider: RMSNorm of row `token` -> write-through store -> flag; then wave 0 alone walks the Top-P chain while the other waves already
-        // request their weights.  Waves 4..7 only keep the two barriers of router4_body company.
+        // rider: the Top-P router of row `token` (its own RMSNorm + gate GEMV on waves 0..3, then wave 0 alone walks the serial chain while
+        // the other waves go on to the GEMM).  Nobody in this launch waits for it: its tables feed the combine of a LATER launch.
+        // Waves 4..7 only keep the two barriers of router4_body company.
         float* rl = reinterpret_cast<float*>(smem + lds_gemm);
         if (threadIdx.x < 256) {
 #ifdef UMOE_TIMELINE
             TL_ENTER(5);
 #endif
-            if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, token, threadIdx.x, rl TL_PASS, pub.flags, epoch, nullptr);
-            else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, rl TL_PASS, pub.flags, epoch, nullptr);
+            if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, token, threadIdx.x, rl TL_PASS, nullptr, 0u, nullptr);
+            else router4_body<9, 2, 0, false>(ra, token, threadIdx.x, rl TL_PASS, nullptr, 0u, nullptr);
         } else {
             __syncthreads();
             __syncthreads();
@@ -369,10 +413,10 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
     }
     const int fp0 = (int)(eg & 2047u), np = (int)((eg >> 11) & 7u);
     switch (np) {
-        case 4: flat_gateup<4>(A, pub, epoch, fp0, b, smem, st); break;
-        case 5: flat_gateup<5>(A, pub, epoch, fp0, b, smem, st); break;
-        case 6: flat_gateup<6>(A, pub, epoch, fp0, b, smem, st); break;
-        case 7: flat_gateup<7>(A, pub, epoch, fp0, b, smem, st); break;
+        case 4: flat_gateup<4>(A, pub, fp0, b, smem, st); break;
+        case 5: flat_gateup<5>(A, pub, fp0, b, smem, st); break;
+        case 6: flat_gateup<6>(A, pub, fp0, b, smem, st); break;
+        case 7: flat_gateup<7>(A, pub, fp0, b, smem, st); break;
         default: break;
     }
     for (int sl = 0; sl < FLAT_SLICES; ++sl) {
@@ -382,25 +426,25 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
         __syncthreads();     // (the reduction slab of the previous GEMM is the staging area of this one)
         if (A.dn_kb[grp] & 1) {
             switch (nd) {
-                case 1: flat_down<1, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 2: flat_down<2, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 3: flat_down<3, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 4: flat_down<4, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 5: flat_down<5, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 6: flat_down<6, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 7: flat_down<7, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 8: flat_down<8, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 9: flat_down<9, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                default: flat_down<10, 1>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 1: flat_down<1, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 2: flat_down<2, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 3: flat_down<3, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 4: flat_down<4, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 5: flat_down<5, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 6: flat_down<6, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 7: flat_down<7, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 8: flat_down<8, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 9: flat_down<9, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                default: flat_down<10, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
             }
         } else {
             switch (nd) {
-                case 1: flat_down<1, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 2: flat_down<2, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 3: flat_down<3, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 4: flat_down<4, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 5: flat_down<5, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
-                default: flat_down<6, 2>(A, pub, epoch, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 1: flat_down<1, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 2: flat_down<2, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 3: flat_down<3, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 4: flat_down<4, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 5: flat_down<5, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                default: flat_down<6, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
             }
         }
     }
@@ -428,7 +472,7 @@ struct FlatShape {
     int G, S, n_wg, kb_gu;
     int pairs[FLAT_MAXG], dn_nb[FLAT_MAXG], dn_kb[FLAT_MAXG], dn_src[FLAT_MAXG];
     int rider_less, heavy_at;           // experiment knobs: -1 = search
-    double rider, stage, flagc;
+    double rider, stage, flagc, pair_scale;
     bool operator==(const FlatShape& o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
 };
 
@@ -514,7 +558,9 @@ static void flat_plan(const FlatShape& sh, FlatPlan& out) {
             int acc = 0;
             for (int j = 0; j < n; ++j) { fp0[j] = acc; acc += np[j]; }
             if (acc != P) break;
-            for (int j = 0; j < n; ++j) avail[j] = (j < S ? sh.rider : 0.0) + np[j] * cp;
+            // (pair_scale < 1: the weight stream is HBM-bound and shared in proportion to what a workgroup has in flight, so a slice of
+            //  7 pairs ends its gate/up phase hardly later than one of 6: measured, scripts/flat_timeline.py)
+            for (int j = 0; j < n; ++j) avail[j] = (j < S ? sh.rider : 0.0) + base * cp + (np[j] - base) * cp * sh.pair_scale;
             double seam[FLAT_MAXG];
             int pb[FLAT_MAXG], pn[FLAT_MAXG], ex[FLAT_MAXG];
             bool fits = true;
@@ -583,8 +629,9 @@ static void flat_knobs(FlatShape& sh) {
     // model constants (KiB of weight stream a workgroup forgoes; calibrated on MI355X) and experiment knobs
     sh.rider = flat_env("UMOE_FLAT_RIDER_KIB", 110.0);
     sh.stage = flat_env("UMOE_FLAT_STAGE_KIB", 40.0);
-    sh.flagc = flat_env("UMOE_FLAT_FLAG_KIB", 60.0);
-    sh.rider_less = (int)flat_env("UMOE_FLAT_RIDER_LESS", -1.0);
+    sh.flagc = flat_env("UMOE_FLAT_FLAG_KIB", 0.0);
+    sh.pair_scale = flat_env("UMOE_FLAT_PAIR_SCALE", 0.3);
+    sh.rider_less = (int)flat_env("UMOE_FLAT_RIDER_LESS", 1.0);
     sh.heavy_at = (int)flat_env("UMOE_FLAT_HEAVY_AT", -1.0);
 }
 
@@ -598,8 +645,8 @@ int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* 
           dn->max_k % 32 == 0 && (gu->lda & 7) == 0 && (gu->ldo & 7) == 0 && (dn->ldo & 3) == 0 && n_wg >= 1 && n_wg <= FLAT_MAXWG && n_wg <= flag_words))
         return 1;
     const umoe_router_args* r = gu->fused_router;
-    if (!(r->S >= 1 && r->S <= 16 && r->n_dyn == 9 && r->n_fix == 2 && (r->D == 2048 || r->D == 4096) && r->x && r->gate_w && r->expert_mask && !r->logits_in &&
-          !r->norm_only && r->norm_w && r->h_out == gu->a && !r->gumbel && !r->x_noise && !r->attn_mask))
+    if (!(r->S >= 1 && r->S <= 16 && r->n_dyn == 9 && r->n_fix == 2 && r->D == 2048 && r->x && r->gate_w && r->expert_mask && !r->logits_in &&
+          !r->norm_only && r->norm_w && !r->gumbel && !r->x_noise && !r->attn_mask))
         return 1;
     FlatShape sh;
     memset(&sh, 0, sizeof(sh));
@@ -641,9 +688,9 @@ int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* 
     if (!pl.ok) return 1;
     flat_args A;
     memset(&A, 0, sizeof(A));
-    A.a = gu->a; A.h = reinterpret_cast<uint16_t*>(gu->out); A.y = reinterpret_cast<uint16_t*>(dn->out); A.flags = flags;
+    A.a = r->x; A.norm_w = r->norm_w; A.rms_eps = r->rms_eps; A.h = reinterpret_cast<uint16_t*>(gu->out); A.y = reinterpret_cast<uint16_t*>(dn->out); A.flags = flags;
     A.dbg = g_flat_dbg;      // diagnostics (scripts/flat_timeline.py; NULL unless umoe_moe_flat_stamps(NULL) enabled them): stamps of the LAST launch
-    A.lda = gu->lda; A.ldh = gu->ldo; A.ldy = dn->ldo; A.S = r->S; A.G = G; A.kb_gu = sh.kb_gu;
+    A.lda = r->D; A.ldh = gu->ldo; A.ldy = dn->ldo; A.S = r->S; A.G = G; A.kb_gu = sh.kb_gu;
     int P = 0, kb_dn_max = 0;
     for (int i = 0; i < G; ++i) {
         A.w_gu[i] = gu->groups_host[i].w; A.w_dn[i] = dn->groups_host[i].w;
@@ -668,7 +715,9 @@ int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* 
         UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_flat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + FLAT_RIDER_LDS)));
         configured = lds + FLAT_RIDER_LDS;
     }
-    moe_flat_kernel<<<dim3((unsigned)n_wg), 512, lds + FLAT_RIDER_LDS, s>>>(A, *r, pub, (int)lds);
+    umoe_router_args rr = *r;
+    rr.h_out = nullptr;          // nobody reads normalised rows from memory: every workgroup makes its own copy in LDS
+    moe_flat_kernel<<<dim3((unsigned)n_wg), 512, lds + FLAT_RIDER_LDS, s>>>(A, rr, pub, (int)lds);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
