@@ -154,11 +154,11 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
         for (int n = 0; n < 8; ++n) buf[n] = ld16(src + ((n >> 1) * KB + sub + TPR * (n & 1)) * 8);
         // (straight-line loads only: a branch around a load makes hipcc wait for vmcnt(0), i.e. for the weight chunk behind the rows)
         const uint4 nw1 = ld16(A.norm_w + (tid & (4 * KB - 1)) * 8);
-        // BOTH register stages are requested here, behind the rows: nothing the prologue waits for queues behind them (a wave's loads
-        // return in issue order), and HBM has 224 KiB per CU to deliver while the rows are normalised
+        // (measured and rejected: BOTH register stages requested here.  A CU issues about 1 KiB of vector loads per 100 cycles, so the
+        //  second stage's 14 requests per wave only delayed the point where the rows are staged -- 8.6 -> 12.1 us -- and bought nothing:
+        //  3.020 vs 3.015 ms/step.  The launch runs at the CU's request rate from its first request on.)
         __builtin_amdgcn_sched_barrier(0);
         load_chunk(w0, i0);
-        load_chunk(w1, i0 + 1);
         __builtin_amdgcn_sched_barrier(0);
         FSTAMP(1);
         st16(nw_lds + (tid & (4 * KB - 1)) * 16, nw1);      // (both halves of the workgroup store the same 4 KiB)
@@ -212,7 +212,7 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
         }
     };
     for (int i = i0; i < i1; i += 2) {
-        if (i + 1 < i1 && i != i0) load_chunk(w1, i + 1);
+        if (i + 1 < i1) load_chunk(w1, i + 1);
         compute_chunk(w0, i);
         if (i + 2 < i1) load_chunk(w0, i + 2);
         if (i + 1 < i1) compute_chunk(w1, i + 1);
