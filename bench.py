@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config1", action="store_true", help="skip the BASELINE configs[0] (single prompt) legs")
+    ap.add_argument("--no-config3", action="store_true", help="skip the BASELINE configs[2] leg (one training step, scripts/train_bench.py as a child process)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] leg (video_text_to_music, scripts/video_bench.py as a child process)")
     ap.add_argument("--cpu-steps", type=int, default=7, help="timed CPU-oracle decode steps (median; two warm-up steps before them)")
     return ap.parse_args()
 
@@ -129,6 +131,7 @@ def decode_leg(model, cfg, args, device, rank, B, ep=None, profile=True, steps=N
     topk = eng.copy_buffer("all_topk", torch.int64, (cfg.num_hidden_layers, 2 * B)).cpu().float()
     tokens = eng.tokens[:, : K + W + 2].cpu().clone()
     prof = eng.profile_steps(4) if profile else None
+    expert_launch = eng.info("expert_launch")
     err = eng.ep_error() if ep is not None else 0
     hand = eng.handoff_error()
     if hand and not (ep is not None and hand == 1):
@@ -136,7 +139,7 @@ def decode_leg(model, cfg, args, device, rank, B, ep=None, profile=True, steps=N
     if ep is not None:
         barrier()                     # peers may still be reading this rank's exchange region
     info = dict(dt=dt, t_prefill=t_prefill, mean_experts_hit=float(hit.mean()), mean_top_k=float(topk.mean()), prof=prof,
-                kv_len_first=T + W, kv_len_end=T + W + K, tokens=tokens, ep_error=err, steps=K)
+                kv_len_first=T + W, kv_len_end=T + W + K, tokens=tokens, ep_error=err, steps=K, expert_launch=expert_launch)
     eng.close()
     return info
 
@@ -185,9 +188,14 @@ def roofline(cfg, info, args, ep=1):
         # gate + up + down weights of every routed expert hit and of the shared experts, bf16: both expert GEMMs of the
         # layer are ONE launch (every workgroup: gate/up slice, publish, down slice)
         bytes_per_launch = (U * 3 * Id * D + n_fix * 3 * Is * D) * 2.0
-        kname = "moe_fused_kernel"
-        what = (" (grouped gate/up SwiGLU + down projections of 8 routed + 2 shared experts in one launch; 16 of its tile-less "
-                "workgroups run the Top-P router and hand the normalised rows over)")
+        if info.get("expert_launch") == 2:
+            kname = "moe_flat_kernel"
+            what = (" (gate/up SwiGLU + down projections of 8 routed + 2 shared experts in one launch of one workgroup per CU with a "
+                    "byte-balanced static schedule; the first 16 workgroups also run the Top-P router of one row each)")
+        else:
+            kname = "moe_fused_kernel"
+            what = (" (grouped gate/up SwiGLU + down projections of 8 routed + 2 shared experts in one launch; 16 of its tile-less "
+                    "workgroups run the Top-P router and hand the normalised rows over)")
     elif ep == 1:
         # gate+up weights of every routed expert hit + of the shared experts, bf16; activations / outputs < 0.3 %
         bytes_per_launch = (U * 2 * Id * D + n_fix * 2 * Is * D) * 2.0
@@ -237,6 +245,8 @@ def cpu_baseline(args, batch=None, steps=None):
     the full 36-layer model at batch 8 (16 rows) with a synthetic 300-token KV cache, greedy sampling."""
     from oracle import decode as OD
     cfg = make_cfg(args)
+    cpu_model, n_phys, usable = host_cpu()
+    torch.set_num_threads(max(1, min(n_phys, usable)))      # one thread per PHYSICAL core (SURVEY.md 8d): SMT siblings oversubscribe MKL
     torch.manual_seed(0)
     bf = torch.bfloat16
     D, H, KV, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -295,9 +305,54 @@ def cpu_baseline(args, batch=None, steps=None):
     steady = sorted(times[2:])                           # first two steps = warm-up (thread pool, page faults of the 14 GB of weights)
     sec = steady[len(steady) // 2]                       # median
     return {"value": round(B / sec, 3), "unit": "audio-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model, "physical_cores": n_phys, "logical_cpus_usable": usable,
+            "router": "C oracle (oracle/router_oracle.c through liboracle_router.so), not the reference's per-k Python loop: the port is "
+                      "not op-for-op the reference, its routing is faster than the reference's",
             "sample": f"median of {len(steady)} decode steps (after 2 warm-up steps) of the full {cfg.num_hidden_layers}-layer model, batch {B} "
                       f"({2 * B} CFG rows), synthetic KV cache of {L} tokens, torch-CPU bf16 oracle (oracle/decode.py), "
                       f"{sec * 1e3:.0f} ms/step"}
+
+
+def host_cpu():
+    """(model string, physical cores, logical cpus usable by this process) of the host, from /proc/cpuinfo and the affinity mask."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n_phys = len(cores) or usable
+    return model, n_phys, usable
+
+
+def child_leg(script, argv, env=None, timeout=420):
+    """Runs one of scripts/*_bench.py as a CHILD process (its own model and GPU context, after this process freed its memory) and
+    returns the JSON object of its last output line; an error object if it fails -- the headline line must not be lost to a leg."""
+    import subprocess
+    e = dict(os.environ)
+    e.update(env or {})
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)] + argv, env=e, capture_output=True, text=True, timeout=timeout)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+        return json.loads(lines[-1])
+    except Exception as ex:
+        return {"error": repr(ex)}
 
 
 def free_port() -> int:
@@ -442,6 +497,12 @@ def main():
             out["config1"] = {"error": repr(e)}
     del model
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.layers and not args.codec_channels:
+        # BASELINE configs[2] and configs[4] at their own shapes on this GPU (secondary keys; `value` stays configs[1])
+        if not args.no_config3:
+            out["config3"] = child_leg("train_bench.py", [], {"TB_STEPS": "4", "TB_NOCACHE_STEPS": "2"})
+        if not args.no_config5:
+            out["config5"] = child_leg("video_bench.py", ["--steps", "100", "--warmup", "5"])
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

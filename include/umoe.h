@@ -684,6 +684,17 @@ enum { UMOE_EP_PEER = 0, UMOE_EP_LOOPBACK = 1, UMOE_EP_RCCL = 2 };
 int umoe_engine_ep_region(umoe_engine* e, void** base_out, size_t* bytes_out);
 int umoe_engine_ep_connect(umoe_engine* e, void* const* peers, void* rccl_comm, int mode);
 int umoe_engine_ep_error(umoe_engine* e, umoe_stream_t stream, int* code_out);
+/* per-layer probe for parity tests (EAGER decode steps only; capture refuses it).  teach_x [layers][rows][D] bf16 replaces the residual
+ * stream at the START of every layer (the layer's input RMSNorm is recomputed from it), so each layer is checked on the oracle's input
+ * of that layer without compounding (model.py:210-256 one layer at a time); dump_x1 / dump_x [layers][rows][D] receive the stream after
+ * attention + o_proj and after the MoE block, dump_logits [layers][rows][E] the router logits (bf16).  Any pointer may be NULL; all
+ * NULL switches the probe off.  With a probe the layer's combine runs as its own launch (it cannot ride in a QKV launch whose input
+ * is replaced); every other launch is the decode step's own. */
+int umoe_engine_set_probe(umoe_engine* e, const uint16_t* teach_x, uint16_t* dump_x1, uint16_t* dump_x, uint16_t* dump_logits);
+/* host-side facts about the engine: "expert_launch" = what the last dense decode layer enqueued for its experts (0 gate/up and down as
+ * two launches, 1 the box-grid fused launch moe_fused_kernel, 2 the flat launch moe_flat_kernel), "n_cu" = compute units the
+ * co-residency guards assume; -1 for an unknown key */
+int umoe_engine_info(umoe_engine* e, const char* key);
 /* introspection for parity tests: device pointers into the workspace */
 const void* umoe_engine_buffer(umoe_engine* e, const char* name, size_t* bytes);
 

@@ -105,7 +105,11 @@ class TextModelOracle:
         self.moe = [DCMoEOracle(cfg, weights, f"{prefix}layers.{l}.mlp.") for l in range(cfg.num_hidden_layers)]
 
     def forward(self, x: torch.Tensor, key_valid: torch.Tensor, position_ids: torch.Tensor, cache: Optional[list],
-                padding_token_mask: Optional[torch.Tensor] = None, collect_router: bool = False):
+                padding_token_mask: Optional[torch.Tensor] = None, collect_router: bool = False,
+                layer_inputs: Optional[list] = None):
+        """collect_router: per-layer routing results AND the layer's residual-stream states (x_in, x1 after attention, x_out).
+        layer_inputs: teacher forcing for per-layer parity -- layer l reads layer_inputs[l] instead of layer l-1's output (cast to the
+        weights' dtype), so an fp32 copy of the model can be walked along the bf16 model's own trajectory one layer at a time."""
         cfg = self.cfg
         hd = cfg.hidden_size // cfg.num_attention_heads
         if position_ids.dim() == 2:
@@ -115,6 +119,9 @@ class TextModelOracle:
         new_cache, router = [], []
         for l in range(cfg.num_hidden_layers):
             lp = f"{self.p}layers.{l}."
+            if layer_inputs is not None:
+                x = layer_inputs[l].to(x.dtype)
+            x_in = x
             res = x
             h = rmsnorm(x, self.w[lp + "input_layernorm.weight"], cfg.rms_norm_eps)
             a, kv = attention(cfg, self.w, lp + "self_attn.", h, cos, sin, None if cache is None else cache[l], key_valid)
@@ -125,7 +132,7 @@ class TextModelOracle:
             out = self.moe[l](h, padding_token_mask, None)
             if collect_router:
                 router.append(dict(logits=out[1], top_k=out[2], expert_mask=out[3], global_weight=out[4],
-                                   aux=out[5], hidden_in=h, hidden_out=out[0]))
+                                   aux=out[5], hidden_in=h, hidden_out=out[0], x_in=x_in, x1=res, x_out=res + out[0]))
             x = res + out[0]
         x = rmsnorm(x, self.w[self.p + "norm.weight"], cfg.rms_norm_eps)
         return x, new_cache, router

@@ -22,7 +22,8 @@ TAG=$TAG OUT=$OUT python3 - <<'PY'
 import json, os
 tag, out = os.environ["TAG"], os.environ["OUT"]
 pmc = json.load(open(f"{out}/{tag}_pmc_traffic.json"))["kernels"]
-name = next((k for k in pmc if k.startswith("moe_fused_kernel")), None) or next(k for k in pmc if k.startswith("wstream_gemm<14, 1, 0, 2, 8, true"))
+name = next((k for k in pmc if k.startswith("moe_flat_kernel")), None) or next((k for k in pmc if k.startswith("moe_fused_kernel")), None) \
+    or next(k for k in pmc if k.startswith("wstream_gemm<14, 1, 0, 2, 8, true"))
 us = None
 for line in open(f"{out}/{tag}_decode_kernels.md"):
     if name in line:

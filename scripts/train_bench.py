@@ -31,12 +31,27 @@ labels[:, :n_text] = -100
 am = torch.ones(B, T, dtype=torch.long)
 
 
+k_real = [0.0]
+
+
 def step():
     for p in model.parameters():
         p.grad = None
-    loss, closs, aux = TR.forward_train(model, ids, codec, am, labels)
+    loss, closs, aux, routing = TR.forward_train(model, ids, codec, am, labels, return_routing=True)
     loss.backward()
+    if k_real[0] == 0.0:      # logged routing (first step only): routed REAL experts per token (no null / shared experts), mean over layers
+        k_real[0] = float(torch.stack([m[1][..., : cfg.mlp_dynamic_expert_num].float().sum(-1).mean() for m in routing]).mean())
     return float(loss.detach())
+
+
+def step_flops(k):
+    """Algorithmic FLOPs of one forward + backward (3 x forward; the attention recompute of the flash backward is not counted):
+    per token and layer QKV + o_proj + causal attention (T/2 keys on average) + gate + k routed experts + the shared experts, + codec head."""
+    D, H, KV, hd = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    per_tok_layer = 2.0 * D * (H * hd + 2 * KV * hd) + 2.0 * H * hd * D + 4.0 * H * hd * (T / 2.0) + 2.0 * D * cfg.num_experts \
+        + k * 6.0 * cfg.dynamic_intermediate_size * D + cfg.mlp_fixed_expert_num * 6.0 * cfg.shared_intermediate_size * D
+    head = 2.0 * D * cfg.codec_channels * cfg.codec_vocab_size
+    return 3.0 * B * T * (layers * per_tok_layer + head)
 
 
 t0 = time.perf_counter()
@@ -51,6 +66,19 @@ for _ in range(steps):
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
 dt = sorted(ts)[len(ts) // 2]
+# a trainer that steps the optimizer after every backward cannot reuse the transposed weight copies: same steps without the cache
+from unimoe_audio_amd import ops as _ops
+_ops.clear_weight_transpose_cache()
+os.environ["UMOE_WT_CACHE"] = "0"
+tn = []
+for _ in range(int(os.environ.get("TB_NOCACHE_STEPS", "3"))):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    tn.append(time.perf_counter() - t0)
+dtn = sorted(tn)[len(tn) // 2] if tn else None
+os.environ.pop("UMOE_WT_CACHE")
 tf = []
 with torch.no_grad():
     for _ in range(2):
@@ -62,8 +90,14 @@ with torch.no_grad():
 print(json.dumps({"workload": f"BASELINE configs[2]: fwd+bwd, {layers} layers, batch {B} x {T} tokens", "tokens_per_step": B * T,
                   "step_ms": round(dt * 1e3, 1), "tokens_per_s": round(B * T / dt, 1), "first_step_ms": round(t_first * 1e3, 1),
                   "all_steps_ms": [round(v * 1e3, 1) for v in ts],
+                  "step_ms_weights_change_every_step": round(dtn * 1e3, 1) if dtn else None,
                   "forward_only_ms": round(min(tf) * 1e3, 1), "loss": round(l0, 4),
                   "max_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                  "k_real": round(k_real[0], 3), "step_tflop": round(step_flops(k_real[0]) / 1e12, 2),
+                  "roofline": {"bound": "mfma", "achieved": round(step_flops(k_real[0]) / dt / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                               "frac": round(step_flops(k_real[0]) / dt / 2.5e15, 4),
+                               "note": "whole step: algorithmic FLOPs (3 x forward, logged k_real routed experts per token) / step time; "
+                                       "peak = dense bf16 MFMA (MI355X_MICROARCH.md)"},
                   "weights_unchanged_between_steps": True,
                   "note": "layer math only, no optimizer step (SURVEY 8d config 3): the weights keep their versions, so from the third step on "
                           "the transposed weight copies of the input-gradient GEMMs are reused (ops._WT_CACHE, the gradient-accumulation "

@@ -201,3 +201,126 @@ def test_full_depth_teacher_forced_decode_vs_oracle(full_model, B, ragged, attn,
 # every flipped near-tie sends a row through another expert and the difference travels on); bounds = that + margin
 BOUNDS = {"med": 0.09, "max": 0.20, "argmax": 0.82, "mask": 0.80}
 ATTN_WIDE_DEFAULT = False      # the engine's default decode attention (umoe_engine.hip: attn_wide)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Every layer in isolation (reference layer: utils/UniMoE_Audio_model.py:210-256).  The test above lets differences compound over 36
+# layers (every flipped near-tie travels on); here layer l of the HIP path gets the ORACLE's input of layer l -- residual stream and KV
+# cache -- through the engine's per-layer probe (umoe_engine_set_probe), so each layer's weights and kernels are checked at the per-op
+# tolerance on their own, router integers exactly given the GPU's own logits, and the distance from an fp32 walk along the same
+# trajectory is split into the attention half (x1 - x_in) and the MoE half (x_out - x1) of every layer.
+PER_LAYER_RESULTS = os.path.join(ROOT, "gpurun_out", "per_layer_parity.json")
+# bounds = first measurement on MI355X + margin (recorded in profiles/r03_per_layer_parity.json)
+PER_LAYER_BOUNDS = {"attn_half": 0.03, "moe_half": 0.03, "mask_agree_mean": 0.93, "mask_agree_min": 0.80, "elem_viol": 0.002}
+
+
+@pytest.mark.parametrize("B,ragged", [(8, False), (1, True)])
+def test_full_depth_every_layer_in_isolation_vs_oracle(full_model, B, ragged, monkeypatch):
+    monkeypatch.setenv("UMOE_DENSE_MIN_ROWS", "6" if ragged else "2")
+    from oracle import decode as OD
+    from oracle import router as OR
+    from unimoe_audio_amd.codec_utils import prepare_audio_prompt
+    from unimoe_audio_amd.model import DecodeEngine
+    cfg, gm, w, dev = full_model
+    T, MAXT = 64, 48
+    C, E, Lyr, D = cfg.codec_channels, cfg.num_experts, cfg.num_hidden_layers, cfg.hidden_size
+    KVH, hd = cfg.num_key_value_heads, cfg.head_dim
+    rows = 2 * B
+    g = torch.Generator().manual_seed(200 + B)
+    ids = torch.randint(0, 290, (rows, T), generator=g)
+    am = torch.ones(rows, T, dtype=torch.long)
+    for r in range(0, rows, 2):
+        am[r, : 9 + (r % 5)] = 0
+    n_codec = 24
+    ids[:, -n_codec - 3:-3] = cfg.codec_placeholder_value
+    codec = torch.randint(0, 1024, (rows * n_codec, C), generator=g)
+    pre, psteps = prepare_audio_prompt(cfg, [None] * B)
+    step0 = min(psteps) - 1
+    forced = torch.randint(0, 1024, (B, max(pre.shape[1], step0 + 3), C), generator=g).to(torch.int32)
+    keep = pre.to(torch.int32) != -1
+    forced[:, : pre.shape[1]][keep] = pre.to(torch.int32)[keep]
+    # ---- oracle: prefill, then ONE decode step with every layer's states kept
+    tm = OD.TextModelOracle(cfg, w)
+    key_valid = am.bool()
+    pos = (am.long().cumsum(-1) - 1).masked_fill(am == 0, 1)
+    x = OD.input_embedding(cfg, w, ids, codec)
+    kv1 = torch.cat([key_valid, torch.ones((rows, 1), dtype=torch.bool)], -1)
+    p1 = (kv1.long().cumsum(-1) - 1).masked_fill(~kv1, 1)[:, -1:]
+    tok2 = forced[:, step0: step0 + 1].long().repeat_interleave(2, dim=0)
+    with torch.no_grad():
+        _, cache, _ = tm.forward(x, key_valid, pos, None)
+        _, _, lay = tm.forward(OD.codec_embedding(cfg, w, tok2), kv1, p1, cache, collect_router=True)
+    x_in = torch.stack([r["x_in"][:, 0] for r in lay])             # [layers, rows, D] bf16: the teacher's layer inputs
+    x1_o = torch.stack([r["x1"][:, 0] for r in lay]).float()
+    xo_o = torch.stack([r["x_out"][:, 0] for r in lay]).float()
+    mask_o = torch.stack([r["expert_mask"].reshape(rows, E) for r in lay])
+    # ---- fp32 centre: the same layers in fp32 on the SAME inputs (the bf16 oracle's layer inputs and KV cache, upcast)
+    w32 = {k: v.float() for k, v in w.items()}
+    tm32 = OD.TextModelOracle(cfg, w32)
+    with torch.no_grad():
+        c32 = [(k.float(), v.float()) for k, v in cache]
+        _, _, lay32 = tm32.forward(OD.codec_embedding(cfg, w32, tok2), kv1, p1, c32, collect_router=True, layer_inputs=[t[:, None].float() for t in x_in])
+    x1_c = torch.stack([r["x1"][:, 0] for r in lay32])
+    xo_c = torch.stack([r["x_out"][:, 0] for r in lay32])
+    mask_c = torch.stack([r["expert_mask"].reshape(rows, E) for r in lay32])
+    del w32, tm32, c32, lay32
+    # ---- engine: its own prefill (positions, KV slots), then the ORACLE's KV cache of every layer in its place, one eager probed step
+    xg = gm.calculate_input_embedding(ids.to(dev), codec.to(dev))
+    eng = DecodeEngine(gm, B, Lmax=T + MAXT + 8, Tmax=MAXT + 64)
+    eng.prefill(xg.reshape(-1, D).contiguous(), am.to(dev))
+    Lmax = eng.Lmax
+    for name, idx in (("k_cache", 0), ("v_cache", 1)):
+        full = torch.zeros(Lyr, rows, KVH, Lmax, hd, dtype=torch.bfloat16)
+        full[:, :, :, :T] = torch.stack([c[idx] for c in cache])
+        eng.write_buffer(name, full.to(dev))
+    eng.start_decode(forced, psteps, MAXT, 6, cfg_scale=3.0, temperature=1.0, top_p=1.0, top_k=45, eos_mul=0.8, do_sample=False)
+    pr = eng.set_probe(teach_x=x_in.to(dev), dump_x1=True, dump_x=True, dump_logits=True)
+    eng.step(use_graph=False)
+    torch.cuda.synchronize()
+    assert eng.handoff_error() == 0
+    x1_h, xo_h, lg_h = pr["x1"].cpu().float(), pr["x"].cpu().float(), pr["logits"].cpu()
+    mask_h = eng.copy_buffer("all_mask", torch.int32, (Lyr, rows, E)).cpu()
+    topk_h = eng.copy_buffer("all_topk", torch.int64, (Lyr, rows)).cpu()
+    eng.set_probe()
+    eng.close()
+    xin = x_in.float()
+    rec = {"rows": rows, "layers": Lyr, "ragged": ragged, "per_layer": []}
+    fro = lambda t: float(t.norm())
+    for l in range(Lyr):
+        # router integers: exact given the GPU's own logits (C oracle, oracle/router_oracle.c)
+        o = OR.route(lg_h[l], cfg.num_dyn, cfg.mlp_dynamic_expert_num, cfg.mlp_fixed_expert_num, float(cfg.mlp_dynamic_top_p),
+                     int(cfg.mlp_dynamic_top_k), float(cfg.router_jitter_noise), None)
+        assert torch.equal(o["expert_mask"].to(torch.int32), mask_h[l]) and torch.equal(o["top_k"], topk_h[l]), f"layer {l}: router integers differ from the oracle on the GPU's logits"
+        same = (mask_h[l] == mask_o[l].to(torch.int32)).all(-1)
+        same_c = same & (mask_c[l].to(torch.int32) == mask_h[l]).all(-1)
+        att = fro(x1_h[l] - x1_o[l]) / fro(x1_o[l] - xin[l])
+        d_h, d_o = (xo_h[l] - x1_h[l]), (xo_o[l] - x1_o[l])
+        moe = fro(d_h[same] - d_o[same]) / max(fro(d_o[same]), 1e-9) if bool(same.any()) else 0.0
+        # element-wise, rows with identical routing: |hip - oracle| <= 2^-6 |oracle| + 2^-8 (the per-op bf16 tolerance)
+        viol = float(((xo_h[l][same] - xo_o[l][same]).abs() > 2 ** -6 * xo_o[l][same].abs() + 2 ** -8).float().mean()) if bool(same.any()) else 0.0
+        d_c = xo_c[l] - x1_c[l]
+        rec["per_layer"].append({
+            "attn_half_rel": att, "moe_half_rel_same_routing": moe, "mask_agree": float(same.float().mean()), "elem_viol_frac": viol,
+            # distance from the fp32 walk, per half, HIP vs CPU oracle
+            "attn_vs_fp32_hip": fro(x1_h[l] - x1_c[l]) / fro(x1_c[l] - xin[l]), "attn_vs_fp32_oracle": fro(x1_o[l] - x1_c[l]) / fro(x1_c[l] - xin[l]),
+            "moe_vs_fp32_hip": fro(d_h[same_c] - d_c[same_c]) / max(fro(d_c[same_c]), 1e-9) if bool(same_c.any()) else None,
+            "moe_vs_fp32_oracle": fro(d_o[same_c] - d_c[same_c]) / max(fro(d_c[same_c]), 1e-9) if bool(same_c.any()) else None})
+    pl = rec["per_layer"]
+    mean = lambda k: sum(p[k] for p in pl if p[k] is not None) / max(1, sum(1 for p in pl if p[k] is not None))
+    rec["summary"] = {k: {"mean": mean(k), "max": max(p[k] for p in pl if p[k] is not None)} for k in pl[0]}
+    rec["summary"]["extra_distance_from_fp32"] = {"attention_half": mean("attn_vs_fp32_hip") - mean("attn_vs_fp32_oracle"),
+                                                  "moe_half": mean("moe_vs_fp32_hip") - mean("moe_vs_fp32_oracle")}
+    print("\nPER-LAYER PARITY", json.dumps(rec["summary"]))
+    os.makedirs(os.path.dirname(PER_LAYER_RESULTS), exist_ok=True)
+    allr = json.load(open(PER_LAYER_RESULTS)) if os.path.exists(PER_LAYER_RESULTS) else {}
+    allr[f"batch{B}" + ("_ragged" if ragged else "")] = rec
+    json.dump(allr, open(PER_LAYER_RESULTS, "w"), indent=1)
+    s = rec["summary"]
+    Bd = PER_LAYER_BOUNDS
+    assert s["attn_half_rel"]["max"] < Bd["attn_half"], s["attn_half_rel"]
+    assert s["moe_half_rel_same_routing"]["max"] < Bd["moe_half"], s["moe_half_rel_same_routing"]
+    assert s["elem_viol_frac"]["max"] < Bd["elem_viol"], s["elem_viol_frac"]
+    assert s["mask_agree"]["mean"] > Bd["mask_agree_mean"] and min(p["mask_agree"] for p in pl) >= (Bd["mask_agree_min"] if rows >= 8 else 0.0), s["mask_agree"]
+    # no half of any layer further from the fp32 walk than the CPU oracle's, x 1.25 (averaged over the layers)
+    assert mean("attn_vs_fp32_hip") < 1.25 * mean("attn_vs_fp32_oracle") + 0.002, s
+    assert mean("moe_vs_fp32_hip") < 1.25 * mean("moe_vs_fp32_oracle") + 0.002, s

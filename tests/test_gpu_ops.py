@@ -6,6 +6,7 @@ tolerances for bf16/fp32 tensors.
 """
 import glob
 import os
+import re
 import types
 
 import numpy as np
@@ -360,21 +361,35 @@ def test_dcmoe_block_backward_vs_reference_autograd(dev, path):
         ok = torch.isfinite(b.float())
         return float((a.float()[ok] - b.float()[ok]).norm() / (b.float()[ok].norm() + 1e-12))
 
-    if not mask_ok:       # a near-tie routed differently from the CPU run: gradients of other experts -- not comparable
-        pytest.skip("routing differs from the fixture on a near-tie")
-    errs = {"x": rel(x.grad.cpu(), g["grad_x"])}
+    # A near-tie may route a few tokens differently from the CPU run that made the fixture.  The test never skips: rows are independent
+    # (the input gradient of every OTHER token is compared as usual), a routed expert that no differing token touches in either mask
+    # keeps the strict bound, and the tensors every token feeds (gate, shared experts, touched experts) get the bound widened by what
+    # a fraction f of differing tokens can move a sum over tokens (2 sqrt(f)); f itself is bounded so the check cannot dissolve.
+    got_mask, ref_mask = out[3].cpu().reshape(-1, out[3].shape[-1]), g["out_mask"].reshape(-1, g["out_mask"].shape[-1])
+    bad = (got_mask != ref_mask).any(-1)
+    f_bad = float(bad.float().mean())
+    assert f_bad <= 0.02, f"{int(bad.sum())} of {bad.numel()} tokens route differently from the fixture: more than near-ties explain"
+    touched = ((got_mask[bad] != 0) | (ref_mask[bad] != 0)).any(0) if bool(bad.any()) else torch.zeros(got_mask.shape[-1], dtype=torch.bool)
+    gx, rx = x.grad.cpu().reshape(-1, x.shape[-1]), g["grad_x"].reshape(-1, x.shape[-1])
+    errs = {"x": rel(gx[~bad], rx[~bad])}
+    loose = set()
     for n, p_ in blk.named_parameters():
         ref = g["g." + n]
         if not bool(torch.isfinite(ref.float()).all()):
             assert p_.grad is not None and not bool(torch.isfinite(p_.grad.float()).all()), n       # NaN where the reference is NaN
             continue
         if float(ref.float().norm()) == 0.0:
-            assert p_.grad is None or float(p_.grad.float().norm()) == 0.0, n
+            assert mask_ok is False or p_.grad is None or float(p_.grad.float().norm()) == 0.0, n
             continue
         assert p_.grad is not None, n
         errs[n] = rel(p_.grad.cpu(), ref)
-    worst = max(errs.items(), key=lambda kv: kv[1])
-    assert worst[1] < 0.03, (worst, errs)
+        if not mask_ok:
+            m_ = re.search(r"deepspeed_experts\.(\d+)\.", n)
+            if m_ is None or bool(touched[int(m_.group(1))]):
+                loose.add(n)
+    bound = {n: 0.03 + (2.0 * f_bad ** 0.5 if n in loose else 0.0) for n in errs}
+    over = {n: (e, bound[n]) for n, e in errs.items() if e >= bound[n]}
+    assert not over, (over, errs, f_bad)
 
 
 def test_dcmoe_block_backward_multitile_vs_autograd_oracle(dev):

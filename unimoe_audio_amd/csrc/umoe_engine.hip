@@ -71,6 +71,10 @@ struct umoe_engine {
     int32_t* all_mask = nullptr;
     int64_t* all_topk = nullptr;
     int T_prompt = 0;
+    // per-layer probe of the parity tests (umoe_engine_set_probe): eager steps only
+    const uint16_t* probe_teach = nullptr;
+    uint16_t *probe_x1 = nullptr, *probe_x = nullptr, *probe_logits = nullptr;
+    bool probe_on() const { return probe_teach || probe_x1 || probe_x || probe_logits; }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     // second stream: the shared experts run beside the (latency-bound) router; fork/join by events, graph-capturable
@@ -92,6 +96,7 @@ struct umoe_engine {
     int dense_min_rows = 2;      // UMOE_DENSE_MIN_ROWS: fewest decode rows that take the dense-expert layout (below: ragged dispatch).  Batch 1
                                  // (2 CFG rows, BASELINE configs[0]) hits 5-6 of the 8 experts: streaming all 8 in the fused launches costs
                                  // fewer microseconds than the ragged path's four extra launches -- 2.91 vs 3.33 ms/step
+    int expert_launch = 0;       // what the last dense decode layer enqueued for its experts: 0 two launches, 1 box-grid fused, 2 flat (umoe_engine_info)
     int n_cu = 0;                // compute units of the device (UMOE_FAKE_CUS overrides: tests of the co-residency guards)
     bool flat_moe = true;        // UMOE_FLAT_MOE: both expert GEMMs as ONE workgroup per CU with a byte-balanced static schedule
                                  // (umoe_moe_flat.hip); 0 / shapes that do not fit: the box-grid launch below
@@ -794,6 +799,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     }
     if (rc) return rc;
     PROF(K_OPROJ);
+    if (e->probe_x1 && n_tok == c.rows)
+        UMOE_HIP(hipMemcpyAsync(e->probe_x1 + (size_t)l * c.rows * D, e->x1, (size_t)c.rows * D * 2, hipMemcpyDeviceToDevice, s));
     if (e->ep_decode(n_tok)) return run_moe_ep(e, l, n_tok, s);
     if (e->overlap_shared && c.n_fix > 0) {   // fork: shared experts on s2 (x1 -> RMSNorm -> SwiGLU -> down)
         UMOE_HIP(hipEventRecord(e->ev_fork, s));
@@ -942,8 +949,12 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
             const bool flat = fv ? atoi(fv) != 0 : e->flat_moe;
             const int n_wg = e->n_cu < 256 ? e->n_cu : 256;
             if (flat && !rs_handoff && n_wg > 0) rc = umoe_moe_flat(&gu, &dn, e->ep_words + 64, 512 - 64, n_wg, s);
+            e->expert_launch = rc == 0 ? 2 : 0;
         }
-        if (rc == 1 && box_fits) rc = umoe_moe_fused(&gu, &dn, e->ep_words + 64, 512 - 64, s);
+        if (rc == 1 && box_fits) {
+            rc = umoe_moe_fused(&gu, &dn, e->ep_words + 64, 512 - 64, s);
+            if (rc == 0) e->expert_launch = 1;
+        }
         UMOE_REQUIRE(!(rc == 1 && !box_fits), "umoe_engine: no expert launch with in-launch hand-offs fits %d compute units (UMOE_RIDER_PUB=0 selects the launch-per-kernel path)", e->n_cu);
         UMOE_REQUIRE(!(rc == 1 && rs_handoff), "umoe_engine: the fused expert launch refused the shapes it was configured for (UMOE_RS_HANDOFF=0 selects the other form)");
         if (rc == 1) {
@@ -967,7 +978,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // fused RMSNorm for the consumer of x: the next layer's input_layernorm, or the final norm in front of the head
     cb.norm_w = (l + 1 < c.layers) ? e->layers[l + 1].w.in_norm : e->final_norm; cb.norm_out = e->hin; cb.rms_eps = c.rms_eps;
     const bool cq_fits = e->n_cu <= 0 || n_tok + QKV / 16 <= 2 * e->n_cu;      // riders + QKV tiles resident at once (two 4-wave workgroups per CU)
-    if (dense && T == 1 && !tiled && e->fuse_cq && e->rider_pub && cq_fits && l + 1 < c.layers && D == 2048 && n_tok <= 16 && c.n_fix >= 1) {
+    if (dense && T == 1 && !tiled && e->fuse_cq && e->rider_pub && cq_fits && l + 1 < c.layers && D == 2048 && n_tok <= 16 && c.n_fix >= 1 && !e->probe_on()) {
         e->cb_stash = cb;        // issued by the next layer's QKV launch (run_layer(l + 1) follows immediately)
         e->cb_pending = true;
         return 0;
@@ -1083,8 +1094,17 @@ static int enqueue_step(umoe_engine* e, const umoe_decode_io* io, hipStream_t s)
         return rc;
     PROF(K_EMBED);
     e->cb_pending = false;
-    for (int l = 0; l < c.layers; ++l)
+    for (int l = 0; l < c.layers; ++l) {
+        if (e->probe_teach) {        // teacher-forced layer input (parity tests): x <- teach[l], hin <- RMSNorm(x)
+            UMOE_HIP(hipMemcpyAsync(e->x, e->probe_teach + (size_t)l * c.rows * c.hidden, (size_t)c.rows * c.hidden * 2, hipMemcpyDeviceToDevice, s));
+            if ((rc = umoe_rmsnorm_residual_fwd(e->x, nullptr, e->layers[l].w.in_norm, c.rms_eps, c.rows, c.hidden, nullptr, e->hin, s))) return rc;
+        }
         if ((rc = run_layer(e, l, c.rows, 1, c.attn_splits, s))) return rc;
+        if (e->probe_x)
+            UMOE_HIP(hipMemcpyAsync(e->probe_x + (size_t)l * c.rows * c.hidden, e->x, (size_t)c.rows * c.hidden * 2, hipMemcpyDeviceToDevice, s));
+        if (e->probe_logits)
+            UMOE_HIP(hipMemcpyAsync(e->probe_logits + (size_t)l * c.rows * (c.n_dyn + c.n_fix), e->r_logits, (size_t)c.rows * (c.n_dyn + c.n_fix) * 2, hipMemcpyDeviceToDevice, s));
+    }
     // final norm + codec head -> fp32 logits                       model.py:428, 982-983
     umoe_gemm_args h{};
     h.groups = e->d_groups + (size_t)c.layers * e->groups_per_layer();
@@ -1137,6 +1157,7 @@ extern "C" int umoe_engine_profile_step(umoe_engine* e, const umoe_decode_io* io
 extern "C" int umoe_engine_capture(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream) {
     UMOE_REQUIRE(e && io && io->tokens && io->state, "umoe_engine_capture: null argument");
     UMOE_REQUIRE(e->T_prompt > 0, "umoe_engine_capture: prefill first");
+    UMOE_REQUIRE(!e->probe_on(), "umoe_engine_capture: the per-layer probe works on eager steps only (umoe_engine_set_probe)");
     hipStream_t s = (hipStream_t)stream;
     if (e->exec) { (void)hipGraphExecDestroy(e->exec); e->exec = nullptr; }
     if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; }
@@ -1154,6 +1175,20 @@ extern "C" int umoe_engine_capture(umoe_engine* e, const umoe_decode_io* io, umo
 extern "C" int umoe_engine_replay(umoe_engine* e, umoe_stream_t stream) {
     UMOE_REQUIRE(e && e->exec, "umoe_engine_replay: no captured step");
     UMOE_HIP(hipGraphLaunch(e->exec, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int umoe_engine_info(umoe_engine* e, const char* key) {
+    if (!e || !key) return -1;
+    if (!strcmp(key, "expert_launch")) return e->expert_launch;
+    if (!strcmp(key, "n_cu")) return e->n_cu;
+    return -1;
+}
+
+extern "C" int umoe_engine_set_probe(umoe_engine* e, const uint16_t* teach_x, uint16_t* dump_x1, uint16_t* dump_x, uint16_t* dump_logits) {
+    UMOE_REQUIRE(e, "umoe_engine_set_probe: null engine");
+    UMOE_REQUIRE(e->c.ep_size == 1 || !(teach_x || dump_x1 || dump_x || dump_logits), "umoe_engine_set_probe: not with expert parallel engines");
+    e->probe_teach = teach_x; e->probe_x1 = dump_x1; e->probe_x = dump_x; e->probe_logits = dump_logits;
     return 0;
 }
 

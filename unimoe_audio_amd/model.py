@@ -649,6 +649,47 @@ class DecodeEngine:
         assert rc == 0
         return out
 
+    def info(self, key: str) -> int:
+        """Host-side facts about the C engine (umoe_engine_info): "expert_launch" (0 two launches, 1 box-grid fused, 2 flat), "n_cu"."""
+        return int(L.lib().umoe_engine_info(self.h, key.encode()))
+
+    def write_buffer(self, name: str, src: torch.Tensor, offset_bytes: int = 0) -> None:
+        """Copies a device tensor INTO an engine workspace buffer (parity tests: the oracle's KV cache for the per-layer probe)."""
+        n = C.c_size_t()
+        p = L.lib().umoe_engine_buffer(self.h, name.encode(), C.byref(n))
+        if not p:
+            raise KeyError(name)
+        src = src.contiguous()
+        nb = src.numel() * src.element_size()
+        assert src.device == self.dev and offset_bytes >= 0 and offset_bytes + nb <= n.value, (name, n.value, offset_bytes, nb)
+        torch.cuda.synchronize()
+        hip = C.CDLL("libamdhip64.so")
+        rc = hip.hipMemcpy(C.c_void_p(p + offset_bytes), C.c_void_p(src.data_ptr()), C.c_size_t(nb), 3)
+        assert rc == 0
+
+    def set_probe(self, teach_x: Optional[torch.Tensor] = None, dump_x1: bool = False, dump_x: bool = False, dump_logits: bool = False):
+        """Per-layer probe of the parity tests (umoe_engine_set_probe; eager steps only).  teach_x [layers, rows, D] bf16 replaces the
+        residual stream at the start of every layer; the returned dict holds the device tensors the following eager steps fill:
+        "x1" / "x" [layers, rows, D] (after attention + o_proj / after the MoE block), "logits" [layers, rows, E] (router, bf16).
+        set_probe() with no argument switches the probe off."""
+        cfg, dev = self.cfg, self.dev
+        Lyr, D, E = cfg.num_hidden_layers, cfg.hidden_size, cfg.num_experts
+        out = {}
+        if teach_x is not None:
+            assert teach_x.shape == (Lyr, self.rows, D) and teach_x.dtype == torch.bfloat16 and teach_x.device == dev
+            out["teach"] = teach_x.contiguous()
+        if dump_x1:
+            out["x1"] = torch.zeros(Lyr, self.rows, D, dtype=torch.bfloat16, device=dev)
+        if dump_x:
+            out["x"] = torch.zeros(Lyr, self.rows, D, dtype=torch.bfloat16, device=dev)
+        if dump_logits:
+            out["logits"] = torch.zeros(Lyr, self.rows, E, dtype=torch.bfloat16, device=dev)
+        ptr = lambda k: C.c_void_p(out[k].data_ptr()) if k in out else None
+        L.check(L.lib().umoe_engine_set_probe(self.h, ptr("teach"), ptr("x1"), ptr("x"), ptr("logits")), "umoe_engine_set_probe")
+        self._probe = out            # (keeps the tensors alive while the engine holds their addresses)
+        self.captured = False
+        return out
+
     def close(self):
         if getattr(self, "h", None):
             torch.cuda.synchronize()
