@@ -210,8 +210,11 @@ ATTN_WIDE_DEFAULT = False      # the engine's default decode attention (umoe_eng
 # tolerance on their own, router integers exactly given the GPU's own logits, and the distance from an fp32 walk along the same
 # trajectory is split into the attention half (x1 - x_in) and the MoE half (x_out - x1) of every layer.
 PER_LAYER_RESULTS = os.path.join(ROOT, "gpurun_out", "per_layer_parity.json")
-# bounds = first measurement on MI355X + margin (recorded in profiles/r03_per_layer_parity.json)
-PER_LAYER_BOUNDS = {"attn_half": 0.03, "moe_half": 0.03, "mask_agree_mean": 0.93, "mask_agree_min": 0.80, "elem_viol": 0.002}
+# bounds = first measurement on MI355X + margin (profiles/r03_per_layer_parity.json: attention half 0.0003 mean / 0.0006 max, MoE half 0.004 /
+# 0.019 -- the one layer at 0.019 has a row whose bf16 router logit differs in its last bit, which moves its routing WEIGHTS by ~1 % --,
+# routing masks identical on every one of the 36 x 16 (layer, row) pairs, 0.03 % of the elements outside the per-op tolerance (1.1 % in
+# that one layer); against the fp32 walk the HIP path and the CPU oracle sit at the same distance to four digits in both halves)
+PER_LAYER_BOUNDS = {"attn_half": 0.003, "moe_half": 0.04, "mask_agree_mean": 0.97, "mask_agree_min": 0.80, "elem_viol": 0.03}
 
 
 @pytest.mark.parametrize("B,ragged", [(8, False), (1, True)])

@@ -25,360 +25,7 @@
 #include "umoe_common.h"
 #include "umoe_router_dev.h"
 
-#define FLAT_MAXG UMOE_GROUPS_INLINE
-#define FLAT_MAXWG 256
-#define FLAT_NP_MIN 4
-#define FLAT_NP_MAX 7
-#define FLAT_ND_MAX2 6      // blocks of one down slice, 2-step chunks (even number of k-steps: the routed experts)
-#define FLAT_ND_MAX1 10     // ... 1-step chunks (odd number of k-steps: the shared experts, half the bytes per block)
-#define FLAT_SLICES 2       // down slices per workgroup
-
-struct flat_args {
-    // (what the first weight request needs sits at the front: one batch of kernel-argument loads)
-    const uint16_t* a;                  // raw rows x1 [S][lda] (the residual stream after attention); every workgroup normalises them itself
-    const uint16_t* norm_w;             // post-attention RMSNorm weights [D]
-    float rms_eps;
-    int lda, S, G;                      // row stride, rows (<= 16), groups
-    int pair0[FLAT_MAXG + 1];           // first flat pair of gate/up group i (pair0[G] = all pairs)
-    const uint16_t* w_gu[FLAT_MAXG];    // WP16 gate/up weights (blocks interleaved) per group
-    uint16_t* h;                        // silu(g)*u rows [.][ldh]: written by the gate/up phase, read by the down phase of this launch
-    uint16_t* y;                        // down-projection outputs [.][ldy]
-    uint32_t* flags;                    // one word per workgroup: its gate/up slice is published
-    unsigned long long* dbg;            // diagnostics only (NULL otherwise): [workgroup][16] wall-clock stamps (100 MHz)
-    int ldh, ldy, kb_gu;                // k-steps (K / 32) of the gate/up GEMMs (64: see flat_gateup)
-    const uint16_t* w_dn[FLAT_MAXG];    // WP16 down weights per group
-    int h_row[FLAT_MAXG];               // gate/up group i writes rows h_row[i] + r of h
-    int dn_kb[FLAT_MAXG];               // k-steps of down group i
-    int dn_a_row[FLAT_MAXG];            // down group i reads rows dn_a_row[i] + r of h ...
-    int dn_y_row[FLAT_MAXG];            // ... and writes rows dn_y_row[i] + r of y
-    int dn_nb[FLAT_MAXG];               // 16-feature blocks of down group i
-    int prod_base[FLAT_MAXG];           // producers of down group i's rows: workgroups [prod_base, prod_base + prod_n)
-    int prod_n[FLAT_MAXG];
-    uint32_t gu[FLAT_MAXWG];            // per workgroup: first flat pair | pairs << 11 | (rider token + 1) << 16 (0: not a rider)
-    uint32_t dn[FLAT_MAXWG];            // per workgroup: TWO down slices, 16 bits each (low half first): group | first block << 4 | blocks << 12
-};                                      //   (blocks 0 = no slice; see FLAT_ND_*)
-
-__device__ __forceinline__ int flat_lds_chunk_off(int QS, int h, int i, int m) {
-    // 16-byte chunk i of K-quarter h, row m: 256-byte segments, slot rotated by the row index (umoe_gemm.hip lds_chunk_off)
-    return h * QS + (i >> 4) * 256 + (((i & 15) + m) & 15) * 16;
-}
-
-// bounded wait of ONE lane for an epoch flag; `code` lands in the sticky error word only on this lane's OWN timeout (a word that is
-// already set -- an earlier cause, e.g. an expert-parallel receive -- ends the wait and is kept)
-__device__ __forceinline__ void flat_wait(uint32_t* flag, uint32_t epoch, uint32_t* err_word, uint32_t code) {
-    umoe_gu32* f = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(flag));
-    umoe_gu32* err = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(err_word));
-    const unsigned long long t0 = wall_clock64();
-    for (unsigned spins = 0;; ++spins) {
-        if ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) >= 0) break;
-        __builtin_amdgcn_s_sleep(1);
-        if ((spins & 1023u) == 1023u) {
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            if (wall_clock64() - t0 > 200000000ull) {      // 2 s
-                uint32_t zero = 0u;
-                __hip_atomic_compare_exchange_strong(err, &zero, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-}
-
-// diagnostics: thread 0 keeps up to 16 stamps in registers and stores them at exit (scalar branch on a kernel argument)
-// (the instrumented build only -- make tl, scripts/flat_timeline.py; the product kernel carries no stamp)
-#ifdef UMOE_TIMELINE
-struct flat_stamps { unsigned long long t[16]; };
-#define FSTAMP(k) do { if (A.dbg) st.t[k] = wall_clock64(); } while (0)
-#else
-struct flat_stamps {};
-#define FSTAMP(k) do { } while (0)
-#endif
-
-typedef uint32_t flat_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t flat_u32x2 __attribute__((ext_vector_type(2)));
-
-// ---- gate/up SwiGLU slice: NP pairs of the flat list starting at fp0 (arithmetic of wstream_body<14, 1, PLAIN, SWIGLU, 8> per tile) ----
-// The workgroup normalises the 16 rows ITSELF while it stages them (post-attention RMSNorm, model.py:240): the raw rows exist when the
-// launch starts, so nothing is waited for -- rows requested first, the weight stream right behind them, and the ~2 us of row arithmetic
-// hide under the first chunk's flight.  The sum of squares follows the router body's tree (umoe_router_dev.h router4_body: lane l of wave
-// h sums the 8 squares of chunk 64 h + l, xor-butterfly 32 .. 1, the four wave sums added in order), so the rows are bit-identical to
-// the rows the router launches write.  K = 2048 only (one staging round, thread (row m, sub) holds chunks sub and sub + 32 of a quarter).
-__device__ __forceinline__ uint32_t flat_epoch(const umoe_rider_pub& pub) {
-    // the step word lives in device memory: read it where it is first needed (a load the compiler may not hoist in front of the
-    // kernel's first weight request -- it was one more dependent scalar round trip there)
-    asm volatile("" ::: "memory");
-    return __builtin_nontemporal_load(pub.step) * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
-}
-
-template <int NP>
-__device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider_pub& pub, const int fp0, const unsigned b, char* smem, flat_stamps& st) {
-    constexpr int NT = 2 * NP, WV = 8, KB = 64;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: every guard around an MFMA is a scalar branch
-    constexpr int QS = (KB * 16 + 255) & ~255, RS = QS * 4;
-    const int i0 = __builtin_amdgcn_readfirstlane((KB * wave) / WV), i1 = __builtin_amdgcn_readfirstlane((KB * (wave + 1)) / WV);
-    // the slice straddles at most two groups (a group has far more than 7 pairs).  Every table read is a kernel-argument read with a
-    // compile-time offset + a scalar select: ONE batch of scalar loads in front of the first request, no dependent second one
-    int g0 = 0;
-#pragma unroll
-    for (int i = 1; i < FLAT_MAXG; ++i) g0 += (fp0 >= A.pair0[i] && i < A.G) ? 1 : 0;      // (pair0 ascends: the count IS the index)
-    const int p0 = A.pair0[g0], cut = A.pair0[g0 + 1];
-    const uint16_t *wg0 = A.w_gu[g0], *wg1 = A.w_gu[g0 + 1 < FLAT_MAXG ? g0 + 1 : g0];
-    const int g1 = min(g0 + 1, A.G - 1);      // pairs >= cut belong to group g1
-    f32x4_t acc[NT];
-    const flat_u32x4* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const int pp = fp0 + (t >> 1);
-        const bool second = pp >= cut;
-        const int lp = pp - (second ? cut : p0);
-        wp[t] = reinterpret_cast<const flat_u32x4*>(second ? wg1 : wg0) + ((size_t)(2 * lp + (t & 1)) * KB) * 64 + lane;
-    }
-    flat_u32x4 w0[NT], w1[NT];
-    auto load_chunk = [&](flat_u32x4 (&dst)[NT], int ii) {
-        const int ic = min(ii, i1 - 1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) dst[t] = __builtin_nontemporal_load(wp[t] + (size_t)ic * 64);
-    };
-    const int count = A.S;
-    // ---- rows first (they exist: the previous launch wrote them), then the weight stream; normalise while the chunk flies ----
-    {
-        constexpr int TPR = WV * 4;      // threads per row
-        const int m = tid / TPR, sub = tid % TPR;
-        const bool valid = m < count;
-        const uint16_t* src = A.a + (size_t)(valid ? m : 0) * A.lda;
-        char* dst = smem + m * RS;
-        char* nw_lds = smem + 16 * RS;
-        uint4 buf[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) buf[n] = ld16(src + ((n >> 1) * KB + sub + TPR * (n & 1)) * 8);
-        // (straight-line loads only: a branch around a load makes hipcc wait for vmcnt(0), i.e. for the weight chunk behind the rows)
-        const uint4 nw1 = ld16(A.norm_w + (tid & (4 * KB - 1)) * 8);
-        // (measured and rejected: BOTH register stages requested here.  A CU issues about 1 KiB of vector loads per 100 cycles, so the
-        //  second stage's 14 requests per wave only delayed the point where the rows are staged -- 8.6 -> 12.1 us -- and bought nothing:
-        //  3.020 vs 3.015 ms/step.  The launch runs at the CU's request rate from its first request on.)
-        __builtin_amdgcn_sched_barrier(0);
-        load_chunk(w0, i0);
-        __builtin_amdgcn_sched_barrier(0);
-        FSTAMP(1);
-        st16(nw_lds + (tid & (4 * KB - 1)) * 16, nw1);      // (both halves of the workgroup store the same 4 KiB)
-        float q4[4];
-#pragma unroll
-        for (int hq = 0; hq < 4; ++hq) {
-            float c2[2];
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                float f[8];
-                unpack8(buf[hq * 2 + k2], f);
-                float cs = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) cs += f[j] * f[j];
-                c2[k2] = cs;
-            }
-            float v = c2[0] + c2[1];
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-            q4[hq] = v;
-        }
-        const float ss = ((q4[0] + q4[1]) + q4[2]) + q4[3];
-        const float rs = rsqrtf(ss / (float)(KB * 32) + A.rms_eps);
-        __syncthreads();
-        FSTAMP(2);
-        // keep the row slice packed (32 registers) between the sum of squares and the scaling
-#pragma unroll
-        for (int n = 0; n < 8; ++n) asm volatile("" : "+v"(buf[n].x), "+v"(buf[n].y), "+v"(buf[n].z), "+v"(buf[n].w));
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int h = n >> 1, i = sub + TPR * (n & 1);
-            float f[8], w[8];
-            unpack8(buf[n], f);
-            unpack8(*reinterpret_cast<const uint4*>(nw_lds + (h * KB + i) * 16), w);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
-            if (valid) st16(dst + flat_lds_chunk_off(QS, h, i, m), pack8(f));
-        }
-    }
-    __syncthreads();
-    FSTAMP(3);
-    // ---- stream: 1-step chunks, double-buffered in registers, the 8 waves split K ----
-    const int h = lane >> 4, mm = lane & 15;
-    const char* bbase = smem + mm * RS;
-    auto compute_chunk = [&](const flat_u32x4 (&src)[NT], int ii) {
-        if (ii < i1) {
-            const uint4 bv = *reinterpret_cast<const uint4*>(bbase + flat_lds_chunk_off(QS, h, ii, mm));
-            const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, bv);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, src[t]), bfrag, acc[t], 0, 0, 0);
-        }
-    };
-    for (int i = i0; i < i1; i += 2) {
-        if (i + 1 < i1) load_chunk(w1, i + 1);
-        compute_chunk(w0, i);
-        if (i + 2 < i1) load_chunk(w0, i + 2);
-        if (i + 1 < i1) compute_chunk(w1, i + 1);
-    }
-    // ---- fixed-order cross-wave reduction through the (now free) staging area ----
-    FSTAMP(4);
-    __syncthreads();
-    FSTAMP(5);
-    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[t];
-    __syncthreads();
-    auto reduced = [&](int t) -> f32x4_t {
-        f32x4_t s = red[t * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < WV; ++w) {
-            const f32x4_t v = red[(w * NT + t) * 64 + lane];
-            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
-        }
-        return s;
-    };
-    // ---- SwiGLU epilogue: lane (h, mm) owns features 4h..4h+3 of row mm; pairs spread over the waves; write-through stores ----
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(A.h, 0, 0x7fffffff, 0x00020000);
-    for (int q = wave; q < NP; q += WV) {
-        const int pp = fp0 + q;
-        const int grp = pp >= cut ? g1 : g0;
-        const int col = (pp - A.pair0[grp]) * 16 + 4 * h;
-        const long orow = (long)A.h_row[grp] + mm;
-        const f32x4_t ga = reduced(2 * q), ua = reduced(2 * q + 1);
-        uint16_t yv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float gt = rbf(ga[j]);
-            const float up = rbf(ua[j]);
-            const float si = rbf(gt / (1.0f + expf(-gt)));
-            yv[j] = f2bf(si * up);
-        }
-        const flat_u32x2 v2 = {(uint32_t)yv[0] | ((uint32_t)yv[1] << 16), (uint32_t)yv[2] | ((uint32_t)yv[3] << 16)};
-        if (mm < count) __builtin_amdgcn_raw_buffer_store_b64(v2, orsrc, (int)((orow * A.ldh + col) * 2), 0, 16);
-    }
-    // publish: every storing wave drains, the workgroup meets, one lane raises this workgroup's flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-        __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(A.flags + b)), flat_epoch(pub), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    FSTAMP(6);
-}
-
-// ---- down-projection slice: blocks [nb0, nb0 + ND) of group grp (arithmetic of wstream_body<6, 2, PLAIN, BF16, 8> per tile) ----
-// U = 2 for an even number of k-steps (whole 2-step chunks per wave), U = 1 for an odd one: the K split of the 2-step launch does not
-// depend on U then, and a 1-step stream has no clamped duplicate step at the end of a wave's slice.
-template <int ND, int U>
-__device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_pub& pub, const int grp, const int nb0, char* smem, flat_stamps& st,
-                                          const int sb) {
-    constexpr int NT = ND, WV = 8;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int KB = A.dn_kb[grp];
-    const int QS = (KB * 16 + 255) & ~255, RS = QS * 4;
-    int i0, i1;
-    if (KB % 2 == 0) {      // whole 2-step chunks per wave when the slice divides (U == 2 here)
-        const int units = KB / 2;
-        i0 = 2 * ((units * wave) / WV);
-        i1 = 2 * ((units * (wave + 1)) / WV);
-    } else {
-        i0 = (KB * wave) / WV;
-        i1 = (KB * (wave + 1)) / WV;
-    }
-    i0 = __builtin_amdgcn_readfirstlane(i0);
-    i1 = __builtin_amdgcn_readfirstlane(i1);
-    f32x4_t acc[NT];
-    const flat_u32x4* wp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        wp[t] = reinterpret_cast<const flat_u32x4*>(A.w_dn[grp]) + ((size_t)(nb0 + t) * KB) * 64 + lane;
-    }
-    flat_u32x4 w0[NT][U], w1[NT][U];
-    auto load_chunk = [&](flat_u32x4 (&dst)[NT][U], int ibase) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ii = min(ibase + u, i1 - 1);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) dst[t][u] = __builtin_nontemporal_load(wp[t] + (size_t)ii * 64);
-        }
-    };
-    if (i0 < i1) load_chunk(w0, i0);
-    const int count = A.S;
-    // wait for the workgroups of THIS launch that produced this group's rows: lane i of wave 0 polls producer i (bounded)
-    if (tid < A.prod_n[grp]) flat_wait(A.flags + A.prod_base[grp] + tid, flat_epoch(pub), pub.err, 3u);
-    __syncthreads();
-    FSTAMP(sb);
-    {
-        constexpr int TPR = WV * 4;
-        const int m = tid / TPR, sub = tid % TPR;
-        const bool valid = m < count;
-        const long arow = (long)A.dn_a_row[grp] + (valid ? m : 0);
-        char* dst = smem + m * RS;
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(A.h, 0, 0x7fffffff, 0x00020000);
-        for (int ib0 = 0; ib0 < KB; ib0 += 4 * TPR) {
-            uint4 buf[16];
-#pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                const int h = n >> 2, i = min(ib0 + sub + TPR * (n & 3), KB - 1);
-                const flat_u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((arow * A.ldh + (h * KB + i) * 8) * 2), 0, 16);
-                buf[n] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-            }
-            if (ib0 == 0) {     // the second register stage right behind the rows (returns: first stage, rows, second stage)
-                __builtin_amdgcn_sched_barrier(0);
-                if (i0 + U < i1) load_chunk(w1, i0 + U);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                const int h = n >> 2, i = ib0 + sub + TPR * (n & 3);
-                if (valid && i < KB) st16(dst + flat_lds_chunk_off(QS, h, i, m), buf[n]);
-            }
-        }
-    }
-    __syncthreads();
-    FSTAMP(sb + 1);
-    const int h = lane >> 4, mm = lane & 15;
-    const char* bbase = smem + mm * RS;
-    auto compute_chunk = [&](const flat_u32x4 (&src)[NT][U], int ibase) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ii = ibase + u;
-            if (ii < i1) {
-                const uint4 bv = *reinterpret_cast<const uint4*>(bbase + flat_lds_chunk_off(QS, h, ii, mm));
-                const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, bv);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, src[t][u]), bfrag, acc[t], 0, 0, 0);
-            }
-        }
-    };
-    for (int i = i0; i < i1; i += 2 * U) {
-        if (i + U < i1 && i != i0) load_chunk(w1, i + U);
-        compute_chunk(w0, i);
-        if (i + 2 * U < i1) load_chunk(w0, i + 2 * U);
-        if (i + U < i1) compute_chunk(w1, i + U);
-    }
-    FSTAMP(sb + 2);
-    __syncthreads();
-    FSTAMP(sb + 3);
-    f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) red[(wave * NT + t) * 64 + lane] = acc[t];
-    __syncthreads();
-    if (mm >= count) return;
-    // tile t is finished by wave t % 8
-    for (int t = wave; t < NT; t += WV) {
-        f32x4_t s = red[t * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < WV; ++w) {
-            const f32x4_t v = red[(w * NT + t) * 64 + lane];
-            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
-        }
-        const int n = (nb0 + t) * 16 + 4 * h;
-        uint16_t yv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) yv[j] = f2bf(rbf(s[j] + 0.f));      // (+ 0.f: the bias slot of the generic epilogue; -0 -> +0 like there)
-        uint16_t* o = A.y + ((long)A.dn_y_row[grp] + mm) * A.ldy + n;
-        *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)yv[0] | ((uint32_t)yv[1] << 16), (uint32_t)yv[2] | ((uint32_t)yv[3] << 16));
-    }
-}
+#include "umoe_flat_dev.h"
 
 #define FLAT_RIDER_LDS 512      // bytes of LDS behind the GEMM area for the riders' partial sums (router4_body: 4 + 4 * 16 floats)
 
