@@ -188,8 +188,6 @@ typedef struct {
     long part_stride;         /* elements between fp32 partial slabs */
     const umoe_group_t* groups_host; /* optional HOST copy of `groups`: with num_groups <= UMOE_GROUPS_INLINE the
                                * descriptors travel in the kernel arguments (one dependent HBM round trip less per launch) */
-    int flat_wgs;             /* SwiGLU, static groups over the same <= 16 rows (dense-expert decode): > 0 = that many workgroups
-                               * take equal slices of ALL groups' gate/up pairs (<= 7 each; per-CU byte balance) */
     int cache_policy;         /* reserved (0): the weight stream is always non-temporal -- a default-policy variant and an
                                * Infinity Cache warm-up were measured and bought nothing */
     const umoe_router_args* fused_router; /* optional HOST pointer (SwiGLU, nt = 14, <= 16 rows, n_dyn 9 / n_fix 2, D 2048 / 4096, S <= 16):
@@ -496,14 +494,6 @@ typedef struct {
     int sec0, sec1, sec2;
     float* lse_out;           /* optional (umoe_attn_prefill_fwd, MFMA path): log-sum-exp per (query, head) [rows*nq][H], +inf for
                                * queries that see no key; kept for umoe_attn_prefill_bwd */
-    int32_t* sync;            /* optional (umoe_attn_decode): [rows*nq][KVH] counters, ZERO before the first call.  When set, the
-                               * last key split of a (query, kv head) to finish merges the partials itself and the combine
-                               * launch disappears; the counters are zero again when the call completes */
-    int defer_merge;          /* umoe_attn_decode: 1 = leave the split partials (part_o / part_ml) unmerged -- the caller merges them
-                               * (decode engine: the merge rides in the o_proj launch) */
-    int wide;                 /* umoe_attn_decode with qkv_raw (nq == 1, GQA group of 8): 1 = 8-wave workgroups, two per (row, kv head) with
-                               * four query heads each, split the keys over their WAVES and write `out` themselves (splits / part_o /
-                               * part_ml unused, no key split across workgroups, no merge launch) */
 } umoe_attn_args;
 int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream);
 /* causal prefill (nq = T queries per row) over keys already appended by umoe_qkv_mrope_kvappend */

@@ -218,12 +218,6 @@ if "flat" in which:
     for nt in (8, 14):
         t = timeit(lambda i: ops.grouped_gemm(sets[i % R][0], x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=nt))
         print("dense gateup nt", nt, f"{t:.2f} us  {gub/t/1e3:.0f} GB/s", flush=True)
-    for fw in (256, 224, 240, 512):
-        try:
-            t = timeit(lambda i: ops.grouped_gemm(sets[i % R][0], x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=14, flat_wgs=fw))
-            print("dense gateup FLAT wgs", fw, f"{t:.2f} us  {gub/t/1e3:.0f} GB/s", flush=True)
-        except Exception as ex:
-            print("flat", fw, "rejected:", str(ex)[:90])
     for nt, wv in ((8, 8), (6, 8), (5, 8)):
         t = timeit(lambda i: ops.grouped_gemm(sets[i % R][1], hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D, nt=nt, waves=wv))
         print("dense down nt", nt, "waves", wv, f"{t:.2f} us  {dnb/t/1e3:.0f} GB/s", flush=True)

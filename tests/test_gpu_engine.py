@@ -477,21 +477,17 @@ def test_router_riding_in_the_gate_up_launch_is_bit_identical(dev, monkeypatch):
     ids, am, codec = prompt(cfg, B, T, 4, [1] + [0] * (2 * B - 1))
     pre, psteps = prepare_audio_prompt(cfg, [None] * B)
     outs = []
-    # (fourth / fifth variant: the hand-off off; the gate/up workgroups normalising x1 themselves, umoe_engine.hip gu_norm)
-    # sixth: gate/up and down as two launches instead of the fused expert launch (umoe_moe_fused), which the default (third) uses
-    # seventh / eighth: the combine and the attention split merge as launches of their own instead of riding in the QKV / o_proj launches
-    # ninth: the fused expert launch with the riders handing over normalised ROWS (the default hands over the rows' scales only)
-    for fuse, mode, pub, gun, fm, cq, ao, rsh in (("0", "0", "1", "0", "1", "1", "1", "1"), ("1", "1", "1", "0", "1", "1", "1", "1"), ("1", "0", "1", "0", "1", "1", "1", "1"),
-                                                  ("1", "0", "0", "0", "1", "1", "1", "1"), ("1", "0", "1", "1", "1", "1", "1", "1"), ("1", "0", "1", "0", "0", "1", "1", "1"),
-                                                  ("1", "0", "1", "0", "1", "0", "1", "1"), ("1", "0", "1", "0", "1", "1", "0", "1"), ("1", "0", "1", "0", "1", "1", "0", "0")):
-        monkeypatch.setenv("UMOE_RS_HANDOFF", rsh)
+    # fourth: the hand-off off (RMSNorm launch in front, gate/up and down as plain launches); fifth: gate/up and down as two launches
+    # instead of one expert launch; sixth: the combine as a launch of its own instead of riding in the next layer's QKV launch;
+    # seventh: the box-grid fused expert launch instead of the flat one
+    for fuse, mode, pub, fm, cq, flat in (("0", "0", "1", "1", "1", "1"), ("1", "1", "1", "1", "1", "1"), ("1", "0", "1", "1", "1", "1"), ("1", "0", "0", "1", "1", "1"),
+                                          ("1", "0", "1", "0", "1", "1"), ("1", "0", "1", "1", "0", "1"), ("1", "0", "1", "1", "1", "0")):
         monkeypatch.setenv("UMOE_FUSE_CQ", cq)
-        monkeypatch.setenv("UMOE_FUSE_AO", ao)
         monkeypatch.setenv("UMOE_FUSE_MOE", fm)
         monkeypatch.setenv("UMOE_FUSE_ROUTER", fuse)
         monkeypatch.setenv("UMOE_RIDER_MODE", mode)
         monkeypatch.setenv("UMOE_RIDER_PUB", pub)
-        monkeypatch.setenv("UMOE_GU_NORM", gun)
+        monkeypatch.setenv("UMOE_FLAT_MOE", flat)
         m, _ = build(cfg, 31, 0.03)
         m = m.to(dev)
         dec = DecoderOutput(pre.clone(), psteps, dev)

@@ -67,15 +67,11 @@ def _save(key, rec):
     json.dump(allr, open(RESULTS, "w"), indent=1)
 
 
-@pytest.mark.parametrize("B,ragged,attn", [(8, False, "default"), (1, False, "default"), (1, True, "default"), (1, False, "other")])
-def test_full_depth_teacher_forced_decode_vs_oracle(full_model, B, ragged, attn, monkeypatch):
+@pytest.mark.parametrize("B,ragged", [(8, False), (1, False), (1, True)])
+def test_full_depth_teacher_forced_decode_vs_oracle(full_model, B, ragged, monkeypatch):
     """B = 8: 16 CFG rows, dense-expert layout with the router riders and the fused expert launch (BASELINE configs[1]); B = 1: 2 rows
-    (configs[0]), in the dense layout (the default from 2 rows) and through the ragged dispatch tables (UMOE_DENSE_MIN_ROWS=6).
-    attn "other": the decode attention form that is NOT the engine's default (UMOE_ATTN_WIDE flipped: keys split over the waves of
-    one workgroup vs 8 key-split workgroups + merge launch), so both forms stay under the full-depth bounds."""
+    (configs[0]), in the dense layout (the default from 2 rows) and through the ragged dispatch tables (UMOE_DENSE_MIN_ROWS=6)."""
     monkeypatch.setenv("UMOE_DENSE_MIN_ROWS", "6" if ragged else "2")
-    if attn == "other":
-        monkeypatch.setenv("UMOE_ATTN_WIDE", "0" if ATTN_WIDE_DEFAULT else "1")
     from oracle import decode as OD
     from unimoe_audio_amd.codec_utils import prepare_audio_prompt
     from unimoe_audio_amd.model import DecodeEngine
@@ -181,7 +177,7 @@ def test_full_depth_teacher_forced_decode_vs_oracle(full_model, B, ragged, attn,
                                 "router_mask_agree_by_depth": [round(float(mask_rows[i:i + 6].mean()), 4) for i in range(0, Lyr, 6)],
                                 "rows_identical_routing_all_layers": int(sum(1 for f in first_bad if f == Lyr))})
     print("\nFULL-DEPTH PARITY", json.dumps(rec))
-    _save(f"batch{B}" + ("_ragged" if ragged else "") + ("" if attn == "default" else ("_attn_split" if ATTN_WIDE_DEFAULT else "_attn_wide")), rec)
+    _save(f"batch{B}" + ("_ragged" if ragged else ""), rec)
     med = max(p["logit_rel_median"] for p in rec["per_step"])
     mx = max(p["logit_rel_max"] for p in rec["per_step"])
     agree = min(p["argmax_agree"] for p in rec["per_step"])
@@ -200,7 +196,6 @@ def test_full_depth_teacher_forced_decode_vs_oracle(full_model, B, ragged, attn,
 # 0.885-0.896, router masks 0.863-0.894 of (layer, row) pairs identical (0.93 in the first six layers, 0.83-0.86 from layer 12 on:
 # every flipped near-tie sends a row through another expert and the difference travels on); bounds = that + margin
 BOUNDS = {"med": 0.09, "max": 0.20, "argmax": 0.82, "mask": 0.80}
-ATTN_WIDE_DEFAULT = False      # the engine's default decode attention (umoe_engine.hip: attn_wide)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------------

@@ -660,70 +660,6 @@ def test_rope_attention_prefill_and_decode(dev):
         assert float(dk.norm() / kref.float()[sel].norm()) < 2 ** -7 and float(dk.abs().max()) < 0.07
 
 
-@pytest.mark.parametrize("rows,H,KVH,L,splits", [(16, 16, 2, 550, 8), (3, 16, 2, 37, 4), (5, 8, 8, 130, 8), (2, 4, 1, 300, 3),
-                                                 (16, 16, 2, 1, 8)])
-def test_attention_decode_single_launch_merge(dev, rows, H, KVH, L, splits):
-    """umoe_attn_args.sync: the last key split to finish merges the partials in the same launch -- bit-identical to the
-    attention + combine pair (same arithmetic, same order), also on repeated calls over the same counters."""
-    from unimoe_audio_amd import ops
-    hd, Lmax = 128, ((L + 80) // 64) * 64
-    g = torch.Generator().manual_seed(5 + rows + L)
-    kc = (torch.randn(rows, KVH, Lmax, hd, generator=g) * 0.5).to(torch.bfloat16).to(dev)
-    vc = (torch.randn(rows, KVH, Lmax, hd, generator=g) * 0.5).to(torch.bfloat16).to(dev)
-    q = torch.randn(rows, H * hd, generator=g).to(torch.bfloat16).to(dev)
-    kv_start = torch.randint(0, max(L // 3, 1), (rows,), generator=g).to(torch.int32).to(dev)
-    q0 = torch.full((rows,), L - 1, dtype=torch.int32, device=dev)
-    ref = ops.attention(q, kc, vc, kv_start, q0, 1, H, splits=splits)
-    sync = torch.zeros((rows, KVH), dtype=torch.int32, device=dev)
-    for _ in range(3):
-        got = ops.attention(q, kc, vc, kv_start, q0, 1, H, splits=splits, single_launch=sync)
-        assert torch.equal(got, ref)
-        assert int(sync.abs().sum()) == 0          # the counters are zero again after every call
-
-
-@pytest.mark.parametrize("rows,L", [(16, 315), (16, 814), (3, 37), (5, 130), (2, 1), (4, 16), (16, 3300)])
-def test_attention_decode_wide_vs_split_path(dev, rows, L):
-    """umoe_attn_args.wide: 8-wave workgroups (two per (row, kv head), four query heads each) split the keys over their WAVES and write
-    the output row themselves -- no partials, no merge launch.  Checked against the 8-split attention + combine pair on the same raw
-    QKV rows (fused mRoPE + KV append in both): the appended K / V are bit-identical, the outputs agree to fp32 summation order
-    (different partition of the softmax), and both sit equally close to an fp64 softmax over the same cache."""
-    from unimoe_audio_amd import ops
-    H, KVH, hd = 16, 2, 128
-    Lmax = ((L + 80) // 64) * 64
-    g = torch.Generator().manual_seed(31 + rows + L)
-    kc = (torch.randn(rows, KVH, Lmax, hd, generator=g) * 0.5).to(torch.bfloat16).to(dev)
-    vc = (torch.randn(rows, KVH, Lmax, hd, generator=g) * 0.5).to(torch.bfloat16).to(dev)
-    qkv = (torch.randn(rows, (H + 2 * KVH) * hd, generator=g) * 0.7).to(torch.bfloat16).to(dev)
-    kv_start = torch.randint(0, max(L // 3, 1), (rows,), generator=g).to(torch.int32).to(dev)
-    q0 = torch.full((rows,), L - 1, dtype=torch.int32, device=dev)          # slot of the new token: L - 1 cached keys before it
-    cos_tab, sin_tab = ops.rope_tables(Lmax + 8, hd, 1e6, dev)
-    p3 = torch.stack([q0, q0 + 1, q0 - torch.minimum(q0, torch.tensor(2, device=dev, dtype=torch.int32))]).to(torch.int32).contiguous()
-    kw = dict(qkv_raw=qkv, cos_tab=cos_tab, sin_tab=sin_tab, pos3=p3, sections=(16, 24, 24))
-    k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
-    ref = ops.attention(None, k1, v1, kv_start, q0, 1, H, splits=8, **kw)
-    got = ops.attention(None, k2, v2, kv_start, q0, 1, H, splits=1, wide=1, **kw)
-    assert torch.equal(k1, k2) and torch.equal(v1, v2)                       # the same roped K / raw V landed in slot L - 1
-    assert not torch.equal(k1, kc)
-    assert torch.allclose(got.float(), ref.float(), rtol=2 ** -7, atol=2 ** -9)
-    # fp64 softmax over the cache the kernels produced (the query = the roped q of the split path's separate rope kernel)
-    kvp = q0.clone()
-    k3, v3 = kc.clone(), vc.clone()
-    q = ops.qkv_mrope_kvappend(qkv, cos_tab, sin_tab, p3, kvp, 1, H, KVH, hd, (16, 24, 24), k3, v3)
-    assert torch.equal(k3, k1)
-    qd = q.double().reshape(rows, KVH, H // KVH, hd).cpu()
-    kd, vd = k1.double().cpu(), v1.double().cpu()
-    exact = torch.zeros(rows, KVH, H // KVH, hd, dtype=torch.float64)
-    for r in range(rows):
-        lo = int(kv_start[r])
-        sc = torch.einsum("kgd,kld->kgl", qd[r], kd[r, :, lo:L]) * hd ** -0.5
-        exact[r] = torch.einsum("kgl,kld->kgd", torch.softmax(sc, -1), vd[r, :, lo:L])
-    exact = exact.reshape(rows, H * hd)
-    e_w = float((got.double().cpu() - exact).norm() / exact.norm())
-    e_s = float((ref.double().cpu() - exact).norm() / exact.norm())
-    print(f"\nWIDE ATTENTION rows {rows} L {L}: rel. error vs fp64 softmax wide {e_w:.2e} split {e_s:.2e}")
-    assert e_w < 2 ** -8 and e_w < 1.5 * e_s + 1e-4
-
-
 def test_gemm256_forced_in_child_process():
     """The 256 x 256 ping-pong GEMM is chosen by size; UMOE_TGEMM_PP=1 forces it for EVERY tiled GEMM.  Re-run the GEMM,
     ragged / SwiGLU, block-backward and backward-kernel tests with it forced (small and odd shapes: partial tiles, K tails,
@@ -977,27 +913,6 @@ def test_ep_all_to_all_rccl_single_rank(dev):
     comm.close()
 
 
-@pytest.mark.parametrize("fw", [256, 231, 512])
-def test_dense_gateup_flat_slices_equal_per_group_grid(dev, fw):
-    """Flat mode of the decode gate/up launch (equal slices of all groups' pairs per workgroup, slices straddling two
-    groups) must be bit-identical to the per-group grid: same kernel arithmetic, only the work assignment changes."""
-    from unimoe_audio_amd import ops
-    gen = torch.Generator().manual_seed(21)
-    S, D, Id, Is = 16, 2048, 2752, 1376
-    x = (torch.randn(S, D, generator=gen) * 1.0).to(torch.bfloat16).to(dev)
-    sizes = [Id] * 8 + [Is] * 2
-    groups = []
-    for e, I in enumerate(sizes):
-        wg = (torch.randn(I, D, generator=gen) * 0.03).to(torch.bfloat16).to(dev)
-        wu = (torch.randn(I, D, generator=gen) * 0.03).to(torch.bfloat16).to(dev)
-        groups.append(dict(w=ops.pack_gate_up(wg, wu), static_count=S, out_row_base=e * S, n_blocks=2 * I // 16, k=D))
-    tab = ops.GroupTable(groups, dev)
-    a = torch.zeros(10 * S, Id, dtype=torch.bfloat16, device=dev)
-    b = torch.zeros_like(a)
-    ops.grouped_gemm(tab, x, a, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=14)
-    ops.grouped_gemm(tab, x, b, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=Id, nt=14, flat_wgs=fw)
-    assert torch.equal(a, b)
-    assert float(a[:8 * S].float().abs().sum()) > 0 and float(a[8 * S:, :Is].float().abs().sum()) > 0
 
 
 @pytest.mark.parametrize("weighted,bf16", [(False, True), (True, True), (False, False)])

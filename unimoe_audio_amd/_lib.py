@@ -47,7 +47,7 @@ class Group(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("groups", vp), ("num_groups", i32), ("max_rows", i32), ("max_n_blocks", i32), ("max_k", i32),
                 ("a", vp), ("lda", i32), ("norm_w", vp), ("rms_eps", f32), ("resid", vp), ("out", vp), ("ldo", i32),
-                ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32), ("waves", i32), ("ksplit", i32), ("part_stride", C.c_long), ("groups_host", vp), ("flat_wgs", i32), ("cache_policy", i32), ("fused_router", vp), ("rider_pub", vp)]
+                ("n_valid", i32), ("prologue", i32), ("epilogue", i32), ("nt", i32), ("waves", i32), ("ksplit", i32), ("part_stride", C.c_long), ("groups_host", vp), ("cache_policy", i32), ("fused_router", vp), ("rider_pub", vp)]
 
 
 class TGroup(C.Structure):
@@ -91,7 +91,7 @@ class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("k_cache", vp), ("v_cache", vp), ("kv_start", vp), ("q_pos0", vp), ("rows", i32),
                 ("nq", i32), ("H", i32), ("KVH", i32), ("hd", i32), ("Lmax", i32), ("splits", i32), ("scale", f32),
                 ("part_o", vp), ("part_ml", vp), ("out", vp), ("qkv_raw", vp), ("cos_tab", vp), ("sin_tab", vp), ("pos3", vp),
-                ("sec0", i32), ("sec1", i32), ("sec2", i32), ("lse_out", vp), ("sync", vp), ("defer_merge", i32), ("wide", i32)]
+                ("sec0", i32), ("sec1", i32), ("sec2", i32), ("lse_out", vp)]
 
 
 class SampleArgs(C.Structure):

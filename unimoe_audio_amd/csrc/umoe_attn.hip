@@ -124,64 +124,6 @@ __device__ __forceinline__ void rope32(const uint16_t* head_raw, int h4, const u
     }
 }
 
-// Merge of the key splits of one (query, kv head) by the LAST split workgroup to finish (a.sync): 256 threads, thread ->
-// (head of the group = tid >> 5, 4 value columns); every partial is requested before the first use (they were written by
-// other XCDs: each dependent load would be a trip to the Infinity Cache).  Same arithmetic and order as attn_combine_kernel.
-__device__ __forceinline__ float cld(const float* p) {   // agent-coherent load (sc1): never served from this XCD's stale L2 line
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <int SP>
-__device__ __forceinline__ void merge_splits_tail(const umoe_attn_args& a, const int qi, const int kvh, const int G, const int tid) {
-    constexpr int HD = 128;
-    const int splits = SP > 0 ? SP : a.splits;
-    const int d4 = (tid & 31) * 4;
-    for (int g = tid >> 5; g < G; g += 8) {
-        const int head = kvh * G + g;
-        const float* pm = a.part_ml + ((size_t)qi * a.H + head) * splits * 2;
-        const float* po = a.part_o + ((size_t)qi * a.H + head) * splits * HD + d4;
-        float L = 0.f;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (SP > 0) {
-            float2 ml[SP > 0 ? SP : 1];
-            float4 ov[SP > 0 ? SP : 1];
-#pragma unroll
-            for (int s = 0; s < SP; ++s) {
-                ml[s].x = cld(pm + 2 * s);
-                ml[s].y = cld(pm + 2 * s + 1);
-                const float* pp = po + (size_t)s * HD;
-                ov[s] = make_float4(cld(pp), cld(pp + 1), cld(pp + 2), cld(pp + 3));
-            }
-            float mm = -INFINITY;
-#pragma unroll
-            for (int s = 0; s < SP; ++s) mm = fmaxf(mm, ml[s].x);
-#pragma unroll
-            for (int s = 0; s < SP; ++s) {
-                const float sc = (ml[s].x == -INFINITY) ? 0.f : __expf(ml[s].x - mm);
-                L += sc * ml[s].y;
-                acc[0] += sc * ov[s].x; acc[1] += sc * ov[s].y; acc[2] += sc * ov[s].z; acc[3] += sc * ov[s].w;
-            }
-        } else {
-            float mm = -INFINITY;
-            for (int s = 0; s < splits; ++s) mm = fmaxf(mm, cld(pm + 2 * s));
-            for (int s = 0; s < splits; ++s) {
-                const float ms = cld(pm + 2 * s);
-                const float sc = (ms == -INFINITY) ? 0.f : __expf(ms - mm);
-                L += sc * cld(pm + 2 * s + 1);
-                const float* pp = po + (size_t)s * HD;
-                const float4 ov = make_float4(cld(pp), cld(pp + 1), cld(pp + 2), cld(pp + 3));
-                acc[0] += sc * ov.x; acc[1] += sc * ov.y; acc[2] += sc * ov.z; acc[3] += sc * ov.w;
-            }
-        }
-        uint16_t r[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = f2bf(L > 0.f ? acc[j] / L : 0.f);
-        uint2 pk;
-        pk.x = (uint32_t)r[0] | ((uint32_t)r[1] << 16);
-        pk.y = (uint32_t)r[2] | ((uint32_t)r[3] << 16);
-        *reinterpret_cast<uint2*>(a.out + ((size_t)qi * a.H + head) * HD + d4) = pk;
-    }
-}
-
 // hd == 128 only (4 MFMA k-steps; lane owns 2 value columns).  GP = GQA group size padded to a power of two.
 // With a.qkv_raw set (decode, nq == 1) the kernel also applies mRoPE and appends the new K/V to the cache.
 template <int GP>
@@ -405,7 +347,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
         const int head = kvh * G + g;
         float* po = a.part_o + (((size_t)qi * a.H + head) * a.splits + split) * HD + cg * 8;
         float* pm = a.part_ml + (((size_t)qi * a.H + head) * a.splits + split) * 2;
-        if (a.splits == 1 && !a.sync) {
+        if (a.splits == 1) {
             // one key split: this workgroup holds the whole softmax -- the merge of umoe_attn_combine over ONE partial is o / l
             // (its scale exp(m - m) is exactly 1), so the output is written here and the combine launch is skipped
             uint16_t y[8];
@@ -414,13 +356,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
             st16(a.out + ((size_t)qi * a.H + head) * HD + cg * 8,
                  make_uint4((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16),
                             (uint32_t)y[4] | ((uint32_t)y[5] << 16), (uint32_t)y[6] | ((uint32_t)y[7] << 16)));
-        } else if (a.sync) {   // agent-coherent (write-through, sc1) stores: read by a workgroup on another XCD in this same launch
-#pragma unroll
-            for (int j = 0; j < 8; ++j) __hip_atomic_store(po + j, acc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cg == 0) {
-                __hip_atomic_store(pm, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pm + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) po[j] = acc[j];
@@ -430,288 +365,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const umoe_attn_args a) {
             }
         }
     }
-    if (a.sync) {
-        // one launch instead of two: every split writes its partials through to the coherence point and takes a ticket; the
-        // workgroup that draws the last ticket of its (query, kv head) merges.  One writer per output element and a fixed
-        // summation order (split 0..SP-1), whichever workgroup happens to be last -> results do not depend on the schedule.
-        // No agent-scope fence: `buffer_wbl2` / `buffer_inv` per wave walk the whole L2 (measured: +37 us per layer); the
-        // partials travel as relaxed agent-scope atomics (sc1 stores / loads) instead, and __syncthreads() (a workgroup
-        // release: vscnt(0)) orders them before the ticket.
-        __shared__ int last_flag;
-        __syncthreads();
-        if (tid == 0) {
-            int* ctr = a.sync + (size_t)qi * a.KVH + kvh;
-            const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == a.splits - 1;
-            if (last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-            last_flag = last;
-        }
-        __syncthreads();
-        if (last_flag) {
-            if (a.splits == 8) merge_splits_tail<8>(a, qi, kvh, G, tid);
-            else if (a.splits == 4) merge_splits_tail<4>(a, qi, kvh, G, tid);
-            else merge_splits_tail<0>(a, qi, kvh, G, tid);
-        }
-    }
-    TL_EXIT(7);
-}
-
-// ---- decode attention without a key split across workgroups (umoe_attn_args.wide) ---------------------------------------------------
-// ONE 8-wave workgroup per (row, kv head, slice of GPW query heads): the key range is split over the WAVES of the workgroup (wave w < 7
-// takes the 16-key tiles w, w + 7, ..., wave 7 the new token; two or three tiles in flight per wave: 256 / 384 keys requested in one round trip), the waves'
-// partial softmaxes meet in LDS, and the output row is written by the launch itself -- no partials in memory and no merge launch
-// (attn_kernel + attn_combine_kernel: two dependent launches and 1 MB of fp32 partials per layer for ~5 MB of K / V).  What bounds
-// it instead is the K / V intake of one CU (161 KB per kv head at 315 cached tokens), so every K / V load is a 16-byte load: a lane
-// holds 8 value columns of 4 keys (the 4-byte column loads of attn_kernel take ~3x the address-path time per byte), its partial
-// output covers those 4 keys only, and the sum over the four key quarters of a tile is folded into the cross-wave merge.
-// GPW = 4 query heads per workgroup: two workgroups per kv head of the 8-head GQA group (K / V requested twice -- 10 MB instead of 5 MB
-// per layer beside 304 MB of expert weights -- and half the P.V work each; GPW = 8 spills: see umoe_attn_decode).
-// Decode only: nq == 1, fused mRoPE + KV append (qkv_raw), G == 8, hd == 128.
-template <int GPW>
-__global__ __launch_bounds__(512) void attn_wide_kernel(const umoe_attn_args a) {
-    constexpr int HD = 128, NW = 8, PS = 20;              // PS: p_lds row stride in floats (80 B: the four key quarters hit disjoint banks)
-    constexpr int ND = 2, NWT = NW - 1;                   // register tiles per wave = one softmax batch of ND * 16 keys (3 tiles spill: 104
-                                                          // registers to scratch, reloaded around the MFMAs); waves that walk the cache
-    extern __shared__ __attribute__((aligned(16))) char smem_w[];
-    float* red_o = reinterpret_cast<float*>(smem_w);      // [NW][4 key quarters][GPW][HD]
-    float* p_lds = red_o + NW * 4 * GPW * HD;             // [NW][48 keys of a batch][PS]
-    float* al_lds = p_lds + NW * 48 * PS;                 // [NW][16]
-    float* red_ml = al_lds + NW * 16;                     // [NW][16][2]
-    TL_ENTER(7);
-    const int G = a.H / a.KVH;
-    const int hsn = G / GPW;
-    const int kvh = (int)blockIdx.x / hsn, hs = (int)blockIdx.x - kvh * hsn;
-    const int qi = blockIdx.y, row = qi;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (guards around MFMAs must be scalar branches)
-    const int h4 = lane >> 4, c = lane & 15;
-    const int head0 = kvh * G + hs * GPW;
-    const int ntok = a.rows;
-    const int p0 = a.pos3[qi], p1 = a.pos3[ntok + qi], p2 = a.pos3[2 * ntok + qi];
-    const int kbeg = a.kv_start[row];
-    const int kend = a.q_pos0[row];                       // exclusive: slot of the new token, which is taken from the raw QKV row
-    const int ntile = __builtin_amdgcn_readfirstlane((max(kend - kbeg, 0) + 15) >> 4);
-    const uint16_t* Kc = a.k_cache + ((size_t)row * a.KVH + kvh) * a.Lmax * HD;
-    const uint16_t* Vc = a.v_cache + ((size_t)row * a.KVH + kvh) * a.Lmax * HD;
-    const int QKV_LD = (a.H + 2 * a.KVH) * HD;
-    struct tile_t { uint4 k[4], v[4]; };
-    // unconditional, clamped loads (a tile past the range re-reads the last key: cache hits, masked below) -- straight-line code, so
-    // the compiler counts the loads and a tile is consumed while the younger ones are still in flight
-    auto load_tile_k = [&](tile_t& t, const int j) {
-        const uint16_t* kp = Kc + (size_t)max(min(kbeg + 16 * j + c, kend - 1), 0) * HD + h4 * 32;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) t.k[kb] = ld16(kp + kb * 8);
-    };
-    auto load_tile_v = [&](tile_t& t, const int j) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t.v[r] = ld16(Vc + (size_t)max(min(kbeg + 16 * j + 4 * h4 + r, kend - 1), 0) * HD + c * 8);
-    };
-    auto load_tile = [&](tile_t& t, const int j) {
-        load_tile_k(t, j);
-        load_tile_v(t, j);
-    };
-    tile_t t0, t1, t2;
-    bf16x8_t qf[4];
-    float m_run = -INFINITY, l_run = 0.f;                 // of head c (replicated over the key quarters)
-    float o[GPW][8];                                      // heads x this lane's 8 value columns, over this lane's key quarter
-#pragma unroll
-    for (int g = 0; g < GPW; ++g)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[g][j] = 0.f;
-    float* pw = p_lds + wave * (ND * 16) * PS;
-    float* aw = al_lds + wave * 16;
-    // ONE online-softmax step over the three register tiles (48 keys): three independent MFMA chains, one max / sum reduction, one
-    // trip through LDS for the probabilities, one rescale of the accumulators -- per 16-key tile that serial chain (4 dependent
-    // MFMAs, 4 cross-row shuffles, LDS write -> read) cost ~1.4 us per tile and wave, which made the launch slower than the
-    // key-split pair from 300 keys on (scripts/attn_bench.py).  Tiles past the key range are masked (p = 0) and carry finite values.
-    // `refill`: the next batch's K is requested right behind the MFMAs, each tile's V right behind its P.V.
-    auto process_batch = [&](const int k0a, const int k0b, const int k0c, const int kend_t, const bool refill, const int jn) {
-        f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, sb = sa, sc = sa;     // S[key = 4 h4 + r][head = c] of the three tiles
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, t0.k[kb]), qf[kb], sa, 0, 0, 0);
-            sb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, t1.k[kb]), qf[kb], sb, 0, 0, 0);
-            if constexpr (ND == 3) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, t2.k[kb]), qf[kb], sc, 0, 0, 0);
-        }
-        float sv[3][4];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sv[0][r] = (k0a + 4 * h4 + r < kend_t) ? sa[r] * a.scale : -INFINITY;
-            sv[1][r] = (k0b + 4 * h4 + r < kend_t) ? sb[r] * a.scale : -INFINITY;
-            sv[2][r] = (ND == 3 && k0c + 4 * h4 + r < kend_t) ? sc[r] * a.scale : -INFINITY;
-            tmax = fmaxf(tmax, fmaxf(sv[0][r], fmaxf(sv[1][r], sv[2][r])));
-        }
-        if (refill) {
-            load_tile_k(t0, jn);
-            load_tile_k(t1, jn + NWT);
-            if constexpr (ND == 3) load_tile_k(t2, jn + 2 * NWT);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int i = 0; i < ND; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = (sv[i][r] == -INFINITY) ? 0.f : __expf(sv[i][r] - m_new);
-                psum += pv;
-                pw[(16 * i + 4 * h4 + r) * PS + c] = pv;
-            }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if (h4 == 0) aw[c] = alpha;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int g = 0; g < GPW; ++g) {
-            const float al = aw[g];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[g][j] *= al;
-        }
-        auto pv_tile = [&](const tile_t& t, const int i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v[8], pv[GPW];
-                unpack8(t.v[r], v);
-                const float4* pr4 = reinterpret_cast<const float4*>(pw + (16 * i + 4 * h4 + r) * PS);
-#pragma unroll
-                for (int q4 = 0; q4 < GPW / 4; ++q4) {
-                    const float4 t4 = pr4[q4];
-                    pv[4 * q4] = t4.x; pv[4 * q4 + 1] = t4.y; pv[4 * q4 + 2] = t4.z; pv[4 * q4 + 3] = t4.w;
-                }
-#pragma unroll
-                for (int g = 0; g < GPW; ++g)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[g][j] += pv[g] * v[j];
-            }
-        };
-        pv_tile(t0, 0);
-        if (refill) load_tile_v(t0, jn);
-        pv_tile(t1, 1);
-        if (refill) load_tile_v(t1, jn + NWT);
-        if constexpr (ND == 3) {
-            pv_tile(t2, 2);
-            if (refill) load_tile_v(t2, jn + 2 * NWT);
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-    const uint16_t* qraw = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(head0 + (c < GPW ? c : 0)) * HD;
-    if (wave == NW - 1) {
-        // The LAST wave takes the new token only: its K is roped from the raw QKV row, its V is raw, and every operand is requested
-        // at kernel entry beside the query's -- behind a cache-tile loop this wave would start the dependent rope loads when the
-        // others are done (measured: 3.5 us of tail).  The first head slice's workgroup is the single writer of cache slot q_pos0
-        // of (row, kv head).  The batch's other two tiles are copies of the token's, masked.
-        const int slot = kend;
-        const uint16_t* kraw = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + kvh) * HD;
-        const uint16_t* vrow = a.qkv_raw + (size_t)qi * QKV_LD + (size_t)(a.H + a.KVH + kvh) * HD;
-        rope_regs rr;
-        rope32_load(qraw, h4, a, p0, p1, p2, rr);
-        // the key's rope shares the query's cos / sin operands (same position, same 32 dims per lane): 8 more loads, not 16
-        // (every lane loads: the lanes c != 0 re-read the same row and drop it)
-        uint4 kx[4], ky[4];
-        {
-            const bool first = h4 < 2;
-            const uint16_t* own = kraw + h4 * 32;
-            const uint16_t* par = kraw + (first ? h4 * 32 + 64 : h4 * 32 - 64);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                kx[kb] = ld16(own + kb * 8);
-                ky[kb] = ld16(par + kb * 8);
-            }
-        }
-        const uint4 vnew = ld16(vrow + c * 8);
-        uint4 u[4], kn[4];
-        rope32_math(rr, h4, u);
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            rr.x[kb] = kx[kb];
-            rr.y[kb] = ky[kb];
-        }
-        rope32_math(rr, h4, kn);
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            qf[kb] = __builtin_bit_cast(bf16x8_t, c < GPW ? u[kb] : make_uint4(0, 0, 0, 0));
-            t0.k[kb] = c == 0 ? kn[kb] : make_uint4(0, 0, 0, 0);
-            t1.k[kb] = t0.k[kb];
-            t2.k[kb] = t0.k[kb];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t0.v[r] = t1.v[r] = t2.v[r] = vnew;
-        if (hs == 0) {
-            if (c == 0) {
-                uint16_t* kd = const_cast<uint16_t*>(a.k_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + h4 * 32;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) st16(kd + kb * 8, kn[kb]);
-            }
-            if (h4 == 0)
-                st16(const_cast<uint16_t*>(a.v_cache) + (((size_t)row * a.KVH + kvh) * a.Lmax + slot) * HD + c * 8, vnew);
-        }
-        TL_MARK(7, 4);
-        process_batch(slot, slot + 16, slot + 32, slot + 1, false, 0);      // keys slot + 1 .. are masked (p = 0)
-    } else {
-        {
-            uint4 u[4];
-            rope_regs rr;
-            rope32_load(qraw, h4, a, p0, p1, p2, rr);
-            __builtin_amdgcn_sched_barrier(0);
-            load_tile(t0, wave);
-            load_tile(t1, wave + NWT);
-            if constexpr (ND == 3) load_tile(t2, wave + 2 * NWT);
-            __builtin_amdgcn_sched_barrier(0);
-            rope32_math(rr, h4, u);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) qf[kb] = __builtin_bit_cast(bf16x8_t, c < GPW ? u[kb] : make_uint4(0, 0, 0, 0));
-        }
-        TL_MARK(7, 4);
-        // `j` and `ntile` are wave-uniform scalars; the refill loads are unconditional (clamped) so that the compiler counts them
-        for (int j = wave; j < ntile; j += ND * NWT)
-            process_batch(kbeg + 16 * j, kbeg + 16 * (j + NWT), kbeg + 16 * (j + 2 * NWT), kend, true, j + ND * NWT);
-        TL_MARK(7, 6);
-    }
-    TL_MARK(7, 5);
-    // ---- merge: 8 waves x 4 key quarters -> one output row per head -------------------------------------------------------------
-    if (h4 == 0) {
-        red_ml[(wave * 16 + c) * 2] = m_run;
-        red_ml[(wave * 16 + c) * 2 + 1] = l_run;
-    }
-#pragma unroll
-    for (int g = 0; g < GPW; ++g) {
-        float* d = red_o + ((size_t)((wave * 4 + h4) * GPW + g)) * HD + c * 8;
-        *reinterpret_cast<float4*>(d) = make_float4(o[g][0], o[g][1], o[g][2], o[g][3]);
-        *reinterpret_cast<float4*>(d + 4) = make_float4(o[g][4], o[g][5], o[g][6], o[g][7]);
-    }
-    // (the last batch's refill loads are still in flight and never consumed: wait for the LDS writes only)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    TL_MARK(7, 8);
-    for (int idx = tid; idx < GPW * (HD / 2); idx += 512) {
-        const int g = idx >> 6, col = (idx & 63) * 2;
-        float mm = -INFINITY;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) mm = fmaxf(mm, red_ml[(w * 16 + g) * 2]);
-        float L = 0.f, acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float mw = red_ml[(w * 16 + g) * 2];
-            const float sc = (mw == -INFINITY) ? 0.f : __expf(mw - mm);
-            L += sc * red_ml[(w * 16 + g) * 2 + 1];
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int kq = 0; kq < 4; ++kq) {
-                const float2 v2 = *reinterpret_cast<const float2*>(red_o + ((size_t)((w * 4 + kq) * GPW + g)) * HD + col);
-                s0 += v2.x;
-                s1 += v2.y;
-            }
-            acc0 += sc * s0;
-            acc1 += sc * s1;
-        }
-        const uint16_t y0 = f2bf(L > 0.f ? acc0 / L : 0.f), y1 = f2bf(L > 0.f ? acc1 / L : 0.f);
-        *reinterpret_cast<uint32_t*>(a.out + ((size_t)qi * a.H + head0 + g) * HD + col) = (uint32_t)y0 | ((uint32_t)y1 << 16);
-    }
+    // (Measured and removed, DESIGN.md 4a: the LAST split to finish merging in this same launch -- write-through partials, a ticket,
+    //  a coherent re-read are three dependent trips to the coherence point, 6.5 us against the 4.9 us combine launch; and a form with
+    //  no key split across workgroups at all -- 8-wave workgroups splitting the keys over their waves: two dependent HBM round trips
+    //  per wave where the split kernel makes one, 10.7 / 17.6 us against 8.3 / 10.3 us at 305 / 814 cached keys.)
     TL_EXIT(7);
 }
 
@@ -775,14 +432,6 @@ static void launch_attn(const umoe_attn_args* a, dim3 grid, hipStream_t s) {
     else attn_kernel<16><<<grid, 256, 0, s>>>(*a);
 }
 
-// merge of the key-split partials as a launch of its own (the engine's fallback when the merge cannot ride in the o_proj launch)
-int umoe_attn_merge(const umoe_attn_args* a, hipStream_t s) {
-    UMOE_REQUIRE(a && a->part_o && a->part_ml && a->out && a->splits >= 1, "umoe_attn_merge: bad argument");
-    launch_attn_combine(a, dim3((unsigned)a->H, (unsigned)(a->rows * a->nq)), s);
-    UMOE_LAUNCH_CHECK();
-    return 0;
-}
-
 extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     UMOE_REQUIRE(a && (a->q || a->qkv_raw) && a->k_cache && a->v_cache && a->kv_start && a->q_pos0 && a->part_o && a->part_ml && a->out,
                  "umoe_attn_decode: null argument");
@@ -798,34 +447,16 @@ extern "C" int umoe_attn_decode(const umoe_attn_args* a, umoe_stream_t stream) {
     UMOE_REQUIRE((long)a->rows * a->nq <= 65535 * 1L * 65535, "umoe_attn_decode: too many queries");
     hipStream_t s = (hipStream_t)stream;
     const unsigned nqi = (unsigned)(a->rows * a->nq);
-    if (a->wide) {
-        // one workgroup per (row, kv head[, half of the GQA group]): no key split across workgroups, no partials, no merge launch
-        UMOE_REQUIRE(a->qkv_raw && a->nq == 1 && a->H / a->KVH == 8 && a->rows <= 65535 && !a->sync && !a->defer_merge && !a->lse_out,
-                     "umoe_attn_decode: wide = decode with fused rope (qkv_raw, nq == 1), GQA group of 8, no sync / defer_merge (H=%d KVH=%d nq=%d)",
-                     a->H, a->KVH, a->nq);
-        // (a workgroup takes FOUR of the eight query heads: with all eight the 64 fp32 accumulators beside two register tiles spill,
-        //  and a scratch reload in front of every MFMA waits for the whole load queue)
-        constexpr int lds4 = (8 * 4 * 4 * 128 + 8 * 48 * 20 + 8 * 16 + 8 * 16 * 2) * 4;
-        static bool configured = false;
-        if (!configured) {
-            UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds4));
-            configured = true;
-        }
-        attn_wide_kernel<4><<<dim3((unsigned)a->KVH * 2u, nqi), 512, lds4, s>>>(*a);
-        UMOE_LAUNCH_CHECK();
-        return 0;
-    }
     // grid.z <= 65535: fold large query counts
     UMOE_REQUIRE(nqi <= 65535u * 32u, "umoe_attn_decode: too many query tokens (%u)", nqi);
     if (nqi <= 65535u) {
         launch_attn(a, dim3((unsigned)a->splits, (unsigned)a->KVH, nqi), s);
         UMOE_LAUNCH_CHECK();
-        if (!a->sync && a->splits > 1 && !a->defer_merge) {
+        if (a->splits > 1) {
             launch_attn_combine(a, dim3((unsigned)a->H, nqi), s);
             UMOE_LAUNCH_CHECK();
         }
     } else {
-        UMOE_REQUIRE(!a->sync, "umoe_attn_decode: the single-launch merge (sync) covers <= 65535 query tokens");
         // process row by row (prefill with very long prompts)
         for (int r = 0; r < a->rows; ++r) {
             umoe_attn_args b = *a;

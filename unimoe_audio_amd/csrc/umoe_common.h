@@ -200,6 +200,10 @@ struct umoe_ep_xfer {          // one push (local rows -> every peer's slab) or 
     const uint32_t* step;      // device word: decode steps taken so far
     int layer, layers;         // epoch = *step * layers + layer + 1
     uint32_t* err;             // device word, sticky: 1 = a receive timed out
+    // return slab filled by umoe_moe_ep.hip: n_cwg > 0 = wait for COUNTERS (word (kind 1, source rank, part 0) >= round * n_cwg,
+    // round = *round * layers + layer + 1) instead of the row flags
+    const uint32_t* round;
+    int n_cwg;
 };
 int umoe_ep_push(const umoe_ep_xfer& x, hipStream_t s);
 int umoe_ep_pull(const umoe_ep_xfer& x, hipStream_t s);
@@ -235,10 +239,9 @@ int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* 
 bool umoe_moe_flat_feasible(int n_wg, int S, int D, int I_dyn, int I_sh, int n_real, int n_fix);
 
 // A small decode GEMM with row riders in front (umoe_gemm.hip wstream_gemm_rk, umoe_riders_dev.h; decode engine only).  kind 2: the
-// MoE combine of the previous layer rides in the QKV launch; kind 3: the attention split merge rides in the o_proj launch.
+// MoE combine of the previous layer rides in the QKV launch; kind 4: the same over the return slab of the expert-parallel exchange.
 // Returns 1 (nothing launched) when the shapes do not fit.
 struct umoe_rider2;
-int umoe_attn_merge(const umoe_attn_args* a, hipStream_t s);      // umoe_attn.hip: the split merge as its own launch
 int umoe_gemm_riders(const umoe_gemm_args* a, int kind, const umoe_rider2* r2, const umoe_rider_pub* pub, hipStream_t s);
 
 // ---- weight-streaming GEMM over several 16-row tiles per weight pass (umoe_gemm_mt.hip; expert parallel decode) --------
@@ -258,6 +261,32 @@ struct umoe_mt_args {
     const umoe_router_args* fused_router;   // optional HOST pointer: S router workgroups ride as an extra z-slice (see umoe_gemm_args)
 };
 int umoe_gemm_mt(const umoe_mt_args* a, hipStream_t s);
+
+// ---- the MoE half of an expert-parallel decode layer in ONE launch (umoe_moe_ep.hip; decode engine only) ------------------------
+#define UMOE_EPF_MAXT 24       // task words per workgroup (the last one stays 0 = end)
+struct umoe_epf_desc {
+    const umoe_router_args* router;    // x = raw rows x1 [S][D] (post-attention residual stream), norm_w / rms_eps = post-attention RMSNorm, gate, tables
+    const umoe_rider_pub* pub;         // step / layer / layers / err (its row flags are not used)
+    int R, rank, loopback, E_loc, S, D, I_dyn, I_sh, n_fix, n_wg;
+    char* const* peer_base;            // [R] exchange regions as mapped here
+    size_t disp_off, ret_off;          // dispatch slab [R][S][D] (raw rows), return slab [n_real][16][D] inside a region
+    const uint16_t* const* w_lgu;      // [E_loc] WP16 gate/up, [E_loc] WP16 down of the local experts
+    const uint16_t* const* w_ldn;
+    const uint16_t* const* w_sgu;      // [n_fix] shared experts
+    const uint16_t* const* w_sdn;
+    uint16_t* xgp;                     // [R][16 * D]: normalised row tiles in MFMA operand order
+    uint16_t* hpk;                     // [E_loc][R][16 * I_dyn]: silu(g)*u tiles in operand order
+    uint16_t* h_sh; int ldh, h_row0;   // shared experts' silu(g)*u rows: expert i at rows h_row0 + i*S of h_sh [.][ldh]
+    uint16_t* y_sh; int ldy, y_row0;   // shared experts' outputs: expert i at rows y_row0 + i*S of y_sh [.][ldy]
+    uint32_t* flags; int flag_words;   // >= 2 * n_wg + UMOE_FLAG_REPL * 16 device words (monotonic epochs)
+    const uint32_t* round;             // device word: decode steps taken (no prefill bumps): base of the return counters' rounds
+    uint32_t* tasks_dev;               // n_wg * UMOE_EPF_MAXT device words (umoe_moe_ep_prepare fills them)
+    // filled by umoe_moe_ep_prepare
+    int n_cwg;                         // workgroups that count themselves in on every return slab per round
+    int proda_base[4], proda_n[4], prodb_base[UMOE_MT_MAXG], prodb_n[UMOE_MT_MAXG];
+};
+int umoe_moe_ep_prepare(umoe_epf_desc* d, hipStream_t s);     // 0 ok, 1 no plan for the shape; NOT inside a stream capture
+int umoe_moe_ep(const umoe_epf_desc* d, hipStream_t s);
 
 // device side of the hand-off (shared by umoe_ep.hip, umoe_router.hip, umoe_misc.hip)
 #if defined(__HIPCC__)

@@ -61,7 +61,7 @@ struct umoe_engine {
              *hbuf = nullptr, *ybuf = nullptr;
     float *part_o = nullptr, *part_ml = nullptr, *logits = nullptr, *ypart = nullptr;
     int32_t *pos3 = nullptr, *kv_pos = nullptr, *q_pos0 = nullptr, *kv_start = nullptr, *tok_in = nullptr,
-            *valid_count = nullptr, *eng_state = nullptr, *attn_sync = nullptr;
+            *valid_count = nullptr, *eng_state = nullptr;
     void* r_logits = nullptr;
     int64_t *r_topk = nullptr, *pred = nullptr;
     int32_t *r_sel = nullptr, *r_mask = nullptr, *counts = nullptr, *offsets = nullptr, *slot_token = nullptr,
@@ -77,20 +77,12 @@ struct umoe_engine {
     bool probe_on() const { return probe_teach || probe_x1 || probe_x || probe_logits; }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    // second stream: the shared experts run beside the (latency-bound) router; fork/join by events, graph-capturable
-    hipStream_t s2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // decode with >= 6 rows: every routed expert is hit with probability ~1, so each expert computes ALL rows (no gather
     // lists, no dispatch kernel, no device-produced row counts in the GEMM prologues) and the combine selects by mask
     bool dense_experts = true;
     bool fuse_router = true;     // UMOE_FUSE_ROUTER: dense decode runs the router inside the gate/up launch (see run_layer)
-    bool rs_handoff = false;     // UMOE_RS_HANDOFF: fused expert launch: the riders hand over the rows' RMSNorm scales (8-byte granules), not the
-                                 // rows.  Off: bit-identical, measured 3.105-3.11 vs 3.075-3.087 ms/step -- 226 workgroups scaling the 16 rows
-                                 // they stage cost more than the drain + reload of the rows the hand-off saves
     bool fuse_cq = true;         // UMOE_FUSE_CQ: the MoE combine of layer l rides in the QKV launch of layer l + 1 (umoe_gemm_riders kind 2)
-    bool fuse_ao = false;        // UMOE_FUSE_AO: the attention split merge rides in the o_proj launch (kind 3).  Off: measured 3.18 vs 3.13
-                                 // ms/step -- the merge is 1 us of work, its hand-off (drain, flag, poll, sc1 reload) costs more than
-                                 // the launch boundary it removes; the combine in the QKV launch (fuse_cq) wins: 3.08 vs 3.13
+    int cb_ep_layer = -1;        // expert parallel: the layer whose return slab the stashed combine reads (>= 0 selects rider kind 4)
     bool cb_pending = false;     // a combine stashed at the end of a layer, issued with the next layer's QKV launch
     umoe_combine_args cb_stash{};
     int dense_min_rows = 2;      // UMOE_DENSE_MIN_ROWS: fewest decode rows that take the dense-expert layout (below: ragged dispatch).  Batch 1
@@ -101,17 +93,9 @@ struct umoe_engine {
     bool flat_moe = true;        // UMOE_FLAT_MOE: both expert GEMMs as ONE workgroup per CU with a byte-balanced static schedule
                                  // (umoe_moe_flat.hip); 0 / shapes that do not fit: the box-grid launch below
     bool fuse_moe = true;        // UMOE_FUSE_MOE: gate/up and down projections of a dense decode layer in ONE launch (umoe_moe_fused)
-    bool gu_norm = false;        // UMOE_GU_NORM: the gate/up workgroups normalise x1 in their staging prologue (no hand-off, no norm launch)
     bool rider_pub = true;       // UMOE_RIDER_PUB: the riders also produce the normalised rows and hand them to the GEMM workgroups of the
                                  // same launch (umoe_gemm_args.rider_pub): no RMSNorm launch in front of gate/up
-    int attn_wide = 0;           // UMOE_ATTN_WIDE: decode attention as 8-wave workgroups (two per (row, kv head)) that split the keys over their
-                                 // waves and write the output themselves (umoe_attn_args.wide): no partials, no combine launch
-    bool attn_single = false;    // UMOE_ATTN_SINGLE: decode attention merges its key splits in the same launch (umoe_attn_args.sync);
-                                 // measured 3.644 vs 3.585 ms/step: ticket + coherent re-read cost more than the combine launch
-    int flat_wgs = 0;            // UMOE_FLAT_WGS: workgroups of the flat gate/up launch; measured 42.4 us (256 slices of 6-7
-                                 // pairs, the 7th slot of a 6-pair slice re-reads) vs 37.3 us for the per-group grid -> off
     bool tiled_prefill = true;   // UMOE_TILED_PREFILL=0: weight-streaming kernels for every row count (A/B, tests)
-    bool overlap_shared = false;  // measured on MI355X: 1429 vs 1825 tok/s -- cross-stream graph edges cost more than they hide
     // optional per-kernel-class timing of one eager step (hipEvents on the launch stream)
     bool prof = false;
     std::vector<hipEvent_t> ev;
@@ -128,6 +112,11 @@ struct umoe_engine {
     uint32_t* ep_words = nullptr;         // [0] decode steps taken (epoch base), [1] sticky error word; own allocation: survives workspace growth
     uint16_t* xg = nullptr;               // RCCL mode: [ep][rows][D] normalised rows of every rank (tile ep_rank is written locally)
     uint16_t *xgp = nullptr, *hpk = nullptr;   // peer modes: operand-order tiles (see carve)
+    // the MoE half of an expert-parallel decode layer as ONE launch with the exchange inside (umoe_moe_ep.hip); prepared at connect time
+    bool ep_flat = true;                  // UMOE_EP_FLAT=0: the launch-per-kernel exchange below (also taken when the shape has no plan)
+    bool epf_ready = false;
+    umoe_epf_desc epf{};
+    uint32_t* epf_tasks = nullptr;
     bool ep_decode(int n_tok) const { return c.ep_size > 1 && n_tok == c.rows; }
     int groups_per_layer() const { return 2 + 2 * (c.n_real + c.n_fix); }
 };
@@ -165,7 +154,6 @@ static size_t carve(umoe_engine* e, int n_tok, char* base) {
     e->kv_start = k.take<int32_t>(c.rows);
     e->valid_count = k.take<int32_t>(c.rows);
     e->eng_state = k.take<int32_t>(8);
-    e->attn_sync = k.take<int32_t>((size_t)n_tok * c.kv_heads);   // zero at allocation; the attention kernel leaves it zero
     e->tok_in = k.take<int32_t>((size_t)c.rows * c.codec_channels);
     e->r_logits = k.take<float>((size_t)n_tok * E);
     e->r_topk = k.take<int64_t>(n_tok);
@@ -203,7 +191,7 @@ static int ensure_workspace(umoe_engine* e, int n_tok) {
 // group table for a pass over n_tok tokens
 static bool dense_mode(const umoe_engine* e, int n_tok) {
     if (e->ep_decode(n_tok)) return true;   // expert parallel decode IS the dense layout: every rank's rows visit every expert
-    return e->dense_experts && n_tok == e->c.rows && n_tok <= 16 && n_tok >= e->dense_min_rows && !e->overlap_shared;
+    return e->dense_experts && n_tok == e->c.rows && n_tok <= 16 && n_tok >= e->dense_min_rows;
 }
 
 static int build_groups(umoe_engine* e, int n_tok, hipStream_t s) {
@@ -343,33 +331,20 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
         }
         e->ep_region = (char*)r;
     }
-    if (hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess) {
-        umoe_set_error("umoe_engine_create: stream/event creation failed");
-        umoe_engine_destroy(e);
-        return -2;
-    }
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) e->n_cu = cus;
         if (const char* v = getenv("UMOE_FAKE_CUS")) e->n_cu = atoi(v);
     }
     if (const char* v = getenv("UMOE_FLAT_MOE")) e->flat_moe = atoi(v) != 0;
-    if (const char* v = getenv("UMOE_OVERLAP_SHARED")) e->overlap_shared = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_EP_FLAT")) e->ep_flat = atoi(v) != 0;
     if (const char* v = getenv("UMOE_DENSE_EXPERTS")) e->dense_experts = atoi(v) != 0;
     if (const char* v = getenv("UMOE_TILED_PREFILL")) e->tiled_prefill = atoi(v) != 0;
-    if (const char* v = getenv("UMOE_FLAT_WGS")) e->flat_wgs = atoi(v);
-    if (const char* v = getenv("UMOE_ATTN_SINGLE")) e->attn_single = atoi(v) != 0;
-    if (const char* v = getenv("UMOE_ATTN_WIDE")) e->attn_wide = atoi(v);
     if (const char* v = getenv("UMOE_FUSE_ROUTER")) e->fuse_router = atoi(v) != 0;
     if (const char* v = getenv("UMOE_RIDER_PUB")) e->rider_pub = atoi(v) != 0;
-    if (const char* v = getenv("UMOE_GU_NORM")) e->gu_norm = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_MOE")) e->fuse_moe = atoi(v) != 0;
     if (const char* v = getenv("UMOE_DENSE_MIN_ROWS")) e->dense_min_rows = atoi(v);
     if (const char* v = getenv("UMOE_FUSE_CQ")) e->fuse_cq = atoi(v) != 0;
-    if (const char* v = getenv("UMOE_RS_HANDOFF")) e->rs_handoff = atoi(v) != 0;
-    if (const char* v = getenv("UMOE_FUSE_AO")) e->fuse_ao = atoi(v) != 0;
     *out = e;
     return 0;
 }
@@ -379,12 +354,10 @@ extern "C" void umoe_engine_destroy(umoe_engine* e) {
     if (e->exec) (void)hipGraphExecDestroy(e->exec);
     if (e->graph) (void)hipGraphDestroy(e->graph);
     for (hipEvent_t x : e->ev) (void)hipEventDestroy(x);
-    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
-    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
-    if (e->s2) (void)hipStreamDestroy(e->s2);
     if (e->ws) (void)hipFree(e->ws);
     if (e->ep_region) (void)hipFree(e->ep_region);
     if (e->ep_words) (void)hipFree(e->ep_words);
+    if (e->epf_tasks) (void)hipFree(e->epf_tasks);
     if (e->k_cache) (void)hipFree(e->k_cache);
     if (e->v_cache) (void)hipFree(e->v_cache);
     if (e->d_delay) (void)hipFree(e->d_delay);
@@ -461,6 +434,23 @@ extern "C" int umoe_engine_ep_connect(umoe_engine* e, void* const* peers, void* 
     }
     e->ep_mode = mode;
     e->groups_for_tok = -1;   // the decode group table depends on the mode (where the own rows' outputs go)
+    // the one-launch form of the MoE half (umoe_moe_ep.hip): its task lists are computed and uploaded here, outside any graph capture.
+    // One workgroup per CU and in-launch hand-offs: every workgroup must be resident, so the launch is sized to the CU count the guards
+    // assume (UMOE_FAKE_CUS: several ranks sharing one card take a share each).
+    e->epf_ready = false;
+    const umoe_engine_cfg& c = e->c;
+    if (mode != UMOE_EP_RCCL && e->ep_flat && e->rider_pub && e->fuse_router && e->n_cu > 0 && c.hidden == 2048 && c.n_dyn == 9 && c.n_fix == 2 && c.rows <= 16 &&
+        e->E_loc >= 1 && e->E_loc <= UMOE_MT_MAXG) {
+        umoe_epf_desc& d = e->epf;
+        memset(&d, 0, sizeof(d));
+        d.n_wg = e->n_cu < 256 ? e->n_cu : 256;
+        d.R = c.ep_size; d.E_loc = e->E_loc; d.S = c.rows; d.D = c.hidden; d.I_dyn = c.inter_dyn; d.I_sh = c.inter_shared; d.n_fix = c.n_fix;
+        if (!e->epf_tasks) UMOE_HIP(hipMalloc(&e->epf_tasks, (size_t)256 * UMOE_EPF_MAXT * sizeof(uint32_t)));
+        d.tasks_dev = e->epf_tasks;
+        const int rc = umoe_moe_ep_prepare(&d, nullptr);
+        if (rc < 0) return rc;
+        e->epf_ready = rc == 0;
+    }
     return 0;
 }
 
@@ -607,8 +597,66 @@ static int run_moe_ep_rccl(umoe_engine* e, int l, int n_tok, hipStream_t s) {
 //   RMSNorm + PUSH of the rows (one launch) | shared gate/up | PULL + re-lay into operand order | local experts gate/up over
 //   all ep*16 rows, weights streamed ONCE (umoe_gemm_mt.hip; + the router riders) | down, own rows' outputs straight into the own
 //   return slab | PUSH outputs | shared down | combine, which waits for the peers' rows itself and reads the slab in place.
+// One launch (umoe_moe_ep.hip): riders push / re-lay the rows and route, phases A..D stream the shared and the local experts' weights,
+// the down epilogue stores into the owners' return slabs; the combine rides in the next layer's QKV launch (kind 4), the last layer's
+// runs as its own launch on the same counters.
+static int run_moe_ep_flat(umoe_engine* e, int l, int n_tok, hipStream_t s) {
+    const umoe_engine_cfg& c = e->c;
+    const int D = c.hidden, E = c.n_dyn + c.n_fix, QKV = (c.heads + 2 * c.kv_heads) * c.head_dim;
+    const int Imax = c.inter_dyn > c.inter_shared ? c.inter_dyn : c.inter_shared;
+    const int ep = c.ep_size, El = e->E_loc, rank = c.ep_rank;
+    const LayerDev& L = e->layers[l];
+    int rc;
+    umoe_router_args ra{};
+    ra.x = e->x1; ra.gate_w = L.w.gate_w; ra.norm_w = L.w.post_norm; ra.h_out = nullptr; ra.S = n_tok; ra.D = D;
+    ra.n_dyn = c.n_dyn; ra.n_real = c.n_real; ra.n_fix = c.n_fix; ra.logits_bf16 = 1; ra.top_p = c.top_p;
+    ra.fixed_top_k = c.fixed_top_k; ra.jitter_eps = c.jitter_eps; ra.rms_eps = c.rms_eps;
+    ra.logits_out = e->r_logits; ra.sel = e->r_sel; ra.routing_w = e->r_routing; ra.global_w = e->r_global; ra.moe_w = e->r_moe;
+    ra.expert_mask = e->all_mask + (size_t)l * c.rows * E;
+    ra.top_k = e->all_topk + (size_t)l * c.rows;
+    umoe_rider_pub pub{};
+    pub.flags = e->ep_words + 1024; pub.step = e->ep_words; pub.layer = l; pub.layers = c.layers; pub.err = e->ep_words + 1;
+    const size_t tile = (size_t)n_tok * D * 2;
+    umoe_epf_desc d = e->epf;
+    d.router = &ra; d.pub = &pub; d.rank = rank; d.loopback = e->ep_mode == UMOE_EP_LOOPBACK;
+    d.peer_base = e->ep_peers; d.disp_off = UMOE_EP_FLAG_BYTES; d.ret_off = UMOE_EP_FLAG_BYTES + (size_t)ep * tile;
+    d.w_lgu = L.exp_gu.data(); d.w_ldn = L.exp_dn.data(); d.w_sgu = L.sh_gu.data(); d.w_sdn = L.sh_dn.data();
+    d.xgp = e->xgp; d.hpk = e->hpk;
+    d.h_sh = e->hbuf; d.ldh = Imax; d.h_row0 = c.n_real * n_tok;
+    d.y_sh = e->ybuf; d.ldy = D; d.y_row0 = c.n_real * n_tok;
+    d.flags = e->ep_words + 2048; d.flag_words = 4096 - 2048;
+    d.round = e->ep_words + 2;
+    if ((rc = umoe_moe_ep(&d, s))) return rc;
+    PROF(K_GATEUP);
+    uint16_t* slab_ret = reinterpret_cast<uint16_t*>(e->ep_region + d.ret_off);
+    umoe_combine_args cb{};
+    cb.y_slots = slab_ret; cb.shared_row0 = -1; cb.slot_of = nullptr; cb.moe_w = e->r_moe;
+    cb.expert_mask = ra.expert_mask; cb.mask_ld = E; cb.dense_rows = n_tok;
+    cb.y_shared = e->ybuf + (size_t)n_tok * c.n_real * D; cb.global_w = e->r_global;
+    cb.resid = e->x1; cb.out = e->x; cb.S = n_tok; cb.D = D; cb.n_real = c.n_real; cb.n_dyn = c.n_dyn; cb.n_fix = c.n_fix;
+    cb.norm_w = (l + 1 < c.layers) ? e->layers[l + 1].w.in_norm : e->final_norm; cb.norm_out = e->hin; cb.rms_eps = c.rms_eps;
+    const bool cq_fits = n_tok + QKV / 16 <= 2 * e->n_cu;
+    if (e->fuse_cq && cq_fits && l + 1 < c.layers && !e->probe_on()) {
+        e->cb_stash = cb;
+        e->cb_pending = true;
+        e->cb_ep_layer = l;
+        return 0;
+    }
+    // own launch: the same counters (umoe_ep_xfer.n_cwg > 0 selects them in combine_kernel<true>)
+    umoe_ep_xfer x{};
+    for (int p = 0; p < ep; ++p) x.peer_base[p] = e->ep_peers[p];
+    x.rank = rank; x.size = ep; x.loopback = d.loopback; x.step = e->ep_words; x.err = e->ep_words + 1;
+    x.layer = l; x.layers = c.layers; x.rows = n_tok; x.row_bytes = D * 2; x.kind = 1;
+    x.round = e->ep_words + 2; x.n_cwg = d.n_cwg;
+    cb.ep_xfer = &x;
+    rc = umoe_unpermute_combine_fwd(&cb, s);
+    PROF(K_COMBINE);
+    return rc;
+}
+
 static int run_moe_ep(umoe_engine* e, int l, int n_tok, hipStream_t s) {
     if (e->ep_mode == UMOE_EP_RCCL) return run_moe_ep_rccl(e, l, n_tok, s);
+    if (e->epf_ready && n_tok == e->c.rows) return run_moe_ep_flat(e, l, n_tok, s);
     const umoe_engine_cfg& c = e->c;
     const int D = c.hidden, G = c.n_real + c.n_fix, GPL = e->groups_per_layer(), E = c.n_dyn + c.n_fix;
     const int Imax = c.inter_dyn > c.inter_shared ? c.inter_dyn : c.inter_shared;
@@ -735,8 +783,22 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
             r2.n_riders = n_tok; r2.cb = e->cb_stash;
             umoe_rider_pub cpub{};
             cpub.flags = e->ep_words + 1024 + 16 * UMOE_FLAG_REPL; cpub.step = e->ep_words; cpub.layer = l; cpub.layers = c.layers; cpub.err = e->ep_words + 1;
-            rc = umoe_gemm_riders(&a, 2, &r2, &cpub, s);
-            if (rc == 1 && (rc = umoe_unpermute_combine_fwd(&e->cb_stash, s)) == 0) rc = 1;     // shapes do not fit: the two launches
+            const bool epc = e->cb_ep_layer >= 0;
+            umoe_ep_xfer x{};
+            if (epc) {       // the rows of the previous layer's routed experts sit in the return slab: the riders wait for the owners' counters
+                r2.ep_region = e->ep_region; r2.ep_round = e->ep_words + 2; r2.ep_layer = e->cb_ep_layer; r2.ep_layers = c.layers;
+                r2.ep_size = c.ep_size; r2.ep_n_cwg = e->epf.n_cwg; r2.ep_err = e->ep_words + 1;
+                for (int p = 0; p < c.ep_size; ++p) x.peer_base[p] = e->ep_peers[p];
+                x.rank = c.ep_rank; x.size = c.ep_size; x.loopback = e->ep_mode == UMOE_EP_LOOPBACK; x.step = e->ep_words; x.err = e->ep_words + 1;
+                x.layer = e->cb_ep_layer; x.layers = c.layers; x.rows = n_tok; x.row_bytes = D * 2; x.kind = 1;
+                x.round = e->ep_words + 2; x.n_cwg = e->epf.n_cwg;
+                e->cb_ep_layer = -1;
+            }
+            rc = umoe_gemm_riders(&a, epc ? 4 : 2, &r2, &cpub, s);
+            if (rc == 1) {       // shapes do not fit: the two launches
+                if (epc) e->cb_stash.ep_xfer = &x;
+                if ((rc = umoe_unpermute_combine_fwd(&e->cb_stash, s)) == 0) rc = 1;
+            }
         }
         if (rc == 1) rc = umoe_grouped_gemm(&a, s);
     }
@@ -758,12 +820,6 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     t.q = e->q_r; t.k_cache = r.k_cache; t.v_cache = r.v_cache; t.kv_start = e->kv_start; t.q_pos0 = e->q_pos0;
     t.rows = c.rows; t.nq = T; t.H = c.heads; t.KVH = c.kv_heads; t.hd = c.head_dim; t.Lmax = c.Lmax; t.splits = splits;
     t.scale = 1.0f / sqrtf((float)c.head_dim); t.part_o = e->part_o; t.part_ml = e->part_ml; t.out = e->attn_out;
-    const bool wide = T == 1 && e->attn_wide > 0 && c.heads == 8 * c.kv_heads && c.head_dim == 128 && (c.mrope0 % 8 == 0) && ((c.mrope0 + c.mrope1) % 8 == 0);
-    if (wide) t.wide = 1;                                  // decode: keys split over the WAVES of a workgroup, output written by the launch
-    if (T == 1 && e->attn_single && !wide) t.sync = e->attn_sync;   // decode: the last key split merges, no combine launch
-    // decode: the merge of the key splits rides in the o_proj launch (16 rider workgroups hand the merged rows over)
-    const bool merge_rides = T == 1 && !tiled && !wide && e->fuse_ao && e->rider_pub && !t.sync && splits == 8 && c.heads == 16 && c.head_dim == 128 && n_tok <= 16;
-    if (merge_rides) t.defer_merge = 1;
     if (fuse_rope) {
         t.qkv_raw = e->qkv; t.cos_tab = e->cos_tab; t.sin_tab = e->sin_tab; t.pos3 = e->pos3;
         t.sec0 = c.mrope0; t.sec1 = c.mrope1; t.sec2 = c.mrope2;
@@ -782,18 +838,6 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         ta.groups = &tg; ta.num_groups = 1; ta.max_rows = n_tok; ta.a = e->attn_out; ta.lda = HD; ta.resid = e->x; ta.out = e->x1;
         ta.ldo = D; ta.epilogue = UMOE_EPI_BF16_RESID;
         rc = umoe_tiled_gemm(&ta, s);
-    } else if (merge_rides) {
-        umoe_rider2 r2{};
-        r2.n_riders = n_tok; r2.part_o = e->part_o; r2.part_ml = e->part_ml; r2.attn_out = e->attn_out; r2.H = c.heads; r2.splits = splits;
-        umoe_rider_pub apub{};
-        apub.flags = e->ep_words + 1024 + 32 * UMOE_FLAG_REPL; apub.step = e->ep_words; apub.layer = l; apub.layers = c.layers; apub.err = e->ep_words + 1;
-        rc = umoe_gemm_riders(&o, 3, &r2, &apub, s);
-        if (rc == 1) {       // shapes do not fit the riders: merge in a launch of its own, then the plain o_proj
-            umoe_attn_args m = t;
-            m.defer_merge = 0;
-            if ((rc = umoe_attn_merge(&m, s))) return rc;
-            rc = umoe_grouped_gemm(&o, s);
-        }
     } else {
         rc = umoe_grouped_gemm(&o, s);
     }
@@ -802,21 +846,6 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     if (e->probe_x1 && n_tok == c.rows)
         UMOE_HIP(hipMemcpyAsync(e->probe_x1 + (size_t)l * c.rows * D, e->x1, (size_t)c.rows * D * 2, hipMemcpyDeviceToDevice, s));
     if (e->ep_decode(n_tok)) return run_moe_ep(e, l, n_tok, s);
-    if (e->overlap_shared && c.n_fix > 0) {   // fork: shared experts on s2 (x1 -> RMSNorm -> SwiGLU -> down)
-        UMOE_HIP(hipEventRecord(e->ev_fork, s));
-        UMOE_HIP(hipStreamWaitEvent(e->s2, e->ev_fork, 0));
-        umoe_gemm_args sg{};
-        sg.groups = g + 2 + c.n_real; sg.groups_host = gh + 2 + c.n_real; sg.num_groups = c.n_fix; sg.max_rows = n_tok; sg.max_n_blocks = 2 * c.inter_shared / 16;
-        sg.max_k = D; sg.a = e->x1; sg.lda = D; sg.norm_w = L.w.post_norm; sg.rms_eps = c.rms_eps;
-        sg.out = e->hbuf; sg.ldo = Imax; sg.n_valid = Imax; sg.prologue = UMOE_PRO_RMSNORM; sg.epilogue = UMOE_EPI_SWIGLU;
-        if ((rc = umoe_grouped_gemm(&sg, e->s2))) return rc;
-        umoe_gemm_args sd{};
-        sd.groups = g + 2 + G + c.n_real; sd.groups_host = gh + 2 + G + c.n_real; sd.num_groups = c.n_fix; sd.max_rows = n_tok; sd.max_n_blocks = D / 16;
-        sd.max_k = c.inter_shared; sd.a = e->hbuf; sd.lda = Imax; sd.out = e->ybuf; sd.ldo = D; sd.n_valid = D;
-        sd.prologue = UMOE_PRO_PLAIN; sd.epilogue = UMOE_EPI_BF16;
-        if ((rc = umoe_grouped_gemm(&sd, e->s2))) return rc;
-        UMOE_HIP(hipEventRecord(e->ev_join, e->s2));
-    }
     // 5. RMSNorm + router                                         model.py:240, core.py:246-291
     umoe_router_args ra{};
     const bool dense = dense_mode(e, n_tok);
@@ -832,11 +861,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     // dense decode: the GEMMs do not read the routing results (every expert computes every row), only the combine does -- so the
     // router rides INSIDE the gate/up launch as 16 extra workgroups and only the RMSNorm (h2, which gate/up needs) stays in the
     // chain as its own small launch: the 4.4 us serial routing chain per token leaves the critical path.
-    const bool fuse_router = dense && e->fuse_router && !tiled && !(e->overlap_shared && c.n_fix > 0) && c.n_dyn == 9 && c.n_fix == 2 &&
-                             (D == 2048 || D == 4096) && n_tok <= 16 && !(e->flat_wgs > 0);
-    // gu_norm: the gate/up workgroups normalise x1 themselves in their staging prologue (the router body's summation tree: the same
-    // bits), so that launch waits for nobody -- no norm launch, no hand-off
-    const bool gu_norm = fuse_router && e->gu_norm && D == 2048;
+    const bool fuse_router = dense && e->fuse_router && !tiled && c.n_dyn == 9 && c.n_fix == 2 &&
+                             (D == 2048 || D == 4096) && n_tok <= 16;
     // In-launch hand-offs need every workgroup of the launch RESIDENT at once (a waiting workgroup never yields its CU): the gate/up box
     // of 8-wave, 256-register workgroups admits ONE per CU, the flat launch is sized to the CU count itself.  A device that exposes
     // fewer CUs (partition, CU mask) takes the launch-per-kernel path instead of discovering it by a timeout.
@@ -844,14 +870,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     const bool box_fits = e->n_cu <= 0 || gu_box <= e->n_cu;
     const bool flat_ok = dense && e->flat_moe && e->fuse_moe && e->n_cu > 0 && c.n_dyn == 9 && c.n_fix == 2 &&
                          umoe_moe_flat_feasible(e->n_cu < 256 ? e->n_cu : 256, n_tok, D, c.inter_dyn, c.inter_shared, c.n_real, c.n_fix);
-    const bool pub_riders = fuse_router && e->rider_pub && !gu_norm && (box_fits || flat_ok);
-    // fused expert launch, second hand-off form: the riders hand over the rows' SCALES only ({rs, epoch} granules); the GEMM
-    // workgroups load the raw rows x1 at launch and finish the norm themselves
-    const bool rs_handoff = pub_riders && e->fuse_moe && e->rs_handoff && D == 2048 && !tiled;
-    if (gu_norm || rs_handoff) {
-        rc = 0;
-        ra.h_out = nullptr;
-    } else if (pub_riders) {
+    const bool pub_riders = fuse_router && e->rider_pub && (box_fits || flat_ok);
+    if (pub_riders) {
         rc = 0;                  // no launch here: the riders write h2 inside the gate/up launch and hand it over (ra.h_out stays h2)
     } else if (fuse_router) {
         umoe_router_args rn = ra;
@@ -867,36 +887,24 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     PROF(K_ROUTER);
     umoe_rider_pub rpub{};
     rpub.flags = e->ep_words + 1024; rpub.step = e->ep_words; rpub.layer = l; rpub.layers = c.layers; rpub.err = e->ep_words + 1;
-    rpub.rs = reinterpret_cast<unsigned long long*>(e->ep_words + 512);
-    // 7./8. experts.  The shared experts need no routing: with `overlap_shared` they run on a second stream from the
-    // residual stream x1 (their own RMSNorm prologue) BESIDE the latency-bound router + dispatch (forked after o_proj,
-    // see below) and are joined before the combine; otherwise routed + shared share one launch each.
-    const bool ov = e->overlap_shared && c.n_fix > 0;
+    // 7./8. experts: routed + shared share one launch (the fused / flat launch) or one launch per GEMM
     umoe_gemm_args gu{};
-    gu.groups = g + 2; gu.groups_host = gh + 2; gu.num_groups = ov ? c.n_real : G; gu.max_rows = n_tok;
-    gu.max_n_blocks = 2 * (ov ? c.inter_dyn : Imax) / 16; gu.max_k = D;
+    gu.groups = g + 2; gu.groups_host = gh + 2; gu.num_groups = G; gu.max_rows = n_tok;
+    gu.max_n_blocks = 2 * Imax / 16; gu.max_k = D;
     gu.a = e->h2; gu.lda = D; gu.out = e->hbuf; gu.ldo = Imax; gu.n_valid = Imax;
     gu.prologue = UMOE_PRO_PLAIN; gu.epilogue = UMOE_EPI_SWIGLU;
     if (dense) {             // per-CU byte balance decides this kernel (see umoe_gemm.hip): 7 pairs per workgroup, flat slices
         gu.nt = 14;
         if (fuse_router) gu.fused_router = &ra;
-        if (gu_norm) {
-            gu.a = e->x1; gu.norm_w = L.w.post_norm; gu.rms_eps = c.rms_eps; gu.prologue = UMOE_PRO_RMSNORM;
-            gu.groups_host = e->h_gu_pub.data() + (size_t)l * G;     // (same order as the hand-off variant: shared experts first)
-        }
-        if (rs_handoff) {
-            gu.a = e->x1; gu.norm_w = L.w.post_norm; gu.rms_eps = c.rms_eps; gu.prologue = UMOE_PRO_RMSNORM;
-        }
         if (pub_riders) {
             gu.rider_pub = &rpub;
             gu.groups_host = e->h_gu_pub.data() + (size_t)l * G;     // shared experts first (riders early in dispatch order)
         }
-        if (e->flat_wgs > 0 && ceil_div((c.n_real * c.inter_dyn + c.n_fix * c.inter_shared) / 16, e->flat_wgs) <= 7) gu.flat_wgs = e->flat_wgs;
     }
     // (dense mode with the post-attention RMSNorm in this launch's staging prologue, so that it would not wait for the
     //  router at all, was measured: 46.9 vs 37.7 us per launch -- 387 workgroups redoing the norm of all 16 rows costs
     //  more than the dependency it removes; the router kernel writes the normalised rows h2 once instead)
-    if (tiled && !ov && G <= 12) {
+    if (tiled && G <= 12) {
         umoe_tgroup_t tg[12];
         memset(tg, 0, sizeof(tg));
         for (int x = 0; x < G; ++x) {
@@ -918,12 +926,12 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     if (rc) return rc;
     if (!(pub_riders && e->fuse_moe)) PROF(K_GATEUP);
     umoe_gemm_args dn{};
-    dn.groups = g + 2 + G; dn.groups_host = gh + 2 + G; dn.num_groups = ov ? c.n_real : G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16;
-    dn.max_k = ov ? c.inter_dyn : Imax;
+    dn.groups = g + 2 + G; dn.groups_host = gh + 2 + G; dn.num_groups = G; dn.max_rows = n_tok; dn.max_n_blocks = D / 16;
+    dn.max_k = Imax;
     dn.a = e->hbuf; dn.lda = Imax; dn.out = e->ybuf; dn.ldo = D; dn.n_valid = D;
     dn.prologue = UMOE_PRO_PLAIN; dn.epilogue = UMOE_EPI_BF16;
     if (dense) dn.nt = 6;    // 220 workgroups of 8 waves: 22.2 vs 23.7 us with 8 blocks per workgroup (scripts/kbench.py flat)
-    if (tiled && !ov && G <= 12) {
+    if (tiled && G <= 12) {
         umoe_tgroup_t tg[12];
         memset(tg, 0, sizeof(tg));
         for (int x = 0; x < G; ++x) {
@@ -948,7 +956,7 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
             const char* fv = getenv("UMOE_FLAT_MOE");      // (read per enqueue: the step graph captures the choice; A/B scripts toggle it)
             const bool flat = fv ? atoi(fv) != 0 : e->flat_moe;
             const int n_wg = e->n_cu < 256 ? e->n_cu : 256;
-            if (flat && !rs_handoff && n_wg > 0) rc = umoe_moe_flat(&gu, &dn, e->ep_words + 64, 512 - 64, n_wg, s);
+            if (flat && n_wg > 0) rc = umoe_moe_flat(&gu, &dn, e->ep_words + 64, 512 - 64, n_wg, s);
             e->expert_launch = rc == 0 ? 2 : 0;
         }
         if (rc == 1 && box_fits) {
@@ -956,7 +964,6 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
             if (rc == 0) e->expert_launch = 1;
         }
         UMOE_REQUIRE(!(rc == 1 && !box_fits), "umoe_engine: no expert launch with in-launch hand-offs fits %d compute units (UMOE_RIDER_PUB=0 selects the launch-per-kernel path)", e->n_cu);
-        UMOE_REQUIRE(!(rc == 1 && rs_handoff), "umoe_engine: the fused expert launch refused the shapes it was configured for (UMOE_RS_HANDOFF=0 selects the other form)");
         if (rc == 1) {
             if ((rc = umoe_grouped_gemm(&gu, s))) return rc;
             rc = umoe_grouped_gemm(&dn, s);
@@ -968,7 +975,6 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         if (rc) return rc;
         PROF(K_DOWN);
     }
-    if (ov) UMOE_HIP(hipStreamWaitEvent(s, e->ev_join, 0));
     // 9. combine + residual -> next layer input                   core.py:488,342-351; model.py:242
     umoe_combine_args cb{};
     cb.y_slots = e->ybuf; cb.shared_row0 = -1; cb.slot_of = dense ? nullptr : e->slot_of; cb.moe_w = e->r_moe;
@@ -1064,7 +1070,10 @@ __global__ void step_prep_kernel(const int32_t* __restrict__ tokens, const int32
                                  int Tmax, int T_prompt, int Lmax, const int32_t* __restrict__ valid_count,
                                  int32_t* tok_in, int32_t* pos3, int32_t* kv_pos, int32_t* q_pos0, uint32_t* ep_step) {
     const int row = blockIdx.x, b = row >> 1;
-    if (row == 0 && threadIdx.x == 0) ep_step[0] += 1u;   // epoch base of this step's expert-parallel hand-offs (read by later launches)
+    if (row == 0 && threadIdx.x == 0) {
+        ep_step[0] += 1u;   // epoch base of this step's in-launch hand-offs (read by later launches; a prefill bumps it too)
+        ep_step[2] += 1u;   // decode steps only: base of the expert-parallel return counters' rounds (umoe_moe_ep.hip)
+    }
     const int step = state[4 * B];
     const int n_dec = step - state[4 * B + 4];  // state[4B+4] = dec_step of the first decode call
     const int ts = min(max(step, 0), Tmax - 1);

@@ -90,9 +90,10 @@ __device__ __forceinline__ uint32_t flat_epoch(const umoe_rider_pub& pub) {
 }
 
 template <int NP, bool PUBLISH = true>
-__device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider_pub& pub, const int fp0, const unsigned b, char* smem, flat_stamps& st) {
+__device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider_pub& pub, const int fp0, const unsigned b, char* smem, flat_stamps& st,
+                                            const int tid_in) {      // tid_in = threadIdx.x (a caller that loops over slices passes an opaque copy: see umoe_moe_ep.hip)
     constexpr int NT = 2 * NP, WV = 8, KB = 64;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tid_in, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: every guard around an MFMA is a scalar branch
     constexpr int QS = (KB * 16 + 255) & ~255, RS = QS * 4;
     const int i0 = __builtin_amdgcn_readfirstlane((KB * wave) / WV), i1 = __builtin_amdgcn_readfirstlane((KB * (wave + 1)) / WV);
@@ -249,9 +250,9 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
 // depend on U then, and a 1-step stream has no clamped duplicate step at the end of a wave's slice.
 template <int ND, int U>
 __device__ __forceinline__ void flat_down(const flat_args& A, const umoe_rider_pub& pub, const int grp, const int nb0, char* smem, flat_stamps& st,
-                                          const int sb) {
+                                          const int sb, const int tid_in) {
     constexpr int NT = ND, WV = 8;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tid_in, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int KB = A.dn_kb[grp];
     const int QS = (KB * 16 + 255) & ~255, RS = QS * 4;

@@ -141,39 +141,17 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
     (void)KID;
     TL_ENTER(KID);
     // group descriptor: from the kernel arguments when the host passed them by value (scalar loads, no HBM round trip)
-    // FLAT mode (SwiGLU, dense-expert decode: every group reads the SAME activation rows): blockIdx.x enumerates
-    // p.flat_wgs equal slices of ALL groups' gate/up pairs, so every CU streams the same number of bytes whatever the
-    // group sizes are (the per-CU byte balance decides this kernel, see the launcher).  A slice may straddle two groups.
-    const bool flat = EPI == UMOE_EPI_SWIGLU && p.flat_wgs > 0;
+    // (measured and removed: blockIdx.x enumerating equal slices of ALL groups' gate/up pairs inside THIS kernel -- 42.4 vs 37.3 us: a
+    //  6-pair slice re-read its 7th register slot; the byte-balanced form is its own launch now, umoe_moe_flat.hip)
     const unsigned zg = blk.z - ((FR && rider_mode == 1) ? 1u : 0u);      // group index
     // BV (descriptors known to be by value: riders / the fused launch need them, the small decode launches are dispatched on it): plain
     // kernel-argument reads = scalar loads.  Left to a run-time choice the compiler selects between the two ADDRESSES and reads the
     // descriptor with flat loads through the vector memory path -- two dependent round trips in front of the first request.
-    const umoe_group_t g = (BV || FR || XW != 0) ? gp.g[flat ? 0 : zg] : (p.groups_host ? gp.g[flat ? 0 : zg] : p.groups[zg]);
+    const umoe_group_t g = (BV || FR || XW != 0) ? gp.g[zg] : (p.groups_host ? gp.g[zg] : p.groups[zg]);
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     const int ks = ksplit > 1 ? (int)(blk.x % ksplit) : 0;      // K-slice of this workgroup (fp32 partial slab `ks`)
     const int nb0 = (ksplit > 1 ? (int)(blk.x / ksplit) : (int)blk.x) * NT;
-    int fp0 = 0, fnp = 0;                    // flat: first global pair and number of pairs of this workgroup
-    if (flat) {
-        int P = 0;
-        for (int i = 0; i < p.num_groups; ++i) P += gp.g[i].n_blocks >> 1;
-        fp0 = (int)(((long)blk.x * P) / p.flat_wgs);
-        fnp = (int)(((long)(blk.x + 1) * P) / p.flat_wgs) - fp0;
-        if (fnp <= 0) return 1;
-    } else if (nb0 >= g.n_blocks) {
-        return 1;
-    }
-    // flat: global pair -> (group, pair inside the group)
-    auto locate = [&](int pp, int& grp, int& lp) {
-        grp = 0;
-        lp = pp;
-        for (int i = 0; i + 1 < p.num_groups; ++i) {
-            const int np = gp.g[i].n_blocks >> 1;
-            if (lp < np) break;
-            lp -= np;
-            grp = i + 1;
-        }
-    };
+    if (nb0 >= g.n_blocks) return 1;
 
     const int K = g.k, KB = K >> 5;
     // this workgroup covers MFMA k-steps [ia, ib) of every K-quarter; only those activation chunks are staged
@@ -208,14 +186,8 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        if (flat) {
-            int grp, lp;
-            locate(fp0 + min(t >> 1, fnp - 1), grp, lp);    // pairs beyond the slice re-read its last pair; never stored
-            wp[t] = reinterpret_cast<const u32x4_t*>(gp.g[grp].w) + ((size_t)(2 * lp + (t & 1)) * KB) * 64 + lane;
-        } else {
-            const int nb = min(nb0 + t, g.n_blocks - 1);  // tail tiles re-read the last block; never stored
-            wp[t] = reinterpret_cast<const u32x4_t*>(g.w) + ((size_t)nb * KB) * 64 + lane;
-        }
+        const int nb = min(nb0 + t, g.n_blocks - 1);  // tail tiles re-read the last block; never stored
+        wp[t] = reinterpret_cast<const u32x4_t*>(g.w) + ((size_t)nb * KB) * 64 + lane;
     }
     u32x4_t w0[NT][U], w1[NT][U];
     auto load_chunk = [&](u32x4_t (&dst)[NT][U], int ibase) {
@@ -548,18 +520,9 @@ __device__ __forceinline__ int wstream_body(const umoe_gemm_args& p, const umoe_
     const long orow = (long)g.out_row_base + roff + r;
     if (EPI == UMOE_EPI_SWIGLU) {
         for (int q = wave; q < NT / 2; q += WV) {
-            int col;
-            long orow_q = orow;
-            if (flat) {
-                if (q >= fnp) break;
-                int grp, lp;
-                locate(fp0 + q, grp, lp);
-                col = lp * 16 + 4 * h;
-                orow_q = (long)gp.g[grp].out_row_base + roff + r;
-            } else {
-                if (nb0 + 2 * q >= g.n_blocks) break;
-                col = (nb0 / 2 + q) * 16 + 4 * h;
-            }
+            if (nb0 + 2 * q >= g.n_blocks) break;
+            const int col = (nb0 / 2 + q) * 16 + 4 * h;
+            const long orow_q = orow;
             const f32x4_t ga = reduced(2 * q), ua = reduced(2 * q + 1);
             uint16_t y[4];
 #pragma unroll
@@ -649,14 +612,14 @@ __global__ __launch_bounds__(WV * 64, 2) void wstream_gemm(const umoe_gemm_args 
 
 // A one-block-per-workgroup decode GEMM (QKV with bias / o_proj with residual: NT 1, 4 waves) with ROW riders in front
 // (umoe_riders_dev.h): workgroups [0, n_riders) run the row kernel that produces this GEMM's activation rows (RK 2: MoE combine +
-// residual + RMSNorm of the previous layer; RK 3: merge of the attention key splits) and hand them over; the GEMM tiles follow.
+// residual + RMSNorm of the previous layer; RK 4: the same over the return slab of the expert-parallel exchange) and hand them over;
+// the GEMM tiles follow.
 template <int EPI, int RK>
 __global__ __launch_bounds__(256, 2) void wstream_gemm_rk(const umoe_gemm_args p, const umoe_group_pack gp, const umoe_rider_pub pub, const umoe_rider2 r2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < r2.n_riders) {
         const uint32_t epoch = *pub.step * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
-        if constexpr (RK == 2) combine_row_dense(r2.cb, (int)blockIdx.x, reinterpret_cast<float*>(smem), pub.flags + blockIdx.x, epoch);
-        else attn_merge_row<8>(r2, (int)blockIdx.x, pub.flags + blockIdx.x, epoch);
+        combine_row_dense<RK == 4>(r2.cb, r2, (int)blockIdx.x, reinterpret_cast<float*>(smem), pub.flags + blockIdx.x, epoch);
         return;
     }
     const umoe_fuse_x fx{};
@@ -723,7 +686,6 @@ static int launch_gemm(const umoe_gemm_args* a, hipStream_t s) {
         configured = lds;
     }
     dim3 grid((unsigned)(ceil_div(a->max_n_blocks, NT) * ksplit), (unsigned)ceil_div(a->max_rows, 16), (unsigned)a->num_groups);
-    if (EPI == UMOE_EPI_SWIGLU && a->flat_wgs > 0) grid = dim3((unsigned)a->flat_wgs, 1, 1);
     umoe_group_pack gp;
     umoe_gemm_args b = *a;
     if (a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE) {
@@ -768,16 +730,13 @@ int umoe_gemm_riders(const umoe_gemm_args* a, int kind, const umoe_rider2* r2, c
         return 1;
     const umoe_group_t& g = a->groups_host[0];
     if (g.rows || g.count || g.row_off || g.a_row_base || g.a_col_off || g.static_count != r2->n_riders) return 1;
-    if (kind == 2) {
+    if (kind == 2 || kind == 4) {
         const umoe_combine_args& c = r2->cb;
         if (!(a->epilogue == UMOE_EPI_BF16 && c.D == 2048 && c.S == r2->n_riders && !c.slot_of && !c.y_parts && c.expert_mask && c.y_slots && c.y_shared &&
               c.global_w && c.moe_w && c.resid && c.out && c.norm_w && c.norm_out == a->a && a->lda == c.D && a->max_k == c.D && c.n_real >= 1 &&
               c.n_real <= UMOE_MAXE && c.n_fix >= 1 && c.n_fix <= 4 && c.dense_rows >= c.S && !c.ep_xfer))
             return 1;
-    } else if (kind == 3) {
-        if (!(a->epilogue == UMOE_EPI_BF16_RESID && a->resid && r2->splits == 8 && r2->H == 16 && r2->part_o && r2->part_ml && r2->attn_out == a->a &&
-              a->lda == r2->H * 128 && a->max_k == r2->H * 128))
-            return 1;
+        if (kind == 4 && !(r2->ep_region && r2->ep_round && r2->ep_err && r2->ep_n_cwg > 0 && r2->ep_size >= 2 && c.n_real % r2->ep_size == 0)) return 1;
     } else {
         return 1;
     }
@@ -786,7 +745,7 @@ int umoe_gemm_riders(const umoe_gemm_args* a, int kind, const umoe_rider2* r2, c
     memset(&gp, 0, sizeof(gp));
     gp.g[0] = g;
     const dim3 grid((unsigned)(r2->n_riders + a->max_n_blocks), 1, 1);
-    static size_t conf2 = 0, conf3 = 0;
+    static size_t conf2 = 0, conf4 = 0;
     if (kind == 2) {
         if (lds > conf2) {
             UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm_rk<UMOE_EPI_BF16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -794,11 +753,11 @@ int umoe_gemm_riders(const umoe_gemm_args* a, int kind, const umoe_rider2* r2, c
         }
         wstream_gemm_rk<UMOE_EPI_BF16, 2><<<grid, 256, lds, s>>>(*a, gp, *pub, *r2);
     } else {
-        if (lds > conf3) {
-            UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm_rk<UMOE_EPI_BF16_RESID, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            conf3 = lds;
+        if (lds > conf4) {
+            UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wstream_gemm_rk<UMOE_EPI_BF16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            conf4 = lds;
         }
-        wstream_gemm_rk<UMOE_EPI_BF16_RESID, 3><<<grid, 256, lds, s>>>(*a, gp, *pub, *r2);
+        wstream_gemm_rk<UMOE_EPI_BF16, 4><<<grid, 256, lds, s>>>(*a, gp, *pub, *r2);
     }
     UMOE_LAUNCH_CHECK();
     return 0;
@@ -810,7 +769,7 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
     if (!(gu->fused_router && gu->rider_pub && gu->groups_host && dn->groups_host && G == dn->num_groups && G <= UMOE_GROUPS_INLINE && gu->nt == 14 &&
           dn->nt == 6 && (gu->prologue == UMOE_PRO_PLAIN || (gu->prologue == UMOE_PRO_RMSNORM && gu->max_k == 2048 && gu->norm_w)) &&
           gu->epilogue == UMOE_EPI_SWIGLU && dn->prologue == UMOE_PRO_PLAIN &&
-          dn->epilogue == UMOE_EPI_BF16 && gu->flat_wgs == 0 && gu->ksplit <= 1 && dn->ksplit <= 1 && gu->max_rows <= 16 && dn->max_rows <= 16 &&
+          dn->epilogue == UMOE_EPI_BF16 && gu->ksplit <= 1 && dn->ksplit <= 1 && gu->max_rows <= 16 && dn->max_rows <= 16 &&
           dn->a == gu->out && dn->lda == gu->ldo && !dn->fused_router && gu->max_k % 32 == 0 && dn->max_k % 32 == 0))
         return 1;
     const umoe_router_args* r = gu->fused_router;
@@ -914,7 +873,7 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
     UMOE_REQUIRE((a->lda & 7) == 0, "umoe_grouped_gemm: lda must be a multiple of 8 (16-byte rows)");
     UMOE_REQUIRE(a->ksplit <= 1 || (a->epilogue == UMOE_EPI_F32_RAW && a->prologue == UMOE_PRO_PLAIN && a->ksplit <= 4),
                  "umoe_grouped_gemm: ksplit > 1 needs the plain prologue and the raw fp32 partial-slab epilogue");
-    UMOE_REQUIRE(!a->fused_router || (a->epilogue == UMOE_EPI_SWIGLU && a->nt == 14 && a->flat_wgs == 0 &&
+    UMOE_REQUIRE(!a->fused_router || (a->epilogue == UMOE_EPI_SWIGLU && a->nt == 14 &&
                                       (a->prologue == UMOE_PRO_PLAIN || (a->prologue == UMOE_PRO_RMSNORM && !a->rider_pub && a->max_k == 2048))),
                  "umoe_grouped_gemm: fused_router rides only in the SwiGLU launch with nt = 14 (RMSNorm prologue: K 2048, no rider_pub)");
     hipStream_t s = (hipStream_t)stream;
@@ -955,21 +914,6 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
             return launch_gemm_nt<UMOE_PRO_PLAIN, UMOE_EPI_BF16_RESID>(a, auto_nt(a, false), s);
         case UMOE_EPI_SWIGLU: {
             UMOE_REQUIRE(a->max_n_blocks % 2 == 0, "umoe_grouped_gemm: SwiGLU needs gate/up block pairs");
-            if (a->flat_wgs > 0) {
-                // flat slices over all groups: static groups sharing the activation rows, descriptors by value, 7 pairs max
-                UMOE_REQUIRE(a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE && a->max_rows <= 16 && a->ksplit <= 1,
-                             "umoe_grouped_gemm: flat mode needs host group descriptors, <= 16 rows, no K split");
-                long P = 0;
-                for (int i = 0; i < a->num_groups; ++i) {
-                    const umoe_group_t& gi = a->groups_host[i];
-                    UMOE_REQUIRE(!gi.count && !gi.rows && !gi.row_off && gi.k == a->groups_host[0].k && gi.a_row_base == a->groups_host[0].a_row_base &&
-                                     gi.static_count == a->groups_host[0].static_count && gi.n_blocks % 2 == 0,
-                                 "umoe_grouped_gemm: flat mode needs static groups over the same rows and K (group %d)", i);
-                    P += gi.n_blocks / 2;
-                }
-                UMOE_REQUIRE(ceil_div((int)P, a->flat_wgs) <= 7, "umoe_grouped_gemm: flat mode: %ld pairs over %d workgroups exceed 7 per workgroup", P, a->flat_wgs);
-                return launch_gemm<14, 1, UMOE_PRO_PLAIN, UMOE_EPI_SWIGLU, 8>(a, s);
-            }
             const int nt = auto_nt(a, true);
             UMOE_REQUIRE(nt >= 2, "umoe_grouped_gemm: SwiGLU needs nt >= 2");
             // (8 waves, 1-step chunks: the K split of the 14-block dense decode launch -- see launch_gemm_nt)

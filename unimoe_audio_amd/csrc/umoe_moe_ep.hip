@@ -60,9 +60,8 @@ __device__ __forceinline__ uint32_t epf_round(const epf_args& P, const umoe_ride
 }
 
 // ---- tile rider: push the own raw rows to rank j (REAL exchange: j != rank; loopback: into the own slab, tile j), then make tile j ----
-__device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rider_pub& pub, const int j, char* smem) {
+__device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rider_pub& pub, const int j, char* smem, const int tid) {
     constexpr int KB = 64, TPR = 32;
-    const int tid = threadIdx.x;
     const int m = tid / TPR, sub = tid % TPR;
     const bool valid = m < P.S.S;
     const uint32_t epoch = flat_epoch(pub);
@@ -148,9 +147,9 @@ __device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rid
 // inside this launch); K split over the 8 waves in whole U-step chunks, fixed-order LDS reduction ----
 template <int NT, int MT, int U, int RW, int RB, bool SWIGLU>
 __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const int nb0, const int KB, const uint16_t* wbase, const uint16_t* fbase,
-                                       const int ftile0, const int fbytes, char* smem) {
+                                       const int ftile0, const int fbytes, char* smem, const int tid) {
     constexpr int WV = 8;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int i0, i1;
     if (KB % U == 0) {
@@ -253,8 +252,8 @@ __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const i
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = f2bf(rbf(a4[j] + 0.f));
             const int dr = P.loopback ? P.rank : m, sr = P.loopback ? m : P.rank;
-            char* dst = P.peer_base[dr] + P.ret_off + ((size_t)(sr * P.E_loc + grp) * 16) * (size_t)P.D * 2;
-            const auto yrs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, 16 * P.D * 2, 0x00020000);
+            char* dst = P.peer_base[dr] + P.ret_off + ((size_t)(sr * P.E_loc + grp) * P.S.S) * (size_t)P.D * 2;      // slab [n_real][S][D]
+            const auto yrs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, P.S.S * P.D * 2, 0x00020000);
             const epf_u32x2 v2 = {(uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16)};
             if (mm < P.S.S) __builtin_amdgcn_raw_buffer_store_b64(v2, yrs, (mm * P.D + n) * 2, 0, UMOE_SYS_AUX);
         }
@@ -281,15 +280,18 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
     flat_stamps st;
     bool tiles_seen = false;
     unsigned seam_seen = 0u;
-    const int tid = threadIdx.x;
     for (int ti = 0; ti < UMOE_EPF_MAXT; ++ti) {
+        // an OPAQUE copy of the thread index per task: with the plain threadIdx.x every per-lane address of every task kind is
+        // loop-invariant, hipcc hoists them all in front of the loop and spills ~170 registers at kernel entry
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
         const uint32_t tw = __builtin_amdgcn_readfirstlane(tl[ti]);
         const unsigned kind = tw >> 28;
         if (kind == EPF_END) break;
         const int grp = (int)((tw >> 24) & 15u), first = (int)((tw >> 8) & 0xffffu), n = (int)(tw & 255u);
         if (ti) __syncthreads();        // (the reduction slab of the previous task is the staging area of this one)
         if (kind == EPF_TILE) {
-            epf_tile_rider(P, pub, grp, smem);
+            epf_tile_rider(P, pub, grp, smem, tid);
         } else if (kind == EPF_ROUTER) {
             float* rl = reinterpret_cast<float*>(smem + lds_gemm);
             if (tid < 256) {
@@ -301,13 +303,13 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
             }
         } else if (kind == EPF_A) {
             switch (n) {
-                case 1: flat_gateup<1, false>(P.S, pub, first, b, smem, st); break;
-                case 2: flat_gateup<2, false>(P.S, pub, first, b, smem, st); break;
-                case 3: flat_gateup<3, false>(P.S, pub, first, b, smem, st); break;
-                case 4: flat_gateup<4, false>(P.S, pub, first, b, smem, st); break;
-                case 5: flat_gateup<5, false>(P.S, pub, first, b, smem, st); break;
-                case 6: flat_gateup<6, false>(P.S, pub, first, b, smem, st); break;
-                default: flat_gateup<7, false>(P.S, pub, first, b, smem, st); break;
+                case 1: flat_gateup<1, false>(P.S, pub, first, b, smem, st, tid); break;
+                case 2: flat_gateup<2, false>(P.S, pub, first, b, smem, st, tid); break;
+                case 3: flat_gateup<3, false>(P.S, pub, first, b, smem, st, tid); break;
+                case 4: flat_gateup<4, false>(P.S, pub, first, b, smem, st, tid); break;
+                case 5: flat_gateup<5, false>(P.S, pub, first, b, smem, st, tid); break;
+                case 6: flat_gateup<6, false>(P.S, pub, first, b, smem, st, tid); break;
+                default: flat_gateup<7, false>(P.S, pub, first, b, smem, st, tid); break;
             }
         } else if (kind == EPF_PUB_A || kind == EPF_PUB_B) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -324,12 +326,12 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
             const uint16_t* w = P.w_lgu[grp];
             constexpr int NTB = 16 / MT;          // blocks per pass: 8 / 4 / 2 at 2 / 4 / 8 tiles
             const int fb = MT * 16 * P.D * 2;
-            if (2 * n == NTB) epf_mt<NTB, MT, 1, (NTB >= 8 ? 4 : 8), 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem);
+            if (2 * n == NTB) epf_mt<NTB, MT, 1, (NTB >= 8 ? 4 : 8), 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid);
             else if constexpr (NTB >= 4) {
-                if (2 * n == NTB / 2) epf_mt<NTB / 2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem);
+                if (2 * n == NTB / 2) epf_mt<NTB / 2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid);
                 else if constexpr (NTB >= 8) {
-                    if (n == 3) epf_mt<6, MT, 1, 4, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem);
-                    else epf_mt<2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem);
+                    if (n == 3) epf_mt<6, MT, 1, 4, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid);
+                    else epf_mt<2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid);
                 }
             }
         } else if (kind == EPF_C) {
@@ -341,11 +343,13 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
             const uint16_t* w = P.w_ldn[grp];
             const int KB = P.I >> 5, fb = P.E_loc * MT * 16 * P.I * 2;
             constexpr int NTC = MT >= 8 ? 2 : (MT >= 4 ? 4 : 8);
-            if (n == NTC) epf_mt<NTC, MT, 2, 8, 4, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem);
-            else if (n == NTC / 2) epf_mt<NTC / 2, MT, 2, 8, 4, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem);
+            // register rings: RW k-steps of NT weight blocks (<= 128 VGPRs), RB k-steps of MT fragments (<= 64)
+            constexpr int RBC = MT >= 8 ? 2 : 4;
+            if (n == NTC) epf_mt<NTC, MT, 2, (NTC >= 4 ? 4 : 8), RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid);
+            else if (n == NTC / 2) epf_mt<NTC / 2, MT, 2, (NTC / 2 >= 4 ? 4 : 8), RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid);
             else if constexpr (NTC >= 4) {
-                if (n == NTC / 4) epf_mt<NTC / 4, MT, 2, 8, 4, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem);
-                else if constexpr (NTC >= 8) epf_mt<1, MT, 2, 8, 4, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem);
+                if (n == NTC / 4) epf_mt<NTC / 4, MT, 2, 8, RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid);
+                else if constexpr (NTC >= 8) epf_mt<1, MT, 2, 8, RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid);
             }
         } else if (kind == EPF_SIG_C) {
             // every storing wave drains its system-scope stores, the workgroup meets, lane t counts this workgroup in on the owner of tile t
@@ -357,16 +361,16 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
             }
         } else if (kind == EPF_D) {
             switch (n) {
-                case 1: flat_down<1, 1>(P.S, pub, grp, first, smem, st, 7); break;
-                case 2: flat_down<2, 1>(P.S, pub, grp, first, smem, st, 7); break;
-                case 3: flat_down<3, 1>(P.S, pub, grp, first, smem, st, 7); break;
-                case 4: flat_down<4, 1>(P.S, pub, grp, first, smem, st, 7); break;
-                case 5: flat_down<5, 1>(P.S, pub, grp, first, smem, st, 7); break;
-                case 6: flat_down<6, 1>(P.S, pub, grp, first, smem, st, 7); break;
-                case 7: flat_down<7, 1>(P.S, pub, grp, first, smem, st, 7); break;
-                case 8: flat_down<8, 1>(P.S, pub, grp, first, smem, st, 7); break;
-                case 9: flat_down<9, 1>(P.S, pub, grp, first, smem, st, 7); break;
-                default: flat_down<10, 1>(P.S, pub, grp, first, smem, st, 7); break;
+                case 1: flat_down<1, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
+                case 2: flat_down<2, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
+                case 3: flat_down<3, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
+                case 4: flat_down<4, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
+                case 5: flat_down<5, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
+                case 6: flat_down<6, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
+                case 7: flat_down<7, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
+                case 8: flat_down<8, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
+                case 9: flat_down<9, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
+                default: flat_down<10, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
             }
         }
     }

@@ -60,10 +60,10 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
     }
     const int fp0 = (int)(eg & 2047u), np = (int)((eg >> 11) & 7u);
     switch (np) {
-        case 4: flat_gateup<4>(A, pub, fp0, b, smem, st); break;
-        case 5: flat_gateup<5>(A, pub, fp0, b, smem, st); break;
-        case 6: flat_gateup<6>(A, pub, fp0, b, smem, st); break;
-        case 7: flat_gateup<7>(A, pub, fp0, b, smem, st); break;
+        case 4: flat_gateup<4>(A, pub, fp0, b, smem, st, (int)threadIdx.x); break;
+        case 5: flat_gateup<5>(A, pub, fp0, b, smem, st, (int)threadIdx.x); break;
+        case 6: flat_gateup<6>(A, pub, fp0, b, smem, st, (int)threadIdx.x); break;
+        case 7: flat_gateup<7>(A, pub, fp0, b, smem, st, (int)threadIdx.x); break;
         default: break;
     }
     for (int sl = 0; sl < FLAT_SLICES; ++sl) {
@@ -73,25 +73,25 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
         __syncthreads();     // (the reduction slab of the previous GEMM is the staging area of this one)
         if (A.dn_kb[grp] & 1) {
             switch (nd) {
-                case 1: flat_down<1, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 2: flat_down<2, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 3: flat_down<3, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 4: flat_down<4, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 5: flat_down<5, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 6: flat_down<6, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 7: flat_down<7, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 8: flat_down<8, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 9: flat_down<9, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                default: flat_down<10, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 1: flat_down<1, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 2: flat_down<2, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 3: flat_down<3, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 4: flat_down<4, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 5: flat_down<5, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 6: flat_down<6, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 7: flat_down<7, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 8: flat_down<8, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 9: flat_down<9, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                default: flat_down<10, 1>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
             }
         } else {
             switch (nd) {
-                case 1: flat_down<1, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 2: flat_down<2, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 3: flat_down<3, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 4: flat_down<4, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                case 5: flat_down<5, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
-                default: flat_down<6, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl); break;
+                case 1: flat_down<1, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 2: flat_down<2, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 3: flat_down<3, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 4: flat_down<4, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                case 5: flat_down<5, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
+                default: flat_down<6, 2>(A, pub, grp, nb0, smem, st, 7 + 4 * sl, (int)threadIdx.x); break;
             }
         }
     }

@@ -4,17 +4,22 @@
 // launch boundary between the two kernels and the second kernel's cold start leave the chain.
 //   combine_row_dense: combine_kernel<false, true> of umoe_misc.hip for ONE row (dense decode layout, D = 2048: one 16-byte chunk per
 //     thread), same loads, same arithmetic order, same fixed-order RMSNorm sum -> bit-identical rows          (core.py:488,342-351)
-//   attn_merge_row:    attn_combine_kernel<8> of umoe_attn.hip for ONE row (thread -> head tid/16, 8 value columns)
+//     EPC (expert parallel, umoe_moe_ep.hip): the routed experts' rows sit in this rank's RETURN slab; lane e of wave 0 waits until the
+//     owner of expert e has counted all its workgroups in for this round, and every load of the slab is a system-scope load
+// (Measured and removed: the merge of the attention key splits riding in the o_proj launch the same way -- 3.18 vs 3.13 ms/step: the
+//  merge is 1 us of work, its hand-off costs more than the launch boundary it removes.)
 #pragma once
 #include "umoe_common.h"
 
 struct umoe_rider2 {
     int n_riders;                  // rows (= rider workgroups in front of the GEMM tiles)
     umoe_combine_args cb;          // kind 2: MoE combine + residual + next RMSNorm; cb.norm_out is the GEMM's activation operand
-    const float* part_o;           // kind 3: attention split partials [row][H][splits][128], [row][H][splits][2]
-    const float* part_ml;
-    uint16_t* attn_out;            //         merged rows [row][H * 128] = the GEMM's activation operand
-    int H, splits;
+    // kind 4 (expert parallel): cb.y_slots = this rank's return slab [n_real][S][D] inside `ep_region`
+    char* ep_region;               // own exchange region (counters: umoe_ep_flag(ep_region, 1, source rank, 0))
+    const uint32_t* ep_round;      // device word: rounds base (decode steps taken)
+    int ep_layer, ep_layers;       // the layer whose experts produced the rows: round = *ep_round * ep_layers + ep_layer + 1
+    int ep_size, ep_n_cwg;         // ranks; workgroups that count themselves in per round and source rank
+    uint32_t* ep_err;
 };
 
 __device__ __forceinline__ void rider_publish(uint32_t* flag, uint32_t epoch) {
@@ -31,7 +36,8 @@ __device__ __forceinline__ void st16_sc1(uint16_t* base, long elem_off, uint4 v,
     __builtin_amdgcn_raw_buffer_store_b128(v4, rsrc, (int)(elem_off * 2), 0, 16);      // aux 16 = sc1 (agent-scope write-through)
 }
 
-__device__ __forceinline__ void combine_row_dense(const umoe_combine_args& a, const int s, float* sh, uint32_t* flag, const uint32_t epoch) {
+template <bool EPC>
+__device__ __forceinline__ void combine_row_dense(const umoe_combine_args& a, const umoe_rider2& r2, const int s, float* sh, uint32_t* flag, const uint32_t epoch) {
     const int tid = threadIdx.x, lane = tid & 63, c = tid;          // D = 2048: chunk c of the row
     const int E = a.n_dyn + a.n_fix;
     // tables (lane e <- entry e; clamped, straight-line) and every row this token needs, all in one round trip
@@ -39,9 +45,27 @@ __device__ __forceinline__ void combine_row_dense(const umoe_combine_args& a, co
     const float sw_l = a.global_w[(size_t)s * E + a.n_dyn + min(lane, a.n_fix - 1)];
     const int tab_v = a.expert_mask[(size_t)s * a.mask_ld + min(lane, a.n_real - 1)];
     uint4 yv[UMOE_MAXE], sv[4];
+    if constexpr (EPC) {
+        // expert e's rows come from rank e / E_loc: wait until that rank has counted every one of its phase C workgroups in (bounded)
+        if (tid < a.n_real) {
+            const int src = tid / (a.n_real / r2.ep_size);
+            const uint32_t target = (__builtin_nontemporal_load(r2.ep_round) * (uint32_t)r2.ep_layers + (uint32_t)r2.ep_layer + 1u) * (uint32_t)r2.ep_n_cwg;
+            umoe_ep_wait(umoe_ep_flag(r2.ep_region, 1, src, 0), target, r2.ep_err);
+        }
+        __syncthreads();
+        typedef uint32_t u32x4_ep __attribute__((ext_vector_type(4)));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.y_slots), 0, a.n_real * a.dense_rows * a.D * 2, 0x00020000);
 #pragma unroll
-    for (int e = 0; e < UMOE_MAXE; ++e)
-        if (e < a.n_real) yv[e] = ld16(a.y_slots + (size_t)(e * a.dense_rows + s) * a.D + c * 8);
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < a.n_real) {
+                const u32x4_ep t4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((e * a.dense_rows + s) * a.D + c * 8) * 2, 0, UMOE_SYS_AUX);
+                yv[e] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+            }
+    } else {
+#pragma unroll
+        for (int e = 0; e < UMOE_MAXE; ++e)
+            if (e < a.n_real) yv[e] = ld16(a.y_slots + (size_t)(e * a.dense_rows + s) * a.D + c * 8);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < a.n_fix) sv[i] = ld16(a.y_shared + ((size_t)i * a.S + s) * a.D + c * 8);
@@ -99,41 +123,5 @@ __device__ __forceinline__ void combine_row_dense(const umoe_combine_args& a, co
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(acc[j] * rs);
     st16_sc1(a.norm_out, (long)s * a.D + c * 8, pack8(f), (long)a.S * a.D * 2);
-    rider_publish(flag, epoch);
-}
-
-template <int SP>
-__device__ __forceinline__ void attn_merge_row(const umoe_rider2& r, const int qi, uint32_t* flag, const uint32_t epoch) {
-    constexpr int HD = 128;
-    const int tid = threadIdx.x, head = tid >> 4, d8 = (tid & 15) * 8;
-    const float* pm = r.part_ml + ((size_t)qi * r.H + head) * SP * 2;
-    const float* po = r.part_o + ((size_t)qi * r.H + head) * SP * HD + d8;
-    float2 ml[SP];
-    float4 ov[SP][2];
-#pragma unroll
-    for (int s = 0; s < SP; ++s) {
-        ml[s] = *reinterpret_cast<const float2*>(pm + 2 * s);
-        ov[s][0] = *reinterpret_cast<const float4*>(po + (size_t)s * HD);
-        ov[s][1] = *reinterpret_cast<const float4*>(po + (size_t)s * HD + 4);
-    }
-    float mm = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < SP; ++s) mm = fmaxf(mm, ml[s].x);
-    float L = 0.f, acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int s = 0; s < SP; ++s) {
-        const float sc = (ml[s].x == -INFINITY) ? 0.f : __expf(ml[s].x - mm);
-        L += sc * ml[s].y;
-        acc[0] += sc * ov[s][0].x; acc[1] += sc * ov[s][0].y; acc[2] += sc * ov[s][0].z; acc[3] += sc * ov[s][0].w;
-        acc[4] += sc * ov[s][1].x; acc[5] += sc * ov[s][1].y; acc[6] += sc * ov[s][1].z; acc[7] += sc * ov[s][1].w;
-    }
-    uint16_t y[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) y[j] = f2bf(L > 0.f ? acc[j] / L : 0.f);
-    const uint4 pk = make_uint4((uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16), (uint32_t)y[4] | ((uint32_t)y[5] << 16),
-                                (uint32_t)y[6] | ((uint32_t)y[7] << 16));
-    st16_sc1(r.attn_out, ((long)qi * r.H + head) * HD + d8, pk, (long)r.n_riders * r.H * HD * 2);
     rider_publish(flag, epoch);
 }

@@ -242,12 +242,12 @@ class GroupTable:
 
 def grouped_gemm(table: GroupTable, a: torch.Tensor, out: torch.Tensor, *, max_rows: int, prologue=PRO_PLAIN,
                  epilogue=EPI_BF16, norm_w=None, rms_eps=1e-6, resid=None, n_valid=None, nt=0, waves=0, ksplit=0, part_stride=0,
-                 cache_policy=0, flat_wgs=0):
+                 cache_policy=0):
     args = L.GemmArgs(groups=_p(table.dev), num_groups=table.n, max_rows=max_rows, max_n_blocks=table.max_n_blocks,
                       max_k=table.max_k, a=_p(a), lda=a.stride(0), norm_w=_p(norm_w), rms_eps=rms_eps, resid=_p(resid),
                       out=_p(out), ldo=out.stride(-2), n_valid=out.shape[1] if n_valid is None else n_valid,
                       prologue=prologue, epilogue=epilogue, nt=nt, waves=waves, ksplit=ksplit, part_stride=part_stride,
-                      groups_host=C.cast(table.host, C.c_void_p), cache_policy=cache_policy, flat_wgs=flat_wgs)
+                      groups_host=C.cast(table.host, C.c_void_p), cache_policy=cache_policy)
     L.check(L.lib().umoe_grouped_gemm(C.byref(args), _stream()), "umoe_grouped_gemm")
     return out
 
@@ -308,26 +308,18 @@ def qkv_mrope_kvappend(qkv, cos_tab, sin_tab, pos3, kv_pos, T, H, KVH, hd, secti
 
 
 def attention(q, k_cache, v_cache, kv_start, q_pos0, nq, H, splits=1, qkv_raw=None, cos_tab=None, sin_tab=None, pos3=None,
-              sections=(16, 24, 24), lse_out=None, single_launch=False, wide=0):
-    """q: rotated queries [rows*nq, H*hd]; or pass qkv_raw (decode, nq == 1) to fuse mRoPE + KV append into the kernel.
-    single_launch: the last key split to finish merges the partials (umoe_attn_args.sync) -- no combine launch.
-    wide (with qkv_raw, GQA group of 8): 8-wave workgroups, two per (row, kv head), split the keys over their waves and write the
-    output themselves (umoe_attn_args.wide): no key split across workgroups, no merge launch."""
+              sections=(16, 24, 24), lse_out=None):
+    """q: rotated queries [rows*nq, H*hd]; or pass qkv_raw (decode, nq == 1) to fuse mRoPE + KV append into the kernel."""
     rows, KVH, Lmax, hd = k_cache.shape
     n = (q if q is not None else qkv_raw).shape[0]
     dev0 = (q if q is not None else qkv_raw).device
     po = torch.empty((n, H, splits, hd), dtype=torch.float32, device=dev0)
     pm = torch.empty((n, H, splits, 2), dtype=torch.float32, device=dev0)
     out = torch.empty((n, H * hd), dtype=torch.bfloat16, device=dev0)
-    sync = None
-    if isinstance(single_launch, torch.Tensor):      # caller-owned counters [n, KVH] int32, zero before the first call
-        sync = single_launch
-    elif single_launch:
-        sync = torch.zeros((n, KVH), dtype=torch.int32, device=dev0)
     a = L.AttnArgs(q=_p(q), k_cache=_p(k_cache), v_cache=_p(v_cache), kv_start=_p(kv_start), q_pos0=_p(q_pos0), rows=rows,
                    nq=nq, H=H, KVH=KVH, hd=hd, Lmax=Lmax, splits=splits, scale=float(hd) ** -0.5, part_o=_p(po),
                    part_ml=_p(pm), out=_p(out), qkv_raw=_p(qkv_raw), cos_tab=_p(cos_tab), sin_tab=_p(sin_tab), pos3=_p(pos3),
-                   sec0=sections[0], sec1=sections[1], sec2=sections[2], lse_out=_p(lse_out), sync=_p(sync), wide=int(wide))
+                   sec0=sections[0], sec1=sections[1], sec2=sections[2], lse_out=_p(lse_out))
     if nq >= 16 and qkv_raw is None:       # many queries per row: MFMA flash-attention kernel (umoe_attn_prefill_fwd)
         L.check(L.lib().umoe_attn_prefill_fwd(C.byref(a), _stream()), "umoe_attn_prefill_fwd")
     else:
