@@ -25,10 +25,14 @@ def _run(cmd, env_extra=None, timeout=600):
     return p.returncode, p.stdout + p.stderr
 
 
-@pytest.mark.parametrize("ranks,graph", [(2, 0), (4, 1)])
-def test_ep_virtual_ranks_bit_identical(ranks, graph):
+@pytest.mark.parametrize("ranks,graph,flat", [(2, 0, 1), (4, 1, 1), (8, 1, 1), (2, 1, 0), (4, 0, 0)])
+def test_ep_virtual_ranks_bit_identical(ranks, graph, flat):
+    """2 / 4 / 8 ranks on one card (8 = BASELINE configs[3]'s own shape: one local expert per rank), eager and hipGraph replay, the MoE
+    half as ONE launch per rank (umoe_moe_ep.hip; each rank's launch takes 1/N of the CUs) and as the launch-per-kernel exchange
+    (UMOE_EP_FLAT=0): logits of every step and all tokens bit-identical to N independent ep_size 1 engines."""
     assert torch.cuda.is_available()
-    rc, out = _run([sys.executable, "scripts/ep_virtual.py", str(ranks), "2", "5", str(graph)], {"GPU_MAX_HW_QUEUES": "8"})
+    rc, out = _run([sys.executable, "scripts/ep_virtual.py", str(ranks), "2", "5", str(graph)],
+                   {"GPU_MAX_HW_QUEUES": "16" if ranks > 4 else "8", "UMOE_EP_FLAT": str(flat)})
     assert rc == 0 and "BIT-IDENTICAL" in out, out[-3000:]
 
 
