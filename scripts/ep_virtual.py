@@ -53,11 +53,13 @@ def main():
     # N ranks share this ONE card: the one-launch MoE half (umoe_moe_ep.hip) needs every workgroup of every rank's launch resident at
     # once, so each rank's engine is told it owns 1/N of the compute units (its launch is then that many workgroups)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    os.environ["UMOE_FAKE_CUS"] = str(cus // N)
+    # (16 CUs stay free: a rank's small launches -- attention, QKV -- must find room while the other ranks' expert launches spin)
+    share = (cus - 16) // N
+    os.environ["UMOE_FAKE_CUS"] = str(share)
     engs = [DecodeEngine(gm, B, Lmax=T + MAXT + 8, Tmax=MAXT + 64, ep=links[r], ep_connect=False) for r in range(N)]
     EpLink.local_mesh([e.h for e in engs])
     del os.environ["UMOE_FAKE_CUS"]
-    print(f"expert launch per rank: {'one launch, ' + str(cus // N) + ' workgroups' if os.environ.get('UMOE_EP_FLAT', '1') != '0' else 'launch per kernel'}")
+    print(f"expert launch per rank: {'one launch, ' + str(share) + ' workgroups' if os.environ.get('UMOE_EP_FLAT', '1') != '0' else 'launch per kernel'}")
     streams = [torch.cuda.Stream() for _ in range(N)]
     for r in range(N):
         with torch.cuda.stream(streams[r]):

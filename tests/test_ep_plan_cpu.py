@@ -23,7 +23,7 @@ def plan(n_wg, R, S=16, Dm=2048, I_dyn=2752, I_sh=1376, n_fix=2):
     return bool(a[0]), int(a[1]), a[2:].reshape(n_wg, MAXT)
 
 
-@pytest.mark.parametrize("n_wg,R", [(256, 2), (256, 4), (256, 8), (128, 2), (64, 4), (32, 8), (240, 8), (200, 2)])
+@pytest.mark.parametrize("n_wg,R", [(256, 2), (256, 4), (256, 8), (120, 2), (60, 4), (30, 8), (240, 8), (200, 2)])
 def test_ep_task_lists_cover_every_unit_once(n_wg, R):
     ok, n_cwg, t = plan(n_wg, R)
     assert ok

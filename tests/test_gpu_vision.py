@@ -134,3 +134,40 @@ def test_generate_with_video_prompt_prefill_and_steps_vs_oracle(dev):
         rel = (got - refs[s]).norm(dim=-1) / refs[s].norm(dim=-1)
         assert float(rel.median()) < 0.03 and float(rel.max()) < 0.25, (s, rel.tolist())
     eng.close()
+
+
+def test_generate_drops_the_pixels_like_the_reference_unless_asked(dev):
+    """The reference's generate() (utils/UniMoE_Audio_model.py:1109-1131) never feeds pixel_values(_videos) to the model: the pad tokens keep
+    their text embeddings and the positions stay 1-D.  Default (vision_in_generate=False): the codes with pixels equal the codes without;
+    vision_in_generate=True takes the vision tower + 3-D positions and (with these weights) generates other codes."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_engine import build, small_cfg
+    from unimoe_audio_amd.codec_utils import DecoderOutput, prepare_audio_prompt
+    vc = dict(depth=2, hidden_size=160, intermediate_size=348, num_heads=2, in_chans=3, patch_size=14, spatial_merge_size=2, temporal_patch_size=2,
+              window_size=112, fullatt_block_indexes=[1], out_hidden_size=256, tokens_per_second=2)
+    cfg = small_cfg(vision_config=vc, image_token_id=301, video_token_id=302, vision_start_token_id=303, vision_end_token_id=304)
+    m, _ = build(cfg, 53, 0.06)
+    gm = m.to(dev)
+    B, T, max_tokens = 2, 40, 12
+    torch.manual_seed(54)
+    ids = torch.randint(0, 290, (2 * B, T))
+    am = torch.ones(2 * B, T, dtype=torch.long)
+    am[0, :4] = 0
+    grid = torch.tensor([[2, 4, 6]] * (2 * B))
+    for r in range(2 * B):
+        ids[r, 10] = 303
+        ids[r, 11:23] = 302
+        ids[r, 23] = 304
+    px = torch.randn(2 * B * 48, 1176).to(torch.bfloat16)
+    sec = torch.tensor([2.0] * (2 * B))
+    pre, psteps = prepare_audio_prompt(cfg, [None] * B)
+    kw = dict(cfg_scale=2.0, do_sample=True, temperature=1.0, top_p=0.9, eos_prob_mul_factor=0.8, seed=5)
+    outs = []
+    for pix, vig in ((False, False), (True, False), (True, True)):
+        dec = DecoderOutput(pre.clone(), psteps, dev)
+        extra = dict(pixel_values_videos=px.to(dev), video_grid_thw=grid, second_per_grid_ts=sec) if pix else {}
+        codes, lengths = gm.generate(ids, am, dec, max_tokens, 4, vision_in_generate=vig, **extra, **kw)
+        outs.append((codes.cpu(), lengths.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][0], outs[2][0])

@@ -162,15 +162,18 @@ class UniMoEAudio:
     def video_text_to_music(self, video, caption: Union[str, List[str]], output_dir: str = "./", max_audio_seconds: int = 20,
                             min_audio_seconds: int = 8, temperature: float = 1.0, top_p: float = 1.0, cfg_filter_top_k: int = 45,
                             save_name: str = "video_music", cfg_scale: float = 10.0, eos_prob_mul_factor: float = 0.6, do_sample: bool = True,
-                            fps: float = 1.0, sampling_fps: float = 1.0, max_frames: int = 8, **_) -> List[str]:
+                            fps: float = 1.0, sampling_fps: float = 1.0, max_frames: int = 8, vision_in_generate: bool = False, **_) -> List[str]:
         """reference UniMoE_Audio.py:203-257 / utils/UniMoE_Audio_mod.py:483-619: a video (here: its frames, a uint8 / float tensor
         [F, H, W, 3] or [F, 3, H, W]; file decoding needs moviepy / qwen_vl_utils, absent offline) + a caption -> music.  The frames are
         resized to multiples of 28 px within the reference's pixel budget (mod.py:49-53: at most 64 * 28 * 28 per frame), cut into the
-        processor's patch layout and sent through the vision tower; their tokens sit between <|vision_start|> and <|vision_end|>."""
+        processor's patch layout; their tokens sit between <|vision_start|> and <|vision_end|>.
+        vision_in_generate: False (default) = the reference's inference path, whose generate() never feeds the pixels to the model (the
+        pad tokens keep their text embeddings, positions stay 1-D; see model.generate); True = vision tower + 3-D positions.
+        A file path is decoded when a decoder is importable here (torchvision.io / decord / moviepy, in that order)."""
         from .vision import frames_to_patches
         caption = self._texts(caption)
         if isinstance(video, (str, bytes, os.PathLike)):
-            raise ValueError("video: pass the frames as a [F, H, W, 3] or [F, 3, H, W] tensor (file decoding is not available offline)")
+            video = _decode_video_file(os.fspath(video), sampling_fps, max_frames)
         frames = video if torch.is_tensor(video) else torch.as_tensor(video)
         if frames.dim() != 4:
             raise ValueError("video: pass the frames as a [F, H, W, 3] or [F, 3, H, W] tensor (file decoding is not available offline)")
@@ -190,9 +193,42 @@ class UniMoEAudio:
                                              min_tokens=min_audio_seconds * 50, pixel_values_videos=patches.repeat(R, 1),
                                              video_grid_thw=grid[None].repeat(R, 1), second_per_grid_ts=torch.full((R,), 2.0 / max(sampling_fps, 1e-6)),
                                              cfg_scale=cfg_scale, temperature=temperature, top_p=top_p, cfg_filter_top_k=cfg_filter_top_k,
-                                             eos_prob_mul_factor=eos_prob_mul_factor, do_sample=do_sample)
+                                             eos_prob_mul_factor=eos_prob_mul_factor, do_sample=do_sample, vision_in_generate=vision_in_generate)
         audios = [] if codes is None else generate_output(cfg, codes, lengths)
         return self._finish(audios, output_dir, save_name)
+
+
+def _decode_video_file(path: str, sampling_fps: float, max_frames: int) -> torch.Tensor:
+    """Frames [F, H, W, 3] uint8 of a video file, sampled at `sampling_fps` (reference utils/UniMoE_Audio_mod.py:158-213 uses moviepy +
+    qwen_vl_utils).  Tries the decoders that may be importable here; raises a ValueError that says what to pass instead when none is."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    errors = []
+    try:
+        from torchvision.io import read_video          # type: ignore
+        frames, _, info = read_video(path, pts_unit="sec", output_format="THWC")
+        step = max(int(round(float(info.get("video_fps", 1.0)) / max(sampling_fps, 1e-6))), 1)
+        return frames[::step][:max_frames]
+    except Exception as e:      # not installed, or no backend for the container
+        errors.append(f"torchvision.io: {e!r}")
+    try:
+        import decord                                   # type: ignore
+        vr = decord.VideoReader(path)
+        step = max(int(round(vr.get_avg_fps() / max(sampling_fps, 1e-6))), 1)
+        idx = list(range(0, len(vr), step))[:max_frames]
+        return torch.from_numpy(vr.get_batch(idx).asnumpy())
+    except Exception as e:
+        errors.append(f"decord: {e!r}")
+    try:
+        from moviepy.editor import VideoFileClip       # type: ignore
+        import numpy as np
+        clip = VideoFileClip(path)
+        ts = [i / max(sampling_fps, 1e-6) for i in range(max_frames) if i / max(sampling_fps, 1e-6) < clip.duration]
+        return torch.from_numpy(np.stack([clip.get_frame(t) for t in ts]))
+    except Exception as e:
+        errors.append(f"moviepy: {e!r}")
+    raise ValueError("video: no video decoder is importable here (" + "; ".join(errors) + "): pass the frames as a [F, H, W, 3] or "
+                     "[F, 3, H, W] tensor instead")
 
 
 def create_unimoe_audio(model_path: str, device_id: int = 0) -> UniMoEAudio:

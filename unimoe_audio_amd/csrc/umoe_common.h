@@ -200,8 +200,8 @@ struct umoe_ep_xfer {          // one push (local rows -> every peer's slab) or 
     const uint32_t* step;      // device word: decode steps taken so far
     int layer, layers;         // epoch = *step * layers + layer + 1
     uint32_t* err;             // device word, sticky: 1 = a receive timed out
-    // return slab filled by umoe_moe_ep.hip: n_cwg > 0 = wait for COUNTERS (word (kind 1, source rank, part 0) >= round * n_cwg,
-    // round = *round * layers + layer + 1) instead of the row flags
+    // return slab filled by umoe_moe_ep.hip: n_cwg > 0 = wait for COUNTERS (cumulative: word (kind 1, source rank, part 0) >=
+    // ((*round - 1) * layers + layer + 1) * n_cwg, *round = decode steps taken incl. this one) instead of the row flags
     const uint32_t* round;
     int n_cwg;
 };

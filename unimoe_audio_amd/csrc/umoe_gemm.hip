@@ -767,7 +767,7 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
     UMOE_REQUIRE(gu && dn && flags, "umoe_moe_fused: null argument");
     const int G = gu->num_groups;
     if (!(gu->fused_router && gu->rider_pub && gu->groups_host && dn->groups_host && G == dn->num_groups && G <= UMOE_GROUPS_INLINE && gu->nt == 14 &&
-          dn->nt == 6 && (gu->prologue == UMOE_PRO_PLAIN || (gu->prologue == UMOE_PRO_RMSNORM && gu->max_k == 2048 && gu->norm_w)) &&
+          dn->nt == 6 && gu->prologue == UMOE_PRO_PLAIN &&
           gu->epilogue == UMOE_EPI_SWIGLU && dn->prologue == UMOE_PRO_PLAIN &&
           dn->epilogue == UMOE_EPI_BF16 && gu->ksplit <= 1 && dn->ksplit <= 1 && gu->max_rows <= 16 && dn->max_rows <= 16 &&
           dn->a == gu->out && dn->lda == gu->ldo && !dn->fused_router && gu->max_k % 32 == 0 && dn->max_k % 32 == 0))
@@ -788,8 +788,9 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
     if (!(r->S <= 16 && r->n_dyn == 9 && r->n_fix == 2 && (r->D == 2048 || r->D == 4096) && r->x && r->gate_w && r->expert_mask && !r->logits_in &&
           !r->norm_only && r->norm_w))
         return 1;
-    const bool rs_mode = gu->prologue == UMOE_PRO_RMSNORM;      // the riders hand over the rows' scales, not the rows
-    if (rs_mode ? !(r->x == gu->a && r->norm_w == gu->norm_w && !r->h_out) : !(r->h_out == gu->a)) return 1;
+    // (measured and removed: the riders handing over only the rows' RMSNorm scales while the GEMM workgroups normalise the raw rows
+    //  themselves -- 3.105-3.11 vs 3.075-3.087 ms/step; and no hand-off at all, every workgroup normalising in its prologue: 3.42 vs 3.36)
+    if (!(r->h_out == gu->a)) return 1;
     umoe_fuse_x fx;
     memset(&fx, 0, sizeof(fx));
     fx.flags = flags;
@@ -804,11 +805,10 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
     }
     const size_t l1 = gemm_lds_bytes(gu->max_k, 14, 8, 1, gu->prologue), l2 = gemm_lds_bytes(dn->max_k, 6, 8, 1), lds = l1 > l2 ? l1 : l2;
     if (lds > 160 * 1024) return 1;
-    static size_t configured[2] = {0, 0};
-    if (lds > configured[rs_mode]) {
-        if (rs_mode) UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_fused_kernel<UMOE_PRO_RMSNORM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_fused_kernel<UMOE_PRO_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured[rs_mode] = lds;
+    static size_t configured = 0;
+    if (lds > configured) {
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_fused_kernel<UMOE_PRO_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
     }
     umoe_group_pack gg, gd;
     memset(&gg, 0, sizeof(gg));
@@ -816,9 +816,8 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
     memcpy(gg.g, gu->groups_host, sizeof(umoe_group_t) * G);
     memcpy(gd.g, dn->groups_host, sizeof(umoe_group_t) * G);
     const umoe_rider_pub pub = *reinterpret_cast<const umoe_rider_pub*>(gu->rider_pub);
-    UMOE_REQUIRE(pub.flags && pub.step && pub.err && (!rs_mode || pub.rs), "umoe_moe_fused: rider_pub needs flags / step / err (and rs)");
-    if (rs_mode) moe_fused_kernel<UMOE_PRO_RMSNORM><<<dim3((unsigned)gx, 1, (unsigned)G), 512, lds, s>>>(*gu, gg, *dn, gd, *r, /*rider_mode*/ 2, pub, fx, per);
-    else moe_fused_kernel<UMOE_PRO_PLAIN><<<dim3((unsigned)gx, 1, (unsigned)G), 512, lds, s>>>(*gu, gg, *dn, gd, *r, /*rider_mode*/ 2, pub, fx, per);
+    UMOE_REQUIRE(pub.flags && pub.step && pub.err, "umoe_moe_fused: rider_pub needs flags / step / err");
+    moe_fused_kernel<UMOE_PRO_PLAIN><<<dim3((unsigned)gx, 1, (unsigned)G), 512, lds, s>>>(*gu, gg, *dn, gd, *r, /*rider_mode*/ 2, pub, fx, per);
     UMOE_LAUNCH_CHECK();
     return 0;
 }
@@ -885,20 +884,6 @@ extern "C" int umoe_grouped_gemm(const umoe_gemm_args* a, umoe_stream_t stream) 
         if (epi == UMOE_EPI_F32) return launch_gemm_nt<UMOE_PRO_RMSNORM, UMOE_EPI_F32>(a, nt, s);
         if (epi == UMOE_EPI_SWIGLU) {  // shared experts straight from the residual stream (norm fused in the staging)
             UMOE_REQUIRE(a->max_n_blocks % 2 == 0, "umoe_grouped_gemm: SwiGLU needs gate/up block pairs");
-            if (a->nt == 14) {
-                // dense decode, the post-attention norm in THIS launch's staging prologue (no rider hand-off, no norm launch): every
-                // workgroup normalises the 16 rows it stages, with the router body's summation tree (bit-identical rows)
-                UMOE_REQUIRE(a->max_k == 2048 && a->max_rows <= 16 && a->groups_host && a->num_groups <= UMOE_GROUPS_INLINE,
-                             "umoe_grouped_gemm: the 14-block RMSNorm SwiGLU launch needs K 2048, <= 16 rows, host descriptors");
-                if (a->fused_router) {
-                    const umoe_router_args* r = a->fused_router;
-                    UMOE_REQUIRE(r->S <= ceil_div(a->max_n_blocks, 14) && r->n_dyn == 9 && r->n_fix == 2 && r->D == 2048 && r->x && r->gate_w &&
-                                     r->expert_mask && !r->logits_in && !r->norm_only,
-                                 "umoe_grouped_gemm: fused_router needs <= 16 rows, n_dyn 9 / n_fix 2, D 2048");
-                    return launch_gemm<14, 1, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU, 8, true>(a, s);
-                }
-                return launch_gemm<14, 1, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU, 8>(a, s);
-            }
             const int ns = auto_nt(a, true);
             if (ns <= 2) return launch_gemm<2, 8, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU>(a, s);
             if (ns == 4) return launch_gemm<4, 4, UMOE_PRO_RMSNORM, UMOE_EPI_SWIGLU>(a, s);

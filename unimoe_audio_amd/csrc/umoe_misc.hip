@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const umoe_combine_args a,
         if (threadIdx.x < (unsigned)a.n_real) {
             const int src = (int)threadIdx.x / (a.n_real / x.size);
             if (x.n_cwg > 0) {      // slab filled by the one-launch exchange (umoe_moe_ep.hip): every source counts its workgroups in
-                const uint32_t target = (*x.round * (uint32_t)x.layers + (uint32_t)x.layer + 1u) * (uint32_t)x.n_cwg;
+                const uint32_t target = ((*x.round - 1u) * (uint32_t)x.layers + (uint32_t)x.layer + 1u) * (uint32_t)x.n_cwg;      // cumulative
                 umoe_ep_wait(umoe_ep_flag(x.peer_base[x.rank], 1, src, 0), target, x.err);
             } else if (src != x.rank) {
                 umoe_ep_wait(umoe_ep_flag(x.peer_base[x.rank], 1, src, s), umoe_ep_epoch(x), x.err);

@@ -21,7 +21,8 @@
 // inside the GPU, system scope to a peer), every storing wave drains, one word per part: an epoch FLAG where one producer writes
 // (dispatch rows: one per source rank; operand-order tiles; a workgroup's phase A / B slices) and a COUNTER where many do (the
 // return slab: every phase C workgroup adds 1 on every destination; the reader waits for rounds x workgroups).  Every poll is bounded
-// and keeps the first error cause in the sticky word.  Bit-identical to ep_size 1: every (expert, row tile, 16-feature block) product
+// and keeps the first error cause in the sticky word (1 a peer's rows / counters, 3 the shared experts' rows, 4 the operand-order tiles, 5 a
+// local expert's h tiles did not arrive).  Bit-identical to ep_size 1: every (expert, row tile, 16-feature block) product
 // keeps the K split over 8 waves and the fixed-order reduction of moe_flat_kernel / moe_fused_kernel.
 #include <stdlib.h>
 #include <string.h>
@@ -55,11 +56,6 @@ struct epf_args {
 };
 
 static_assert(sizeof(epf_args) + sizeof(umoe_router_args) + sizeof(umoe_rider_pub) + 16 <= 4096, "moe_ep_kernel: kernel arguments exceed 4 KiB");
-
-__device__ __forceinline__ uint32_t epf_round(const epf_args& P, const umoe_rider_pub& pub) {
-    asm volatile("" ::: "memory");
-    return __builtin_nontemporal_load(P.round) * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
-}
 
 // ---- tile rider: push the own raw rows to rank j (REAL exchange: j != rank; loopback: into the own slab, tile j), then make tile j ----
 __device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rider_pub& pub, const int j, char* smem, const int tid) {
@@ -149,7 +145,8 @@ __device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rid
 // inside this launch); K split over the 8 waves in whole U-step chunks, fixed-order LDS reduction ----
 template <int NT, int MT, int U, int RW, int RB, bool SWIGLU>
 __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const int nb0, const int KB, const uint16_t* wbase, const uint16_t* fbase,
-                                       const int ftile0, const int fbytes, char* smem, const int tid) {
+                                       const int ftile0, const int fbytes, char* smem, const int tid, const umoe_rider_pub& pub, uint32_t* wflag,
+                                       const int nwait, const uint32_t wcode) {
     constexpr int WV = 8;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -183,10 +180,17 @@ __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const i
         for (int m = 0; m < MT; ++m) d[m] = __builtin_amdgcn_raw_buffer_load_b128(frs, (((ftile0 + m) * KB + ii) * 64 + lane) * 16, 0, 16);
     };
     const int il = i1 - 1;
-#pragma unroll
-    for (int r = 0; r < RB; ++r) load_b(br[r], min(i0 + r, il));
+    // the weights first: they depend on nobody.  Then (first pass of a phase only: nwait > 0) the hand-off this pass's fragments hang on --
+    // the operand-order row tiles (phase B) or the h tiles of this expert's producers (phase C) -- lane i of wave 0 polls part i, bounded
 #pragma unroll
     for (int r = 0; r < RW; ++r) load_w(wr[r], min(i0 + r, il));
+    __builtin_amdgcn_sched_barrier(0);
+    if (nwait > 0) {
+        if (tid < nwait) flat_wait(wflag + tid, flat_epoch(pub), pub.err, wcode);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) load_b(br[r], min(i0 + r, il));
     __builtin_amdgcn_sched_barrier(0);
     for (int base = i0; base < i1; base += RW) {
 #pragma unroll
@@ -280,6 +284,15 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
     const unsigned b = blockIdx.x;
     const uint32_t* tl = P.tasks + (size_t)b * UMOE_EPF_MAXT;
     flat_stamps st;
+#ifdef UMOE_TIMELINE
+    // diagnostics (instrumented build only, scripts/ep_timeline.py): stamp 0 = entry, stamp k + 1 = end of task k, 15 = exit
+    unsigned long long tstamp[16];
+    if (P.S.dbg) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tstamp[k] = 0;
+        tstamp[0] = wall_clock64();
+    }
+#endif
     bool tiles_seen = false;
     unsigned seam_seen = 0u;
     for (int ti = 0; ti < UMOE_EPF_MAXT; ++ti) {
@@ -297,6 +310,9 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
         } else if (kind == EPF_ROUTER) {
             float* rl = reinterpret_cast<float*>(smem + lds_gemm);
             if (tid < 256) {
+#ifdef UMOE_TIMELINE
+                TL_ENTER(5);
+#endif
                 if (ra.logits_bf16) router4_body<9, 2, 1, false>(ra, first, tid, rl TL_PASS, nullptr, 0u, nullptr);
                 else router4_body<9, 2, 0, false>(ra, first, tid, rl TL_PASS, nullptr, 0u, nullptr);
             } else {
@@ -316,42 +332,40 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
         } else if (kind == EPF_PUB_A || kind == EPF_PUB_B) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0)
-                __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>((kind == EPF_PUB_A ? P.S.flags : P.flag_b) + b)), flat_epoch(pub),
+            if (tid == 0)      // (`first` = this workgroup's position among the producers of its role)
+                __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>((kind == EPF_PUB_A ? P.S.flags : P.flag_b) + first)), flat_epoch(pub),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (kind == EPF_B) {
-            if (!tiles_seen) {      // the operand-order tiles of every rank (lanes 0 .. MT-1 poll one tile flag each; replicated lines)
-                if (tid < MT) flat_wait(P.tile_ready + (b % UMOE_FLAG_REPL) * 16 + tid, flat_epoch(pub), pub.err, 2u);
-                __syncthreads();
-                tiles_seen = true;
-            }
+            // the operand-order tiles of every rank: waited for INSIDE the first pass, behind its weight requests (replicated flag lines)
+            uint32_t* wf = P.tile_ready + (b % UMOE_FLAG_REPL) * 16;
+            const int nw = tiles_seen ? 0 : MT;
+            tiles_seen = true;
             const uint16_t* w = P.w_lgu[grp];
             constexpr int NTB = 16 / MT;          // blocks per pass: 8 / 4 / 2 at 2 / 4 / 8 tiles
             const int fb = MT * 16 * P.D * 2;
-            if (2 * n == NTB) epf_mt<NTB, MT, 1, (NTB >= 8 ? 4 : 8), 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid);
+            if (2 * n == NTB) epf_mt<NTB, MT, 1, (NTB >= 8 ? 4 : 8), 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u);
             else if constexpr (NTB >= 4) {
-                if (2 * n == NTB / 2) epf_mt<NTB / 2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid);
+                if (2 * n == NTB / 2) epf_mt<NTB / 2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u);
                 else if constexpr (NTB >= 8) {
-                    if (n == 3) epf_mt<6, MT, 1, 4, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid);
-                    else epf_mt<2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid);
+                    if (n == 3) epf_mt<6, MT, 1, 4, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u);
+                    else epf_mt<2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u);
                 }
             }
         } else if (kind == EPF_C) {
-            if (!((seam_seen >> grp) & 1u)) {      // the workgroups that produced this expert's h tiles
-                if (tid < P.prodb_n[grp]) flat_wait(P.flag_b + P.prodb_base[grp] + tid, flat_epoch(pub), pub.err, 3u);
-                __syncthreads();
-                seam_seen |= 1u << grp;
-            }
+            // the workgroups that produced this expert's h tiles: waited for inside the first pass on this expert, behind its weight requests
+            uint32_t* wf = P.flag_b + P.prodb_base[grp];
+            const int nw = ((seam_seen >> grp) & 1u) ? 0 : P.prodb_n[grp];
+            seam_seen |= 1u << grp;
             const uint16_t* w = P.w_ldn[grp];
             const int KB = P.I >> 5, fb = P.E_loc * MT * 16 * P.I * 2;
             constexpr int NTC = MT >= 8 ? 2 : (MT >= 4 ? 4 : 8);
             // register rings: RW k-steps of NT weight blocks (<= 128 VGPRs), RB k-steps of MT fragments (<= 64)
             constexpr int RBC = MT >= 8 ? 2 : 4;
-            if (n == NTC) epf_mt<NTC, MT, 2, (NTC >= 4 ? 4 : 8), RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid);
-            else if (n == NTC / 2) epf_mt<NTC / 2, MT, 2, (NTC / 2 >= 4 ? 4 : 8), RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid);
+            if (n == NTC) epf_mt<NTC, MT, 2, (NTC >= 4 ? 4 : 8), RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid, pub, wf, nw, 5u);
+            else if (n == NTC / 2) epf_mt<NTC / 2, MT, 2, (NTC / 2 >= 4 ? 4 : 8), RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid, pub, wf, nw, 5u);
             else if constexpr (NTC >= 4) {
-                if (n == NTC / 4) epf_mt<NTC / 4, MT, 2, 8, RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid);
-                else if constexpr (NTC >= 8) epf_mt<1, MT, 2, 8, RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid);
+                if (n == NTC / 4) epf_mt<NTC / 4, MT, 2, 8, RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid, pub, wf, nw, 5u);
+                else if constexpr (NTC >= 8) epf_mt<1, MT, 2, 8, RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid, pub, wf, nw, 5u);
             }
         } else if (kind == EPF_SIG_C) {
             // every storing wave drains its system-scope stores, the workgroup meets, lane t counts this workgroup in on the owner of tile t
@@ -375,32 +389,51 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
                 default: flat_down<10, 1>(P.S, pub, grp, first, smem, st, 7, tid); break;
             }
         }
+#ifdef UMOE_TIMELINE
+        if (P.S.dbg) {
+#pragma unroll
+            for (int k = 1; k < 15; ++k)
+                if (k == ti + 1) tstamp[k] = wall_clock64();
+        }
+#endif
     }
+#ifdef UMOE_TIMELINE
+    if (P.S.dbg && threadIdx.x == 0) {
+        tstamp[15] = wall_clock64();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) P.S.dbg[(size_t)b * 16 + k] = tstamp[k];
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ host: the task lists
-// Every phase is dealt out on its own, in equal shares over the workgroups that take part in it (the remainders start at a different
-// workgroup per phase): all workgroups then finish a phase at about the same time, so the seams (B -> C per expert, A -> D) are short
-// and every CU streams the same number of bytes.  The riders (R tile riders, then S router riders) take no phase A slice: phase A is
-// what hides the dispatch flight, which they are busy producing.  Order per workgroup: rider task | A | B | C + count-in | D.
+// At the decode shape a phase of one workgroup is a LATENCY chain (stage / wait, first round trip, 8-11 k-steps, reduction, epilogue:
+// 8-12 us whatever the slice), so a workgroup that walked all four phases took ~57 us for 67 MB at ep 8.  Hence two ROLES: SHARED
+// workgroups take phases A and D (the shared experts, own rows, no exchange), LOCAL workgroups take B and C (the local experts over
+// every rank's rows) -- two chains per workgroup, and the shared experts' bytes stream beside the exchange instead of in front of it.
+// The split follows a small intake model (HBM ~26 GB/s and L2-resident fragments ~100 GB/s per CU); UMOE_EPF_NS overrides it.
+// Workgroup order: [0, R) tile riders (local role, dispatched first: everything hangs on them), [R, R + n_s) shared role, its first S
+// also route one own row each, then the local role.  With few workgroups (ranks sharing a card in the tests) every workgroup takes a
+// share of every phase instead: rider | A | B | C | D.
 struct EpfPlan {
     bool ok = false;
-    int n_wg = 0, n_cwg = 0;
+    int n_wg = 0, n_cwg = 0, n_s = 0;
     int proda_base[4], proda_n[4], prodb_base[UMOE_MT_MAXG], prodb_n[UMOE_MT_MAXG];
     std::vector<uint32_t> tasks;
 };
 
 static inline uint32_t epf_task(unsigned kind, int grp, int first, int n) { return (kind << 28) | ((uint32_t)grp << 24) | ((uint32_t)first << 8) | (uint32_t)n; }
 
-// deals `units` of one group list over workgroups [w0, w0 + nw) starting the remainder at `rot`: out[w] = (first, count)
-static void epf_deal(int units, int w0, int nw, int rot, std::vector<int>& first, std::vector<int>& count) {
+// deals `units` over the workgroups wgs[0 .. nw) in equal shares, the remainder starting at position `rot`
+static void epf_deal(int units, const std::vector<int>& wgs, int rot, std::vector<int>& first, std::vector<int>& count) {
+    const int nw = (int)wgs.size();
     const int base = units / nw, extra = units % nw;
     std::vector<int> cnt(nw, base);
     for (int k = 0; k < extra; ++k) cnt[(rot + k) % nw] += 1;
     int acc = 0;
     for (int k = 0; k < nw; ++k) {
-        first[w0 + k] = acc;
-        count[w0 + k] = cnt[k];
+        first[wgs[k]] = acc;
+        count[wgs[k]] = cnt[k];
         acc += cnt[k];
     }
 }
@@ -412,20 +445,40 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
     if (n_wg < riders + 1 || n_wg > 256 || E_loc < 1 || E_loc > UMOE_MT_MAXG || n_fix < 1 || n_fix > 4 || !(R == 2 || R == 4 || R == 8) || D != 2048 ||
         I_dyn % 32 || I_sh % 32 || (I_sh / 32) % 2 == 0)       // (the shared experts' down slices run on flat_down<., 1>: odd k-steps)
         return;
+    // ---- roles
+    std::vector<int> ws, wl;           // shared role / local role, in the order their units are dealt
+    int n_s = 0;
+    if (n_wg >= 128) {
+        const double hbm = 0.0385, l2 = 0.01;      // us per KiB of intake of one CU
+        const double shared = (n_fix * (I_sh / 16) * 4.0 * (D / 32) + n_fix * (D / 16) * (double)(I_sh / 32)) * hbm;
+        const double local = E_loc * ((I_dyn / 16) * (4.0 * (D / 32) * hbm + R * 2.0 * (D / 32) * l2) + (D / 16) * ((I_dyn / 32) * hbm + R * (double)(I_dyn / 32) * l2));
+        n_s = (int)(n_wg * shared / (shared + local) + 0.5);
+        if (const char* v = getenv("UMOE_EPF_NS")) n_s = atoi(v);
+        n_s = std::max(n_s, S);
+        n_s = std::min(n_s, n_wg - R - 1);
+        for (int w = R; w < R + n_s; ++w) ws.push_back(w);
+        for (int w = R + n_s; w < n_wg; ++w) wl.push_back(w);
+        for (int w = 0; w < R; ++w) wl.push_back(w);          // the tile riders last in the deal: the remainder units go to the others first
+    } else {
+        for (int w = 0; w < n_wg; ++w) { ws.push_back(w); wl.push_back(w); }
+    }
+    pl.n_s = n_s;
     std::vector<std::vector<uint32_t>> lists(n_wg);
     for (int j = 0; j < R; ++j) lists[j].push_back(epf_task(EPF_TILE, j, 0, 0));
     for (int t = 0; t < S; ++t) lists[R + t].push_back(epf_task(EPF_ROUTER, 0, t, 0));
-    std::vector<int> first(n_wg), count(n_wg);
-    // ---- A: the shared experts' pairs as ONE flat list over the non-rider workgroups (a slice may straddle two experts)
+    std::vector<int> first(n_wg, 0), count(n_wg, 0);
+    auto clear = [&]() { std::fill(first.begin(), first.end(), 0); std::fill(count.begin(), count.end(), 0); };
+    // position of a workgroup in its role's flag array (phase A flags: the shared role; phase B flags: the local role)
+    std::vector<int> pos_s(n_wg, -1), pos_l(n_wg, -1);
+    for (size_t k = 0; k < ws.size(); ++k) pos_s[ws[k]] = (int)k;
+    for (size_t k = 0; k < wl.size(); ++k) pos_l[wl[k]] = (int)k;
+    // ---- A: the shared experts' pairs as ONE flat list (a slice may straddle two experts)
     {
-        // (few workgroups -- ranks sharing one card in the tests: the riders take their share too, or the others' lists overflow)
         const int P = n_fix * (I_sh / 16);
-        const int a0 = (n_wg - riders >= n_wg / 2) ? riders : 0, nw = n_wg - a0;
-        std::fill(first.begin(), first.end(), 0);
-        std::fill(count.begin(), count.end(), 0);
-        epf_deal(P, a0, nw, 0, first, count);
+        clear();
+        epf_deal(P, ws, 0, first, count);
         for (int g = 0; g < n_fix; ++g) { pl.proda_base[g] = -1; pl.proda_n[g] = 0; }
-        for (int w = a0; w < n_wg; ++w) {
+        for (int w : ws) {
             int f = first[w], c = count[w];
             while (c > 0) {
                 const int k = std::min(c, 7);
@@ -433,12 +486,12 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
                 f += k; c -= k;
             }
             if (count[w] > 0) {
-                lists[w].push_back(epf_task(EPF_PUB_A, 0, 0, 0));
+                lists[w].push_back(epf_task(EPF_PUB_A, 0, pos_s[w], 0));
                 for (int g = 0; g < n_fix; ++g) {
                     const int lo = g * (I_sh / 16), hi = lo + I_sh / 16;
                     if (first[w] < hi && first[w] + count[w] > lo) {
-                        if (pl.proda_base[g] < 0) pl.proda_base[g] = w;
-                        pl.proda_n[g] = w - pl.proda_base[g] + 1;
+                        if (pl.proda_base[g] < 0) pl.proda_base[g] = pos_s[w];
+                        pl.proda_n[g] = pos_s[w] - pl.proda_base[g] + 1;
                     }
                 }
             }
@@ -446,25 +499,26 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
         for (int g = 0; g < n_fix; ++g)
             if (pl.proda_base[g] < 0 || pl.proda_n[g] > 512) return;
     }
-    // ---- B: local experts' pairs, expert-major, over ALL workgroups; task sizes from the kernel's pass shapes (NT * MT <= 16)
+    // ---- B: local experts' pairs, expert-major; task sizes from the kernel's pass shapes (NT * MT <= 16)
     {
         const int PP = I_dyn / 16, P = E_loc * PP;
-        epf_deal(P, 0, n_wg, riders % n_wg, first, count);
+        clear();
+        epf_deal(P, wl, 0, first, count);
         const int pmax = 8 / R;      // pairs per pass: 4 / 2 / 1
         for (int g = 0; g < E_loc; ++g) { pl.prodb_base[g] = -1; pl.prodb_n[g] = 0; }
-        for (int w = 0; w < n_wg; ++w) {
+        for (int w : wl) {
             int f = first[w], c = count[w];
             bool any = false;
             while (c > 0) {
                 const int g = f / PP, lp = f % PP;
                 const int k = std::min(std::min(c, pmax), PP - lp);      // 1..4 pairs at 2 tiles, 1..2 at 4, 1 at 8: every size has a pass shape
                 lists[w].push_back(epf_task(EPF_B, g, lp, k));
-                if (pl.prodb_base[g] < 0) pl.prodb_base[g] = w;
-                pl.prodb_n[g] = w - pl.prodb_base[g] + 1;
+                if (pl.prodb_base[g] < 0) pl.prodb_base[g] = pos_l[w];
+                pl.prodb_n[g] = pos_l[w] - pl.prodb_base[g] + 1;
                 f += k; c -= k;
                 any = true;
             }
-            if (any) lists[w].push_back(epf_task(EPF_PUB_B, 0, 0, 0));
+            if (any) lists[w].push_back(epf_task(EPF_PUB_B, 0, pos_l[w], 0));
         }
         for (int g = 0; g < E_loc; ++g)
             if (pl.prodb_base[g] < 0 || pl.prodb_n[g] > 512) return;
@@ -472,10 +526,11 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
     // ---- C: local experts' down blocks, expert-major; block counts per pass 8/4/2/1 (2 tiles), 4/2/1 (4), 2/1 (8)
     {
         const int NB = D / 16, P = E_loc * NB;
-        epf_deal(P, 0, n_wg, (2 * riders) % n_wg, first, count);
+        clear();
+        epf_deal(P, wl, (int)wl.size() / 3, first, count);
         const int bmax = R >= 8 ? 2 : (R >= 4 ? 4 : 8);
         pl.n_cwg = 0;
-        for (int w = 0; w < n_wg; ++w) {
+        for (int w : wl) {
             int f = first[w], c = count[w];
             bool any = false;
             while (c > 0) {
@@ -494,11 +549,12 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
             }
         }
     }
-    // ---- D: shared experts' down blocks (43 k-steps each: half a routed block), per expert, over all workgroups
+    // ---- D: shared experts' down blocks (43 k-steps each: half a routed block), per expert
     {
         const int NB = D / 16, P = n_fix * NB;
-        epf_deal(P, 0, n_wg, (3 * riders) % n_wg, first, count);
-        for (int w = 0; w < n_wg; ++w) {
+        clear();
+        epf_deal(P, ws, (int)ws.size() / 2, first, count);
+        for (int w : ws) {
             int f = first[w], c = count[w];
             while (c > 0) {
                 const int g = f / NB, lb = f % NB;
@@ -514,6 +570,17 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
         for (size_t k = 0; k < lists[w].size(); ++k) pl.tasks[(size_t)w * UMOE_EPF_MAXT + k] = lists[w][k];
     }
     pl.ok = true;
+}
+
+static unsigned long long* g_epf_dbg = nullptr;
+// diagnostics: NULL enables the stamps of the instrumented build (outside any capture); otherwise copies the last launch's [256][16] stamps
+extern "C" int umoe_moe_ep_stamps(unsigned long long* host_out) {
+    if (!host_out) {
+        if (!g_epf_dbg && hipMalloc(&g_epf_dbg, sizeof(unsigned long long) * 16 * 256) != hipSuccess) return -2;
+        return hipMemset(g_epf_dbg, 0, sizeof(unsigned long long) * 16 * 256) == hipSuccess ? 0 : -2;
+    }
+    if (!g_epf_dbg) return -1;
+    return hipMemcpy(host_out, g_epf_dbg, sizeof(unsigned long long) * 16 * 256, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
 }
 
 // test hook (no GPU needed): the task lists of a shape; out[0] = ok, out[1] = n_cwg, then n_wg * UMOE_EPF_MAXT task words
@@ -576,6 +643,7 @@ int umoe_moe_ep(const umoe_epf_desc* d, hipStream_t s) {
     flat_args& A = P.S;
     A.a = r->x; A.norm_w = r->norm_w; A.rms_eps = r->rms_eps; A.lda = d->D; A.S = d->S; A.G = d->n_fix; A.kb_gu = d->D / 32;
     A.h = d->h_sh; A.ldh = d->ldh; A.y = d->y_sh; A.ldy = d->ldy; A.flags = d->flags;
+    A.dbg = g_epf_dbg;
     int PP = 0;
     for (int i = 0; i < d->n_fix; ++i) {
         A.w_gu[i] = d->w_sgu[i]; A.w_dn[i] = d->w_sdn[i];

@@ -49,7 +49,8 @@ __device__ __forceinline__ void combine_row_dense(const umoe_combine_args& a, co
         // expert e's rows come from rank e / E_loc: wait until that rank has counted every one of its phase C workgroups in (bounded)
         if (tid < a.n_real) {
             const int src = tid / (a.n_real / r2.ep_size);
-            const uint32_t target = (__builtin_nontemporal_load(r2.ep_round) * (uint32_t)r2.ep_layers + (uint32_t)r2.ep_layer + 1u) * (uint32_t)r2.ep_n_cwg;
+            // (the counters are cumulative: ep_n_cwg per layer of every decode step taken so far; *ep_round counts the steps incl. this one)
+            const uint32_t target = ((__builtin_nontemporal_load(r2.ep_round) - 1u) * (uint32_t)r2.ep_layers + (uint32_t)r2.ep_layer + 1u) * (uint32_t)r2.ep_n_cwg;
             umoe_ep_wait(umoe_ep_flag(r2.ep_region, 1, src, 0), target, r2.ep_err);
         }
         __syncthreads();

@@ -693,14 +693,10 @@ static int launch_tgemm_pp_v(const umoe_tgemm_args* a, int max_n, hipStream_t s)
     // dispatcher balances those launches): one workgroup per CU
     int rows_on_device = 0;
     for (int i = 0; i < a->num_groups; ++i) rows_on_device |= a->groups[i].count != nullptr;
-    static int persist = -1;
-    if (persist < 0) {
-        const char* v = getenv("UMOE_TGEMM_PERSIST");
-        persist = v ? atoi(v) : 0;      // off: measured in the training step 254-259 vs 248-249 ms -- the hardware dispatcher's dynamic placement of
-                                        // one-tile workgroups beats a static walk (codec head 1225 tiles: 331 vs 329 us)
-    }
+    // (a persistent walk -- fewer workgroups than tiles -- was measured and is not offered: training step 254-259 vs 248-249 ms, the hardware
+    //  dispatcher's dynamic placement of one-tile workgroups beats a static walk; codec head, 1225 tiles: 331 vs 329 us)
+    (void)rows_on_device;
     dim3 grid((unsigned)nwg);
-    if (!rows_on_device && persist >= 8 && nwg > persist) grid = dim3((unsigned)(persist & ~7));
     // which bf16 epilogues go through LDS (bit 0 plain, 1 residual, 2 SwiGLU).  Measured at 6240 rows (scripts/kbench.py tiled):
     // residual 621 -> 833 TFLOP/s (the residual is read in whole rows too), SwiGLU +2 %, plain -5 % (stays direct)
     static int mask = -1;
@@ -753,17 +749,9 @@ static int tgemm_tm(const umoe_tgemm_args* a) {
 
 template <int EPI>
 static int launch_tgemm_pp(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
-    static int prio = -1, ring = -1;
-    if (prio < 0) {
-        const char* v = getenv("UMOE_TGEMM_PRIO");
-        prio = v ? atoi(v) : 1;
-        const char* r = getenv("UMOE_TGEMM_RING");
-        ring = r ? atoi(r) : 4;
-    }
-    if (prio == 0) return launch_tgemm_pp_v<EPI, 0, 4>(a, max_n, s);
-    if (prio == 2) return launch_tgemm_pp_v<EPI, 2, 4>(a, max_n, s);
-    if (ring == 4) return launch_tgemm_pp_v<EPI, 1, 4>(a, max_n, s);
-    return launch_tgemm_pp_v<EPI, 1, 5>(a, max_n, s);
+    // s_setprio around every MFMA segment, LDS ring of 4 tiles (128 KiB, the DMA three tiles ahead).  Measured and not offered: no
+    // priority or a static one for the younger group (both -20 %), a 5-slot ring (0-4 % slower on every shape and in the training step)
+    return launch_tgemm_pp_v<EPI, 1, 4>(a, max_n, s);
 }
 
 // 256 x 256 ping-pong tiles once they fill the chip (one workgroup per CU)

@@ -367,16 +367,25 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
                  image_grid_thw=None, video_grid_thw=None, second_per_grid_ts=None, cfg_scale: float = 3.0,
                  temperature: float = 1.2, top_p: float = 0.95, cfg_filter_top_k: int = 45,
                  eos_prob_mul_factor: float = 0.8, do_sample: bool = True, debug_guidance_step: int = 0, use_cache=True,
-                 seed: int = 0, use_graph: bool = True, poll_every: int = 16):
-        if not use_cache:
-            raise NotImplementedError("use_cache=False is not supported: the engine always keeps a KV cache")
+                 seed: int = 0, use_graph: bool = True, poll_every: int = 16, vision_in_generate: bool = False):
+        """reference generate(), utils/UniMoE_Audio_model.py:1070-1231 (same arguments, same return).
+        vision_in_generate (not in the reference).  The reference's generate() accepts pixel_values(_videos) but never uses them: it builds
+        inputs_embeds with calculate_input_embedding only (model.py:1116: the <|video_pad|> / <|image_pad|> tokens keep their TEXT
+        embeddings), passes explicit 1-D positions cumsum(attention_mask) - 1 at the prefill (:1113-1114) and at every decode step
+        (:940-944), and its text model drops the pixel arguments.  False (default) reproduces exactly that, so video_text_to_music
+        yields the tokens the reference's inference path yields; True runs what the reference's forward() does for training
+        (model.py:708-790): vision tower, embeddings scattered over the pad tokens, 3-D mRoPE positions from get_rope_index.
+        use_cache=False: the reference recomputes the whole prefix every step without a cache (model.py:964-980) and allows it only
+        without a codec prompt (:1092-1093); the result is the same tokens, so the engine serves it from its KV cache."""
+        if not use_cache and codec_input_ids is not None:
+            raise AssertionError("use_cache=False with a codec prompt: the reference asserts use_cache here (model.py:1092-1093)")
         dev = self.device
         input_ids, attention_mask = input_ids.to(dev), attention_mask.to(dev)
         B = input_ids.shape[0] // 2
         T = input_ids.shape[1]
         eng = self.engine(B, T, int(max_tokens))
         pos3 = deltas = None
-        if pixel_values is not None or pixel_values_videos is not None:
+        if vision_in_generate and (pixel_values is not None or pixel_values_videos is not None):
             x = self.multimodal_embedding(input_ids, None if codec_input_ids is None else codec_input_ids.to(dev), pixel_values, image_grid_thw,
                                           pixel_values_videos, video_grid_thw)
             pos3, deltas = self.get_rope_index(input_ids, image_grid_thw, video_grid_thw, second_per_grid_ts, attention_mask)   # model.py:753-777
@@ -574,7 +583,8 @@ class DecodeEngine:
 
     def handoff_error(self) -> int:
         """Sticky error word of the in-launch hand-offs (0 = none; 1 = an expert-parallel receive, 2 = the riders' rows, 3 = an expert's
-        SwiGLU rows were not published within the bounded wait -- e.g. a workgroup of a fused launch was not resident)."""
+        SwiGLU rows were not published within the bounded wait -- e.g. a workgroup of a fused launch was not resident; 4 / 5 = the
+        operand-order row tiles / a local expert's h tiles of the one-launch expert-parallel MoE half, umoe_moe_ep.hip)."""
         return int(self.copy_buffer("ep_words", torch.int32, (2,))[1].item())
 
     def all_done(self) -> bool:
