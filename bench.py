@@ -201,9 +201,16 @@ def roofline(cfg, info, args, ep=1):
         bytes_per_launch = (U * 2 * Id * D + n_fix * 2 * Is * D) * 2.0
         kname = "wstream_gemm<14, 1, 0, 2, 8, true>"
         what = " (grouped gate/up SwiGLU, 8 routed + 2 shared experts in one launch; 16 of its tile-less workgroups run the Top-P router)"
+    elif info.get("expert_launch") == 3:
+        # expert parallel, the MoE half of a layer as ONE launch (umoe_moe_ep.hip): gate + up + down weights of the n_real / ep local experts and
+        # of the shared experts, each streamed once; the exchange (riders, return stores) is inside the launch
+        bytes_per_launch = ((n_real / ep) * 3 * Id * D + n_fix * 3 * Is * D) * 2.0
+        kname = f"moe_ep_kernel<{ep}>"
+        what = (f" (expert parallel x{ep}: local + shared experts' gate/up SwiGLU and down projections in one launch of one workgroup per CU; "
+                "tile riders push / re-lay the rows, the down epilogue stores into the owners' return slabs)")
     else:
-        # expert parallel: two gate/up launches per layer (shared experts beside the exchange, then the local experts over the
-        # ep*16 gathered rows); algorithmic bytes = each weight once
+        # expert parallel, launch-per-kernel exchange: two gate/up launches per layer (shared experts beside the exchange, then the local
+        # experts over the ep*16 gathered rows); algorithmic bytes = each weight once
         bytes_per_launch = ((n_real / ep) * 2 * Id * D + n_fix * 2 * Is * D) * 2.0 / 2
         # (peer / loopback exchange: the local experts run in the multi-tile launch wstream_mt over all ranks' rows; the RCCL
         #  fallback keeps the single-tile grouped launch)
@@ -484,6 +491,9 @@ def main():
         out["ep_emulation"] = {"ep_size": args.ep_emulate, "ms_per_step": round(emu["dt"] / K * 1e3, 4),
                                "audio_tokens_per_s_per_gpu": round(B * K / emu["dt"], 2), "ep_error": emu["ep_error"],
                                "kernel_ms_per_step": {k: round(v[0] * v[1], 4) for k, v in emu["prof"].items()},
+                               "expert_launch": emu.get("expert_launch"),
+                               "roofline": {k: v for k, v in roofline(cfg, dict(emu, backend="loopback"), args, args.ep_emulate).items()
+                                            if k in ("kernel", "achieved", "frac", "bytes_per_launch", "avg_launch_us", "step_bytes", "step_achieved", "step_frac")},
                                "note": "ONE rank of an expert-parallel job in loopback on one GPU (its own rows stand in for the "
                                        "peers'): kernel time of the sharded step without xGMI latency; not the model's outputs"}
     if world == 1 and not args.no_config1:

@@ -682,7 +682,8 @@ int umoe_engine_ep_error(umoe_engine* e, umoe_stream_t stream, int* code_out);
  * is replaced); every other launch is the decode step's own. */
 int umoe_engine_set_probe(umoe_engine* e, const uint16_t* teach_x, uint16_t* dump_x1, uint16_t* dump_x, uint16_t* dump_logits);
 /* host-side facts about the engine: "expert_launch" = what the last dense decode layer enqueued for its experts (0 gate/up and down as
- * two launches, 1 the box-grid fused launch moe_fused_kernel, 2 the flat launch moe_flat_kernel), "n_cu" = compute units the
+ * two launches, 1 the box-grid fused launch moe_fused_kernel, 2 the flat launch moe_flat_kernel, 3 the one-launch expert-parallel MoE half
+ * moe_ep_kernel), "n_cu" = compute units the
  * co-residency guards assume; -1 for an unknown key */
 int umoe_engine_info(umoe_engine* e, const char* key);
 /* introspection for parity tests: device pointers into the workspace */

@@ -28,9 +28,10 @@ def test_ep_task_lists_cover_every_unit_once(n_wg, R):
     ok, n_cwg, t = plan(n_wg, R)
     assert ok
     E_loc, S = 8 // R, 16
-    cover = {A: np.zeros(2 * 86, int), B: np.zeros((E_loc, 172), int), CC: np.zeros((E_loc, 128), int), D: np.zeros((2, 128), int)}
+    halves = 2 if R == 8 else 1                                       # at 8 row tiles a down pass takes four of them
+    cover = {A: np.zeros(2 * 86, int), B: np.zeros((E_loc, 172), int), CC: np.zeros((E_loc, halves, 128), int), D: np.zeros((2, 128), int)}
     legal_b = {2: {1, 2, 3, 4}, 4: {1, 2}, 8: {1}}[R]
-    legal_c = {2: {1, 2, 4, 8}, 4: {1, 2, 4}, 8: {1, 2}}[R]
+    legal_c = {1, 2, 3, 4}
     counted = 0
     for w in range(n_wg):
         kinds = []
@@ -47,8 +48,8 @@ def test_ep_task_lists_cover_every_unit_once(n_wg, R):
                 assert n in legal_b and first + n <= 172
                 cover[B][grp, first:first + n] += 1
             elif kind == CC:
-                assert n in legal_c and first + n <= 128
-                cover[CC][grp, first:first + n] += 1
+                assert n in legal_c and first + n <= 128 and (grp & 3) < E_loc and (grp >> 2) < halves
+                cover[CC][grp & 3, grp >> 2, first:first + n] += 1
             elif kind == D:
                 assert 1 <= n <= 10 and first + n <= 128
                 cover[D][grp, first:first + n] += 1
@@ -56,11 +57,14 @@ def test_ep_task_lists_cover_every_unit_once(n_wg, R):
                 assert w == grp < R
             elif kind == ROUTER:
                 assert R <= w < R + S and first == w - R
-        # order: rider | A .. publish | B .. publish | C .. count-in | D
+        # order: rider | A .. publish | B .. publish | C .. count-in, with D behind C (every workgroup takes every phase: D hides the
+        # return flight) or in front of it (roles: D only needs A, C hangs on everybody's B)
         core = [k for k in kinds if k not in (TILE, ROUTER)]
         assert kinds[:len(kinds) - len(core)] == [k for k in kinds if k in (TILE, ROUTER)]
-        rank = {A: 0, PUB_A: 1, B: 2, PUB_B: 3, CC: 4, SIG_C: 5, D: 6}
+        rank = {A: 0, PUB_A: 1, B: 2, PUB_B: 3, CC: 4, SIG_C: 5, D: 6 if n_wg < 128 else 3.5}
         assert [rank[k] for k in core] == sorted(rank[k] for k in core)
+        if n_wg >= 128:
+            assert not (B in core and D in core)                     # two roles
         assert (A in core) == (PUB_A in core) and (B in core) == (PUB_B in core) and (CC in core) == (SIG_C in core)
         assert core.count(PUB_A) <= 1 and core.count(PUB_B) <= 1 and core.count(SIG_C) <= 1
         counted += SIG_C in core

@@ -32,7 +32,7 @@ def test_ep_virtual_ranks_bit_identical(ranks, graph, flat):
     (UMOE_EP_FLAT=0): logits of every step and all tokens bit-identical to N independent ep_size 1 engines."""
     assert torch.cuda.is_available()
     rc, out = _run([sys.executable, "scripts/ep_virtual.py", str(ranks), "2", "5", str(graph)],
-                   {"GPU_MAX_HW_QUEUES": "16" if ranks > 4 else "8", "UMOE_EP_FLAT": str(flat)})
+                   {"GPU_MAX_HW_QUEUES": "32", "UMOE_EP_FLAT": str(flat)})
     assert rc == 0 and "BIT-IDENTICAL" in out, out[-3000:]
 
 

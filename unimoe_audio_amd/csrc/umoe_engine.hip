@@ -88,7 +88,8 @@ struct umoe_engine {
     int dense_min_rows = 2;      // UMOE_DENSE_MIN_ROWS: fewest decode rows that take the dense-expert layout (below: ragged dispatch).  Batch 1
                                  // (2 CFG rows, BASELINE configs[0]) hits 5-6 of the 8 experts: streaming all 8 in the fused launches costs
                                  // fewer microseconds than the ragged path's four extra launches -- 2.91 vs 3.33 ms/step
-    int expert_launch = 0;       // what the last dense decode layer enqueued for its experts: 0 two launches, 1 box-grid fused, 2 flat (umoe_engine_info)
+    int expert_launch = 0;       // what the last dense decode layer enqueued for its experts: 0 launch per GEMM, 1 box-grid fused, 2 flat, 3 the
+                                 // one-launch expert-parallel MoE half (umoe_engine_info)
     int n_cu = 0;                // compute units of the device (UMOE_FAKE_CUS overrides: tests of the co-residency guards)
     bool flat_moe = true;        // UMOE_FLAT_MOE: both expert GEMMs as ONE workgroup per CU with a byte-balanced static schedule
                                  // (umoe_moe_flat.hip); 0 / shapes that do not fit: the box-grid launch below
@@ -627,6 +628,7 @@ static int run_moe_ep_flat(umoe_engine* e, int l, int n_tok, hipStream_t s) {
     d.flags = e->ep_words + 2048; d.flag_words = 4096 - 2048;
     d.round = e->ep_words + 2;
     if ((rc = umoe_moe_ep(&d, s))) return rc;
+    e->expert_launch = 3;
     PROF(K_GATEUP);
     uint16_t* slab_ret = reinterpret_cast<uint16_t*>(e->ep_region + d.ret_off);
     umoe_combine_args cb{};

@@ -146,7 +146,7 @@ __device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rid
 template <int NT, int MT, int U, int RW, int RB, bool SWIGLU>
 __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const int nb0, const int KB, const uint16_t* wbase, const uint16_t* fbase,
                                        const int ftile0, const int fbytes, char* smem, const int tid, const umoe_rider_pub& pub, uint32_t* wflag,
-                                       const int nwait, const uint32_t wcode) {
+                                       const int nwait, const uint32_t wcode, const int tile0) {      // tile0: first of this pass's MT row tiles
     constexpr int WV = 8;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,7 +230,7 @@ __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const i
     if constexpr (SWIGLU) {
         // silu(g) * u of tile (grp, m) in operand order of the [16][I] matrix the down projection contracts over (write-through)
         const int I = P.I, Q = I >> 2;
-        const auto hrs = __builtin_amdgcn_make_buffer_rsrc(P.hpk, 0, P.E_loc * MT * 16 * I * 2, 0x00020000);
+        const auto hrs = __builtin_amdgcn_make_buffer_rsrc(P.hpk, 0, P.E_loc * P.R * 16 * I * 2, 0x00020000);
         for (int q = wave; q < MT * (NT / 2); q += WV) {
             const int m = q / (NT / 2), pq = q % (NT / 2);
             const f32x4_t ga = reduced(m, 2 * pq), ua = reduced(m, 2 * pq + 1);
@@ -244,7 +244,7 @@ __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const i
             }
             const int f = (nb0 / 2 + pq) * 16 + 4 * h;
             const int qq = f / Q, r = f % Q;
-            const long eo = (long)(grp * MT + m) * 16 * I + ((long)(r >> 3) * 64 + qq * 16 + mm) * 8 + (r & 7);
+            const long eo = (long)(grp * P.R + tile0 + m) * 16 * I + ((long)(r >> 3) * 64 + qq * 16 + mm) * 8 + (r & 7);
             const epf_u32x2 v2 = {(uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16)};
             __builtin_amdgcn_raw_buffer_store_b64(v2, hrs, (int)(eo * 2), 0, 16);
         }
@@ -257,7 +257,8 @@ __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const i
             uint16_t y[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = f2bf(rbf(a4[j] + 0.f));
-            const int dr = P.loopback ? P.rank : m, sr = P.loopback ? m : P.rank;
+            const int gt = tile0 + m;      // the rows of tile gt belong to rank gt
+            const int dr = P.loopback ? P.rank : gt, sr = P.loopback ? gt : P.rank;
             char* dst = P.peer_base[dr] + P.ret_off + ((size_t)(sr * P.E_loc + grp) * P.S.S) * (size_t)P.D * 2;      // slab [n_real][S][D]
             const auto yrs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, P.S.S * P.D * 2, 0x00020000);
             const epf_u32x2 v2 = {(uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16)};
@@ -272,7 +273,7 @@ __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const i
 #define EPF_PUB_A 2u
 #define EPF_B 3u          // local gate/up: group = local expert, first = pair, units = pairs (NT / 2)
 #define EPF_PUB_B 4u
-#define EPF_C 5u          // local down: first = block, units = blocks
+#define EPF_C 5u          // local down: group = local expert | tile half << 2 (8 tiles: a pass takes 4), first = block, units = blocks (1..4)
 #define EPF_SIG_C 6u
 #define EPF_D 7u          // shared down: group = shared expert, first = block, units = blocks (1..10)
 #define EPF_TILE 8u       // rider: group = tile / peer j
@@ -343,29 +344,31 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
             const uint16_t* w = P.w_lgu[grp];
             constexpr int NTB = 16 / MT;          // blocks per pass: 8 / 4 / 2 at 2 / 4 / 8 tiles
             const int fb = MT * 16 * P.D * 2;
-            if (2 * n == NTB) epf_mt<NTB, MT, 1, (NTB >= 8 ? 4 : 8), 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u);
+            if (2 * n == NTB) epf_mt<NTB, MT, 1, (NTB >= 8 ? 4 : 8), 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u, 0);
             else if constexpr (NTB >= 4) {
-                if (2 * n == NTB / 2) epf_mt<NTB / 2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u);
+                if (2 * n == NTB / 2) epf_mt<NTB / 2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u, 0);
                 else if constexpr (NTB >= 8) {
-                    if (n == 3) epf_mt<6, MT, 1, 4, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u);
-                    else epf_mt<2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u);
+                    if (n == 3) epf_mt<6, MT, 1, 4, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u, 0);
+                    else epf_mt<2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u, 0);
                 }
             }
         } else if (kind == EPF_C) {
             // the workgroups that produced this expert's h tiles: waited for inside the first pass on this expert, behind its weight requests
-            uint32_t* wf = P.flag_b + P.prodb_base[grp];
-            const int nw = ((seam_seen >> grp) & 1u) ? 0 : P.prodb_n[grp];
-            seam_seen |= 1u << grp;
-            const uint16_t* w = P.w_ldn[grp];
+            const int ex = grp & 3, tile0 = (grp >> 2) * 4;      // (task group field: local expert | tile half << 2)
+            uint32_t* wf = P.flag_b + P.prodb_base[ex];
+            const int nw = ((seam_seen >> ex) & 1u) ? 0 : P.prodb_n[ex];
+            seam_seen |= 1u << ex;
+            const uint16_t* w = P.w_ldn[ex];
             const int KB = P.I >> 5, fb = P.E_loc * MT * 16 * P.I * 2;
-            constexpr int NTC = MT >= 8 ? 2 : (MT >= 4 ? 4 : 8);
-            // register rings: RW k-steps of NT weight blocks (<= 128 VGPRs), RB k-steps of MT fragments (<= 64)
-            constexpr int RBC = MT >= 8 ? 2 : 4;
-            if (n == NTC) epf_mt<NTC, MT, 2, (NTC >= 4 ? 4 : 8), RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid, pub, wf, nw, 5u);
-            else if (n == NTC / 2) epf_mt<NTC / 2, MT, 2, (NTC / 2 >= 4 ? 4 : 8), RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid, pub, wf, nw, 5u);
-            else if constexpr (NTC >= 4) {
-                if (n == NTC / 4) epf_mt<NTC / 4, MT, 2, 8, RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid, pub, wf, nw, 5u);
-                else if constexpr (NTC >= 8) epf_mt<1, MT, 2, 8, RBC, false>(P, grp, first, KB, w, P.hpk, grp * MT, fb, smem, tid, pub, wf, nw, 5u);
+            // one pass = 1..4 blocks x MTC tiles (at 8 tiles a pass takes HALF of them: twice the tasks, so every workgroup of the launch has
+            // one, and four k-steps of fragments fit the ring).  Rings: RW k-steps of NT weight blocks (<= 64 VGPRs), 4 k-steps of fragments
+            constexpr int MTC = MT >= 8 ? 4 : MT;
+            const int ft0 = ex * MT + tile0;
+            switch (n) {
+                case 1: epf_mt<1, MTC, 2, 8, 4, false>(P, ex, first, KB, w, P.hpk, ft0, fb, smem, tid, pub, wf, nw, 5u, tile0); break;
+                case 2: epf_mt<2, MTC, 2, 8, 4, false>(P, ex, first, KB, w, P.hpk, ft0, fb, smem, tid, pub, wf, nw, 5u, tile0); break;
+                case 3: epf_mt<3, MTC, 2, 4, 4, false>(P, ex, first, KB, w, P.hpk, ft0, fb, smem, tid, pub, wf, nw, 5u, tile0); break;
+                default: epf_mt<4, MTC, 2, 4, 4, false>(P, ex, first, KB, w, P.hpk, ft0, fb, smem, tid, pub, wf, nw, 5u, tile0); break;
             }
         } else if (kind == EPF_SIG_C) {
             // every storing wave drains its system-scope stores, the workgroup meets, lane t counts this workgroup in on the owner of tile t
@@ -407,14 +410,19 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
 }
 
 // ------------------------------------------------------------------------------------ host: the task lists
-// At the decode shape a phase of one workgroup is a LATENCY chain (stage / wait, first round trip, 8-11 k-steps, reduction, epilogue:
-// 8-12 us whatever the slice), so a workgroup that walked all four phases took ~57 us for 67 MB at ep 8.  Hence two ROLES: SHARED
-// workgroups take phases A and D (the shared experts, own rows, no exchange), LOCAL workgroups take B and C (the local experts over
-// every rank's rows) -- two chains per workgroup, and the shared experts' bytes stream beside the exchange instead of in front of it.
-// The split follows a small intake model (HBM ~26 GB/s and L2-resident fragments ~100 GB/s per CU); UMOE_EPF_NS overrides it.
-// Workgroup order: [0, R) tile riders (local role, dispatched first: everything hangs on them), [R, R + n_s) shared role, its first S
-// also route one own row each, then the local role.  With few workgroups (ranks sharing a card in the tests) every workgroup takes a
-// share of every phase instead: rider | A | B | C | D.
+// At the decode shape a phase of one workgroup is a LATENCY chain (stage / wait, first round trip, 8-11 k-steps of fragments, reduction,
+// epilogue: 8-12 us whatever the slice), so a workgroup that walked all four phases took ~57 us for 67 MB at ep 8.  The lists keep the
+// chains short and side by side (scripts/ep_timeline.py):
+//   * phase A (shared gate/up, own rows, nobody to wait for) on EVERY workgroup that is not a rider: it fills the ~12 us the tile
+//     riders need to push / re-lay the rows, which is when phase B can start at the earliest;
+//   * then two roles: LOCAL workgroups take B (local gate/up over every rank's rows), SHARED workgroups -- the router riders among them
+//     -- take D (shared down: it only needs phase A); the split follows a small intake model (HBM ~26 GB/s, L2-resident fragments
+//     ~100 GB/s per CU; UMOE_EPF_NS overrides it);
+//   * phase C (local down + return stores) on EVERY workgroup, one pass each where the units allow it: it hangs on ALL of phase B, so
+//     its own duration sits fully on the critical path.
+// Workgroup order: [0, R) tile riders (local role, dispatched first: everything hangs on them), [R, R + n_s) shared role, its first S also
+// route one own row each, then the local role.  With few workgroups (ranks sharing a card in the tests) every workgroup takes a share
+// of every phase instead: rider | A | B | C | D.
 struct EpfPlan {
     bool ok = false;
     int n_wg = 0, n_cwg = 0, n_s = 0;
@@ -445,53 +453,58 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
     if (n_wg < riders + 1 || n_wg > 256 || E_loc < 1 || E_loc > UMOE_MT_MAXG || n_fix < 1 || n_fix > 4 || !(R == 2 || R == 4 || R == 8) || D != 2048 ||
         I_dyn % 32 || I_sh % 32 || (I_sh / 32) % 2 == 0)       // (the shared experts' down slices run on flat_down<., 1>: odd k-steps)
         return;
-    // ---- roles
-    std::vector<int> ws, wl;           // shared role / local role, in the order their units are dealt
+    // ---- who takes which phase
+    const bool roles = n_wg >= 128;
+    std::vector<int> wa, wb, wc, wd;      // workgroups of phases A, B, C, D in the order their units are dealt
     int n_s = 0;
-    if (n_wg >= 128) {
+    if (roles) {
         const double hbm = 0.0385, l2 = 0.01;      // us per KiB of intake of one CU
-        const double shared = (n_fix * (I_sh / 16) * 4.0 * (D / 32) + n_fix * (D / 16) * (double)(I_sh / 32)) * hbm;
-        const double local = E_loc * ((I_dyn / 16) * (4.0 * (D / 32) * hbm + R * 2.0 * (D / 32) * l2) + (D / 16) * ((I_dyn / 32) * hbm + R * (double)(I_dyn / 32) * l2));
-        n_s = (int)(n_wg * shared / (shared + local) + 0.5);
+        const double dcost = n_fix * (D / 16) * (double)(I_sh / 32) * hbm;      // shared down
+        const double bcost = E_loc * (I_dyn / 16) * (4.0 * (D / 32) * hbm + R * 2.0 * (D / 32) * l2);
+        n_s = (int)(n_wg * dcost / (dcost + bcost) + 0.5);
+        n_s = std::max(n_s, n_wg - E_loc * (I_dyn / 16));      // (no more B workgroups than there are pairs: at 8 tiles a pass is one pair)
+        n_s = std::max(n_s, (n_fix * (D / 16) + 3) / 4);       // (<= 4 down blocks per shared workgroup: its chain must end before phase C starts)
         if (const char* v = getenv("UMOE_EPF_NS")) n_s = atoi(v);
         n_s = std::max(n_s, S);
         n_s = std::min(n_s, n_wg - R - 1);
-        for (int w = R; w < R + n_s; ++w) ws.push_back(w);
-        for (int w = R + n_s; w < n_wg; ++w) wl.push_back(w);
-        for (int w = 0; w < R; ++w) wl.push_back(w);          // the tile riders last in the deal: the remainder units go to the others first
+        for (int w = R + S; w < n_wg; ++w) wa.push_back(w);                 // everybody but the riders
+        for (int w = R + n_s; w < n_wg; ++w) wb.push_back(w);
+        for (int w = 0; w < R; ++w) wb.push_back(w);                         // the tile riders last in the deal: remainder units go to the others first
+        for (int w = R + S; w < R + n_s; ++w) wd.push_back(w);               // the router riders last in the deal, too
+        for (int w = R; w < R + S; ++w) wd.push_back(w);
+        for (int w = R; w < n_wg; ++w) wc.push_back(w);
+        for (int w = 0; w < R; ++w) wc.push_back(w);
     } else {
-        for (int w = 0; w < n_wg; ++w) { ws.push_back(w); wl.push_back(w); }
+        for (int w = 0; w < n_wg; ++w) { wa.push_back(w); wb.push_back(w); wc.push_back(w); wd.push_back(w); }
     }
     pl.n_s = n_s;
-    std::vector<std::vector<uint32_t>> lists(n_wg);
-    for (int j = 0; j < R; ++j) lists[j].push_back(epf_task(EPF_TILE, j, 0, 0));
-    for (int t = 0; t < S; ++t) lists[R + t].push_back(epf_task(EPF_ROUTER, 0, t, 0));
+    std::vector<std::vector<uint32_t>> la(n_wg), lb(n_wg), lc(n_wg), ld(n_wg);
     std::vector<int> first(n_wg, 0), count(n_wg, 0);
     auto clear = [&]() { std::fill(first.begin(), first.end(), 0); std::fill(count.begin(), count.end(), 0); };
-    // position of a workgroup in its role's flag array (phase A flags: the shared role; phase B flags: the local role)
-    std::vector<int> pos_s(n_wg, -1), pos_l(n_wg, -1);
-    for (size_t k = 0; k < ws.size(); ++k) pos_s[ws[k]] = (int)k;
-    for (size_t k = 0; k < wl.size(); ++k) pos_l[wl[k]] = (int)k;
+    // position of a workgroup among the producers of a phase (its word in that phase's flag array)
+    std::vector<int> pos_a(n_wg, -1), pos_b(n_wg, -1);
+    for (size_t k = 0; k < wa.size(); ++k) pos_a[wa[k]] = (int)k;
+    for (size_t k = 0; k < wb.size(); ++k) pos_b[wb[k]] = (int)k;
     // ---- A: the shared experts' pairs as ONE flat list (a slice may straddle two experts)
     {
         const int P = n_fix * (I_sh / 16);
         clear();
-        epf_deal(P, ws, 0, first, count);
+        epf_deal(P, wa, 0, first, count);
         for (int g = 0; g < n_fix; ++g) { pl.proda_base[g] = -1; pl.proda_n[g] = 0; }
-        for (int w : ws) {
+        for (int w : wa) {
             int f = first[w], c = count[w];
             while (c > 0) {
                 const int k = std::min(c, 7);
-                lists[w].push_back(epf_task(EPF_A, 0, f, k));
+                la[w].push_back(epf_task(EPF_A, 0, f, k));
                 f += k; c -= k;
             }
             if (count[w] > 0) {
-                lists[w].push_back(epf_task(EPF_PUB_A, 0, pos_s[w], 0));
+                la[w].push_back(epf_task(EPF_PUB_A, 0, pos_a[w], 0));
                 for (int g = 0; g < n_fix; ++g) {
                     const int lo = g * (I_sh / 16), hi = lo + I_sh / 16;
                     if (first[w] < hi && first[w] + count[w] > lo) {
-                        if (pl.proda_base[g] < 0) pl.proda_base[g] = pos_s[w];
-                        pl.proda_n[g] = pos_s[w] - pl.proda_base[g] + 1;
+                        if (pl.proda_base[g] < 0) pl.proda_base[g] = pos_a[w];
+                        pl.proda_n[g] = pos_a[w] - pl.proda_base[g] + 1;
                     }
                 }
             }
@@ -503,48 +516,44 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
     {
         const int PP = I_dyn / 16, P = E_loc * PP;
         clear();
-        epf_deal(P, wl, 0, first, count);
+        epf_deal(P, wb, 0, first, count);
         const int pmax = 8 / R;      // pairs per pass: 4 / 2 / 1
         for (int g = 0; g < E_loc; ++g) { pl.prodb_base[g] = -1; pl.prodb_n[g] = 0; }
-        for (int w : wl) {
+        for (int w : wb) {
             int f = first[w], c = count[w];
             bool any = false;
             while (c > 0) {
                 const int g = f / PP, lp = f % PP;
                 const int k = std::min(std::min(c, pmax), PP - lp);      // 1..4 pairs at 2 tiles, 1..2 at 4, 1 at 8: every size has a pass shape
-                lists[w].push_back(epf_task(EPF_B, g, lp, k));
-                if (pl.prodb_base[g] < 0) pl.prodb_base[g] = pos_l[w];
-                pl.prodb_n[g] = pos_l[w] - pl.prodb_base[g] + 1;
+                lb[w].push_back(epf_task(EPF_B, g, lp, k));
+                if (pl.prodb_base[g] < 0) pl.prodb_base[g] = pos_b[w];
+                pl.prodb_n[g] = pos_b[w] - pl.prodb_base[g] + 1;
                 f += k; c -= k;
                 any = true;
             }
-            if (any) lists[w].push_back(epf_task(EPF_PUB_B, 0, pos_l[w], 0));
+            if (any) lb[w].push_back(epf_task(EPF_PUB_B, 0, pos_b[w], 0));
         }
         for (int g = 0; g < E_loc; ++g)
             if (pl.prodb_base[g] < 0 || pl.prodb_n[g] > 512) return;
     }
-    // ---- C: local experts' down blocks, expert-major; block counts per pass 8/4/2/1 (2 tiles), 4/2/1 (4), 2/1 (8)
+    // ---- C: local experts' down blocks as (expert, tile half, block) units -- at 8 tiles a pass takes four of them --, 1..4 blocks per pass
     {
-        const int NB = D / 16, P = E_loc * NB;
+        const int NB = D / 16, H = R >= 8 ? 2 : 1, P = E_loc * H * NB;
         clear();
-        epf_deal(P, wl, (int)wl.size() / 3, first, count);
-        const int bmax = R >= 8 ? 2 : (R >= 4 ? 4 : 8);
+        epf_deal(P, wc, (int)wc.size() / 3, first, count);
         pl.n_cwg = 0;
-        for (int w : wl) {
+        for (int w : wc) {
             int f = first[w], c = count[w];
             bool any = false;
             while (c > 0) {
-                const int g = f / NB, lb = f % NB;
-                int k = std::min(std::min(c, bmax), NB - lb);
-                int p2 = 1;
-                while (p2 * 2 <= k) p2 *= 2;
-                k = p2;
-                lists[w].push_back(epf_task(EPF_C, g, lb, k));
+                const int g = f / (H * NB), hf = (f / NB) % H, lb0 = f % NB;
+                const int k = std::min(std::min(c, 4), NB - lb0);
+                lc[w].push_back(epf_task(EPF_C, g | (hf << 2), lb0, k));
                 f += k; c -= k;
                 any = true;
             }
             if (any) {
-                lists[w].push_back(epf_task(EPF_SIG_C, 0, 0, 0));
+                lc[w].push_back(epf_task(EPF_SIG_C, 0, 0, 0));
                 pl.n_cwg += 1;
             }
         }
@@ -553,21 +562,30 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
     {
         const int NB = D / 16, P = n_fix * NB;
         clear();
-        epf_deal(P, ws, (int)ws.size() / 2, first, count);
-        for (int w : ws) {
+        epf_deal(P, wd, 0, first, count);
+        for (int w : wd) {
             int f = first[w], c = count[w];
             while (c > 0) {
-                const int g = f / NB, lb = f % NB;
-                const int k = std::min(std::min(c, 10), NB - lb);
-                lists[w].push_back(epf_task(EPF_D, g, lb, k));
+                const int g = f / NB, lb0 = f % NB;
+                const int k = std::min(std::min(c, 10), NB - lb0);
+                ld[w].push_back(epf_task(EPF_D, g, lb0, k));
                 f += k; c -= k;
             }
         }
     }
     pl.tasks.assign((size_t)n_wg * UMOE_EPF_MAXT, 0u);
     for (int w = 0; w < n_wg; ++w) {
-        if ((int)lists[w].size() >= UMOE_EPF_MAXT) return;      // (the last word stays EPF_END)
-        for (size_t k = 0; k < lists[w].size(); ++k) pl.tasks[(size_t)w * UMOE_EPF_MAXT + k] = lists[w][k];
+        std::vector<uint32_t> l;
+        if (w < R) l.push_back(epf_task(EPF_TILE, w, 0, 0));
+        else if (w < R + S) l.push_back(epf_task(EPF_ROUTER, 0, w - R, 0));
+        // with roles: A | B or D | C (D only needs A; C hangs on every workgroup's B); without: A | B | C | D (D hides the return flight)
+        l.insert(l.end(), la[w].begin(), la[w].end());
+        l.insert(l.end(), lb[w].begin(), lb[w].end());
+        if (roles) l.insert(l.end(), ld[w].begin(), ld[w].end());
+        l.insert(l.end(), lc[w].begin(), lc[w].end());
+        if (!roles) l.insert(l.end(), ld[w].begin(), ld[w].end());
+        if ((int)l.size() >= UMOE_EPF_MAXT) return;      // (the last word stays EPF_END)
+        for (size_t k = 0; k < l.size(); ++k) pl.tasks[(size_t)w * UMOE_EPF_MAXT + k] = l[k];
     }
     pl.ok = true;
 }
