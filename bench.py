@@ -385,11 +385,13 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     shared_gpu = world > ndev                          # rehearsal of N ranks on fewer GPUs: ranks share cards, no RCCL
-    if shared_gpu:
-        # workgroups of one launch hand rows to each other (umoe_gemm_args.rider_pub): they must all be resident, which two
-        # processes on one card cannot promise each other
-        os.environ["UMOE_RIDER_PUB"] = "0"
     torch.cuda.set_device(local % ndev)
+    if shared_gpu:
+        # workgroups of one launch hand rows to each other: they must all be resident, which processes sharing a card can only promise
+        # each other when every rank's launches are sized to a SHARE of the compute units (the engine's co-residency guards then pick
+        # the launch-per-kernel forms where a one-launch form would not fit its share)
+        cus = torch.cuda.get_device_properties(local % ndev).multi_processor_count
+        os.environ["UMOE_FAKE_CUS"] = str(max((cus - 16) // (world // ndev + (1 if world % ndev else 0)), 1))
     device = torch.device("cuda", local % ndev)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")

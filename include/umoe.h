@@ -645,6 +645,12 @@ int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint8_t* valid_
  * (the reference's cache_position + rope_deltas; NULL = number of valid tokens) */
 int umoe_engine_prefill_pos(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T, const int32_t* pos3_host,
                             const int32_t* next_pos_host, umoe_stream_t stream);
+/* the prompt was run outside the engine (an expert-parallel rank that holds ONLY its local experts -- core.py:505,
+ * deepspeed_ep_param_aggregation.py:16-48 -- prefills through the module-level forward, whose DCMoE blocks exchange rows between the ranks)
+ * and the caller copied the roped K / V of every layer into slots [0, T) of the cache buffers (umoe_engine_buffer "k_cache" / "v_cache",
+ * [layer][row][kv_head][Lmax][head_dim]): sets the decode state only (arguments as umoe_engine_prefill_pos) */
+int umoe_engine_prefill_external(umoe_engine* e, const uint8_t* valid_host, int T, const int32_t* pos3_host, const int32_t* next_pos_host,
+                                 umoe_stream_t stream);
 /* decode bookkeeping state + token buffer (device, owned by caller) */
 typedef struct {
     int32_t* tokens;          /* [B][Tmax][C], -1 = to be generated */
@@ -662,8 +668,9 @@ int umoe_engine_replay(umoe_engine* e, umoe_stream_t stream);
 int umoe_engine_profile_step(umoe_engine* e, const umoe_decode_io* io, umoe_stream_t stream, float* ms, int* launches,
                              int n);
 /* Expert parallel decode (ep_size > 1).  umoe_engine_set_layer then takes exp_gu / exp_dn of the n_real / ep_size LOCAL experts
- * (global ids [ep_rank * E_loc, (ep_rank + 1) * E_loc), core.py:505) and, for the prefill, the row-major tensors of ALL n_real
- * experts (the prefill is not timed and runs replicated; the decode step is what is sharded).
+ * (global ids [ep_rank * E_loc, (ep_rank + 1) * E_loc), core.py:505) and EITHER the row-major tensors of ALL n_real experts (the
+ * engine then prefills replicated on its tiled path) OR no row-major expert tensors at all (rm_exp_* NULL: the rank holds its local
+ * experts only; prefill through umoe_engine_prefill_external).
  * umoe_engine_ep_region: this rank's exchange region (export with umoe_ep_ipc_export).
  * umoe_engine_ep_connect: peers[p] = rank p's region as mapped in this process (peers[ep_rank] = own base).
  *   mode UMOE_EP_PEER: xGMI peer stores; UMOE_EP_LOOPBACK: single-GPU emulation of ONE rank of an ep_size job for timing

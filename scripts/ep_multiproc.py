@@ -27,7 +27,10 @@ def main():
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo")
     if world > ndev:
-        os.environ["UMOE_RIDER_PUB"] = "0"       # processes sharing a card: see bench.py
+        # processes sharing a card: in-launch hand-offs need every workgroup of a launch resident, so every rank's engine is told it
+        # owns a share of the compute units (its one-launch MoE half is then that many workgroups; see bench.py)
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        os.environ["UMOE_FAKE_CUS"] = str((cus - 16) // world)
     cfg = small_cfg(hidden_size=2048, num_attention_heads=16, num_key_value_heads=2, dynamic_intermediate_size=2752,
                     shared_intermediate_size=1376, num_hidden_layers=layers)
     m, _ = build(cfg, 1, 0.02)                       # same seed in every process: slices of one model

@@ -45,6 +45,18 @@ def test_ep_two_processes_hip_ipc_bit_identical():
     assert rc == 0 and "BIT-IDENTICAL" in out, out[-3000:]
 
 
+def test_ep_sharded_weights_two_processes_bit_identical():
+    """Every rank holds ONLY its local experts (core.py:505): packed local experts in the engine, prompt through the module-level forward
+    with the blocks' exchange between the ranks, KV cache handed to the engine, expert-parallel decode -- tokens and logits bit-identical
+    to ep_size 1 on the full model, routed-expert bytes per rank = 1 / N (scripts/ep_sharded_multiproc.py)."""
+    assert torch.cuda.is_available()
+    import random
+    port = random.randint(20000, 40000)
+    rc, out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), "scripts/ep_sharded_multiproc.py", "2", "5"])
+    assert rc == 0 and "SHARDED-BIT-IDENTICAL" in out, out[-3000:]
+
+
 def test_ep_training_step_two_processes_vs_single_block():
     """Expert-parallel training of one DCMoE block (ep_size 2, two processes, the exchange as part of the HIP block's forward and backward,
     core.py:455-488 under autograd) against the ep_size 1 block: outputs, input gradients, gate / shared gradients and the local experts'

@@ -135,7 +135,7 @@ EXPORTS = [
     "umoe_attn_prefill_bwd_workspace_bytes", "umoe_attn_prefill_bwd",
     "umoe_ep_unique_id", "umoe_ep_comm_create", "umoe_ep_comm_destroy", "umoe_ep_all_to_all",
     "umoe_ep_ipc_export", "umoe_ep_ipc_open", "umoe_ep_ipc_close", "umoe_engine_ep_region", "umoe_engine_ep_connect",
-    "umoe_engine_ep_error", "umoe_token_drop", "umoe_router_bwd_drop", "umoe_router_bwd_ex", "umoe_dac_conv1d", "umoe_dac_conv_transpose1d", "umoe_dac_resample", "umoe_vision_rope", "umoe_vision_attn", "umoe_swiglu_pair", "umoe_gelu", "umoe_engine_prefill_pos", "umoe_engine_set_probe", "umoe_engine_info",
+    "umoe_engine_ep_error", "umoe_token_drop", "umoe_router_bwd_drop", "umoe_router_bwd_ex", "umoe_dac_conv1d", "umoe_dac_conv_transpose1d", "umoe_dac_resample", "umoe_vision_rope", "umoe_vision_attn", "umoe_swiglu_pair", "umoe_gelu", "umoe_engine_prefill_pos", "umoe_engine_set_probe", "umoe_engine_info", "umoe_engine_prefill_external",
 ]
 
 EP_PEER, EP_LOOPBACK, EP_RCCL = 0, 1, 2
@@ -218,6 +218,7 @@ def lib():
         L.umoe_engine_ep_error.argtypes = [vp, vp, C.POINTER(i32)]
         L.umoe_engine_set_probe.argtypes = [vp, vp, vp, vp, vp]
         L.umoe_engine_info.argtypes = [vp, C.c_char_p]
+        L.umoe_engine_prefill_external.argtypes = [vp, vp, i32, vp, vp, vp]
         L.umoe_router_dispatch_fwd.argtypes = [C.POINTER(RouterArgs), vp, vp, vp, vp, vp]
         L.umoe_permute_fwd.argtypes = [vp, i32, vp, vp, i32, vp, vp]
         L.umoe_grouped_gemm.argtypes = [C.POINTER(GemmArgs), vp]

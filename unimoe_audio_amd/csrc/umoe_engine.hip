@@ -1010,19 +1010,11 @@ extern "C" int umoe_engine_prefill(umoe_engine* e, const uint16_t* x, const uint
     return umoe_engine_prefill_pos(e, x, valid_host, T, nullptr, nullptr, stream);
 }
 
-extern "C" int umoe_engine_prefill_pos(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T, const int32_t* pos3_host,
-                                       const int32_t* next_pos_host, umoe_stream_t stream) {
-    UMOE_REQUIRE(e && x && valid_host && T > 0, "umoe_engine_prefill: bad argument");
+// positions / KV slots / first generated position of a prompt into the engine's device state (shared by the engine's own prefill and by
+// a prefill computed outside it)
+static int prefill_state(umoe_engine* e, const uint8_t* valid_host, int T, const int32_t* pos3_host, const int32_t* next_pos_host, hipStream_t s) {
     const umoe_engine_cfg& c = e->c;
-    UMOE_REQUIRE(T < c.Lmax, "umoe_engine_prefill: prompt length %d does not fit Lmax %d", T, c.Lmax);
-    UMOE_REQUIRE(e->final_norm, "umoe_engine_prefill: globals not set");
-    UMOE_REQUIRE(c.ep_size == 1 || e->ep_mode >= 0, "umoe_engine_prefill: expert parallel engine is not connected (umoe_engine_ep_connect)");
-    UMOE_REQUIRE(c.ep_size == 1 || (c.rows * T >= 64 && e->tiled_prefill), "umoe_engine_prefill: expert parallel prefill runs replicated on the tiled path: needs rows*T >= 64 (got %d)", c.rows * T);
-    hipStream_t s = (hipStream_t)stream;
     const int n_tok = c.rows * T;
-    int rc;
-    if ((rc = ensure_workspace(e, n_tok))) return rc;
-    if ((rc = build_groups(e, n_tok, s))) return rc;
     // positions: cumsum(mask)-1, masked -> 1 (model.py:1113-1114); kv slot = t; first valid slot per row
     std::vector<int32_t> pos((size_t)3 * n_tok), kvp(n_tok), start(c.rows), q0(c.rows, 0), vc(c.rows);
     for (int r = 0; r < c.rows; ++r) {
@@ -1051,8 +1043,28 @@ extern "C" int umoe_engine_prefill_pos(umoe_engine* e, const uint16_t* x, const 
     UMOE_HIP(hipMemcpyAsync(e->kv_start, start.data(), start.size() * 4, hipMemcpyHostToDevice, s));
     UMOE_HIP(hipMemcpyAsync(e->q_pos0, q0.data(), q0.size() * 4, hipMemcpyHostToDevice, s));
     UMOE_HIP(hipMemcpyAsync(e->valid_count, vc.data(), vc.size() * 4, hipMemcpyHostToDevice, s));
-    UMOE_HIP(hipMemcpyAsync(e->x, x, (size_t)n_tok * c.hidden * 2, hipMemcpyDeviceToDevice, s));
     UMOE_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+    return 0;
+}
+
+extern "C" int umoe_engine_prefill_pos(umoe_engine* e, const uint16_t* x, const uint8_t* valid_host, int T, const int32_t* pos3_host,
+                                       const int32_t* next_pos_host, umoe_stream_t stream) {
+    UMOE_REQUIRE(e && x && valid_host && T > 0, "umoe_engine_prefill: bad argument");
+    const umoe_engine_cfg& c = e->c;
+    UMOE_REQUIRE(T < c.Lmax, "umoe_engine_prefill: prompt length %d does not fit Lmax %d", T, c.Lmax);
+    UMOE_REQUIRE(e->final_norm, "umoe_engine_prefill: globals not set");
+    UMOE_REQUIRE(c.ep_size == 1 || e->ep_mode >= 0, "umoe_engine_prefill: expert parallel engine is not connected (umoe_engine_ep_connect)");
+    UMOE_REQUIRE(c.ep_size == 1 || (c.rows * T >= 64 && e->tiled_prefill), "umoe_engine_prefill: expert parallel prefill runs replicated on the tiled path: needs rows*T >= 64 (got %d)", c.rows * T);
+    for (int l = 0; l < c.layers && c.ep_size > 1; ++l)
+        UMOE_REQUIRE(e->layers[l].has_rm, "umoe_engine_prefill: this expert parallel engine holds its LOCAL experts only (no row-major tensors of the others): "
+                                          "prefill outside the engine and hand the KV cache over (umoe_engine_prefill_external)");
+    hipStream_t s = (hipStream_t)stream;
+    const int n_tok = c.rows * T;
+    int rc;
+    if ((rc = ensure_workspace(e, n_tok))) return rc;
+    if ((rc = build_groups(e, n_tok, s))) return rc;
+    if ((rc = prefill_state(e, valid_host, T, pos3_host, next_pos_host, s))) return rc;
+    UMOE_HIP(hipMemcpyAsync(e->x, x, (size_t)n_tok * c.hidden * 2, hipMemcpyDeviceToDevice, s));
     if ((rc = umoe_rmsnorm_residual_fwd(e->x, nullptr, e->layers[0].w.in_norm, c.rms_eps, n_tok, c.hidden, nullptr, e->hin, s)))
         return rc;
     e->cb_pending = false;
@@ -1062,6 +1074,26 @@ extern "C" int umoe_engine_prefill_pos(umoe_engine* e, const uint16_t* x, const 
         if ((rc = run_layer(e, l, n_tok, T, 1, s))) return rc;
     e->T_prompt = T;
     // switch the group table to decode shape now, outside any later graph capture
+    if ((rc = build_groups(e, c.rows, s))) return rc;
+    return 0;
+}
+
+// The prompt was run OUTSIDE the engine (an expert-parallel rank that holds only its local experts prefills through the module-level
+// forward, whose DCMoE blocks exchange rows over torch.distributed, core.py:455-488) and its roped K / V were copied into the cache buffers
+// (umoe_engine_buffer "k_cache" / "v_cache", slots [0, T) of every row): only the decode state is set here.
+extern "C" int umoe_engine_prefill_external(umoe_engine* e, const uint8_t* valid_host, int T, const int32_t* pos3_host, const int32_t* next_pos_host,
+                                            umoe_stream_t stream) {
+    UMOE_REQUIRE(e && valid_host && T > 0, "umoe_engine_prefill_external: bad argument");
+    const umoe_engine_cfg& c = e->c;
+    UMOE_REQUIRE(T < c.Lmax, "umoe_engine_prefill_external: prompt length %d does not fit Lmax %d", T, c.Lmax);
+    UMOE_REQUIRE(e->final_norm, "umoe_engine_prefill_external: globals not set");
+    UMOE_REQUIRE(c.ep_size == 1 || e->ep_mode >= 0, "umoe_engine_prefill_external: expert parallel engine is not connected (umoe_engine_ep_connect)");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure_workspace(e, c.rows * T))) return rc;      // (pos3 / kv_pos are sized by the token count)
+    if ((rc = prefill_state(e, valid_host, T, pos3_host, next_pos_host, s))) return rc;
+    e->cb_pending = false;
+    e->T_prompt = T;
     if ((rc = build_groups(e, c.rows, s))) return rc;
     return 0;
 }

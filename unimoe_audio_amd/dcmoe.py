@@ -289,8 +289,19 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         a2 = recv.reshape(T2, E_loc * D)
         hbuf = torch.empty((T2 * E_loc, I_d), dtype=torch.bfloat16, device=recv.device)
         ybuf = torch.zeros((T2 * E_loc + 1, D), dtype=torch.bfloat16, device=recv.device)    # last row = zeros for -1
-        ops.grouped_gemm(ops.GroupTable(gu, recv.device), a2, hbuf, max_rows=T2, epilogue=ops.EPI_SWIGLU, n_valid=I_d)
-        ops.grouped_gemm(ops.GroupTable(dn, recv.device), hbuf, ybuf, max_rows=T2, epilogue=ops.EPI_BF16, n_valid=D)
+        if T2 >= TILED_MIN_ROWS:
+            # many rows (an expert-parallel PREFILL): the tiled MFMA kernel on the local experts' own nn.Linear tensors -- per row the
+            # arithmetic of the ep_size 1 block's tiled path (a row's result does not depend on which other rows share its tile), so
+            # the KV cache an expert-parallel prefill leaves is bit-identical to the single-GPU one
+            ex = self._experts()
+            tg_gu = [dict(w=ex[e].gate_proj.weight.data, w2=ex[e].up_proj.weight.data, rows=d2["slot_token"], row_off=d2["offsets"][e:e + 1],
+                          count=d2["counts"][e:e + 1], a_col_off=e * D) for e in range(E_loc)]
+            tg_dn = [dict(w=ex[e].down_proj.weight.data, row_off=d2["offsets"][e:e + 1], count=d2["counts"][e:e + 1]) for e in range(E_loc)]
+            ops.tiled_gemm(tg_gu, a2, hbuf, max_rows=T2, epilogue=ops.EPI_SWIGLU)
+            ops.tiled_gemm(tg_dn, hbuf, ybuf, max_rows=T2, epilogue=ops.EPI_BF16)
+        else:
+            ops.grouped_gemm(ops.GroupTable(gu, recv.device), a2, hbuf, max_rows=T2, epilogue=ops.EPI_SWIGLU, n_valid=I_d)
+            ops.grouped_gemm(ops.GroupTable(dn, recv.device), hbuf, ybuf, max_rows=T2, epilogue=ops.EPI_BF16, n_valid=D)
         so = d2["slot_of"].long()                                             # [T2, E_loc], -1 = no row
         idx = torch.where(so >= 0, so, torch.full_like(so, T2 * E_loc))
         return ybuf[idx.reshape(-1)].reshape(ep, S, E_loc, D)
@@ -303,6 +314,13 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
               for i in range(n_fix)]
         hbuf = torch.empty((n_fix * S, I_s), dtype=torch.bfloat16, device=x.device)
         ybuf = torch.empty((n_fix * S, D), dtype=torch.bfloat16, device=x.device)
+        if S >= TILED_MIN_ROWS:      # (as the ep_size 1 block does from this many rows on: same kernel, same bits)
+            sh = self.fixed_real_moe
+            ops.tiled_gemm([dict(w=sh[i].gate_proj.weight.data, w2=sh[i].up_proj.weight.data, static_count=S, out_row_base=i * S) for i in range(n_fix)],
+                           x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU)
+            ops.tiled_gemm([dict(w=sh[i].down_proj.weight.data, static_count=S, a_row_base=i * S, out_row_base=i * S) for i in range(n_fix)],
+                           hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16)
+            return ybuf
         ops.grouped_gemm(ops.GroupTable(gu, x.device), x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, n_valid=I_s)
         ops.grouped_gemm(ops.GroupTable(dn, x.device), hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16, n_valid=D)
         return ybuf

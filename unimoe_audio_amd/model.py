@@ -223,7 +223,9 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
     @torch.no_grad()
     def text_forward(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                      position_ids: Optional[torch.Tensor] = None, padding_token_mask: Optional[torch.Tensor] = None,
-                     aux_balance_weight: Optional[torch.Tensor] = None, output_router_logits_and_topk: bool = False):
+                     aux_balance_weight: Optional[torch.Tensor] = None, output_router_logits_and_topk: bool = False, kv_sink=None):
+        """kv_sink(layer, k [B, KVH, T, hd], v): called with every layer's roped keys / values (the buffers are reused by the next layer:
+        copy what you keep) -- how an expert-parallel engine that holds only its local experts gets its KV cache from this forward."""
         cfg, dev = self.config, inputs_embeds.device
         B, T, D = inputs_embeds.shape
         H, KVH, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -251,6 +253,8 @@ class UniAudioRVQQwen2_5VLMoEForConditionalGeneration(nn.Module):
             qkv = (ops.tlinear(h, lp["qkv_rm"], bias=lp["qkv_b"]) if tiled
                    else ops.linear(h, lp["qkv_w"], (H + 2 * KVH) * hd, bias=lp["qkv_b"]))
             q = ops.qkv_mrope_kvappend(qkv, cos, sin, pos3, kv_pos, T, H, KVH, hd, cfg.mrope_section, kc, vc)
+            if kv_sink is not None:
+                kv_sink(li, kc, vc)
             ao = ops.attention(q, kc, vc, first_valid, q0, T, H, splits=1)
             x1 = (ops.tlinear(ao, layer.self_attn.o_proj.weight.data, resid=x) if tiled
                   else ops.linear(ao, lp["o_w"], D, resid=x))                             # model.py:238
@@ -480,16 +484,26 @@ class DecodeEngine:
             # expert parallel: this rank streams its n_real / ep_size local experts (core.py:505) at decode; the prefill runs
             # replicated on the row-major tensors of all experts
             e_loc = n_real // self.ep_size
-            lo = self.ep_rank * e_loc
-            eg, ed = arr(pk["exp_gu"][lo:lo + e_loc]), arr(pk["exp_dn"][lo:lo + e_loc])
-            sg, sd = arr(pk["sh_gu"]), arr(pk["sh_dn"])
             # row-major originals (the module's own parameters) for the tiled MFMA kernels of the prefill
             ex = layer.mlp.dynamic_real_moe.deepspeed_moe.experts.deepspeed_experts
             sh = layer.mlp.fixed_real_moe
+            # SHARDED model (from_pretrained(ep_rank, ep_size) / config.ep_size: the modules hold the n_real / ep_size local experts only,
+            # core.py:505, deepspeed_ep_param_aggregation.py:16-48): the engine gets exactly those, and no row-major tensors of experts it
+            # does not have -- its prefill then runs through the module-level forward (prefill below)
+            sharded = self.ep_size > 1 and len(ex) == e_loc
+            if not sharded and len(ex) != n_real:
+                raise L.UmoeError(f"the model holds {len(ex)} routed experts per layer: expected {n_real} (replicated) or {e_loc} (sharded for ep_size {self.ep_size})")
+            self.sharded = sharded
+            lo = 0 if sharded else self.ep_rank * e_loc
+            eg, ed = arr(pk["exp_gu"][lo:lo + e_loc]), arr(pk["exp_dn"][lo:lo + e_loc])
+            sg, sd = arr(pk["sh_gu"]), arr(pk["sh_dn"])
             rm = [p for mods in (ex, sh) for m_ in mods for p in (m_.gate_proj.weight, m_.up_proj.weight, m_.down_proj.weight)]
             if not all(p.is_contiguous() for p in rm + [layer.self_attn.o_proj.weight]):
                 raise L.UmoeError("engine weights must be contiguous")
-            reg, reu, red = arr([m_.gate_proj.weight for m_ in ex]), arr([m_.up_proj.weight for m_ in ex]), arr([m_.down_proj.weight for m_ in ex])
+            if sharded:
+                reg = reu = red = None
+            else:
+                reg, reu, red = arr([m_.gate_proj.weight for m_ in ex]), arr([m_.up_proj.weight for m_ in ex]), arr([m_.down_proj.weight for m_ in ex])
             rsg, rsu, rsd = arr([m_.gate_proj.weight for m_ in sh]), arr([m_.up_proj.weight for m_ in sh]), arr([m_.down_proj.weight for m_ in sh])
             w = L.LayerWeights(in_norm=layer.input_layernorm.weight.data_ptr(), qkv_w=qkv_w.data_ptr(), qkv_b=qkv_b.data_ptr(),
                                o_w=o_w.data_ptr(), post_norm=layer.post_attention_layernorm.weight.data_ptr(),
@@ -512,13 +526,16 @@ class DecodeEngine:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def prefill(self, x: torch.Tensor, attention_mask: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
-                rope_deltas: Optional[torch.Tensor] = None):
+                rope_deltas: Optional[torch.Tensor] = None, external: bool = False):
         """position_ids [3, rows, T] / rope_deltas [rows, 1] (get_rope_index): multimodal prompts; a generated token then sits at
         position T + steps + delta on all three streams (the reference's cache_position + rope_deltas, model.py:779-790)."""
         rows, T = attention_mask.shape
         assert rows == self.rows and x.shape == (rows * T, self.cfg.hidden_size) and x.dtype == torch.bfloat16
         valid = attention_mask.to(torch.uint8).cpu().contiguous()
         self.T_prompt = T
+        if getattr(self, "sharded", False) or external:
+            # (external=True on an engine that COULD prefill itself: the same module-level forward, e.g. as the reference of a sharded run)
+            return self._prefill_sharded(x, attention_mask, valid, position_ids, rope_deltas)
         if position_ids is None:
             L.check(L.lib().umoe_engine_prefill(self.h, x.data_ptr(), valid.data_ptr(), T, self._stream()), "umoe_engine_prefill")
         else:
@@ -530,6 +547,35 @@ class DecodeEngine:
                 raise L.UmoeError(f"rope table of the engine covers {self.max_pos} positions, the prompt needs {need}")
             L.check(L.lib().umoe_engine_prefill_pos(self.h, x.data_ptr(), valid.data_ptr(), T, pos.data_ptr(), nxt.data_ptr(), self._stream()),
                     "umoe_engine_prefill_pos")
+        self.captured = False
+
+    def _prefill_sharded(self, x, attention_mask, valid, position_ids, rope_deltas):
+        """Prefill of a rank that holds ONLY its local experts: the module-level forward (text_forward: the same tiled kernels the engine's
+        own prefill runs; its DCMoE blocks exchange the routed rows with the other ranks over the link's process group, core.py:455-488)
+        hands every layer's roped K / V to the engine's cache, then the engine takes the decode state (umoe_engine_prefill_external).
+        All ranks must call it together (every layer is two collectives)."""
+        rows, T = attention_mask.shape
+        cfg = self.cfg
+        KVH, hd, Lmax = cfg.num_key_value_heads, cfg.head_dim, self.Lmax
+        per_layer = rows * KVH * Lmax * hd * 2
+        pad_k = torch.zeros((rows, KVH, Lmax, hd), dtype=torch.bfloat16, device=self.dev)
+        pad_v = torch.zeros_like(pad_k)
+
+        def sink(li, kc, vc):
+            pad_k[:, :, :T] = kc
+            pad_v[:, :, :T] = vc
+            self.write_buffer("k_cache", pad_k, li * per_layer)
+            self.write_buffer("v_cache", pad_v, li * per_layer)
+
+        with torch.no_grad():
+            self.model.text_forward(x.view(rows, T, cfg.hidden_size), attention_mask.to(self.dev), position_ids=position_ids, kv_sink=sink)
+        pos_p = nxt_p = None
+        if position_ids is not None:
+            assert tuple(position_ids.shape) == (3, rows, T) and rope_deltas is not None
+            pos = position_ids.to(torch.int32).cpu().contiguous()
+            nxt = (rope_deltas.reshape(rows).to(torch.int64).cpu() + T).to(torch.int32).contiguous()
+            pos_p, nxt_p = pos.data_ptr(), nxt.data_ptr()
+        L.check(L.lib().umoe_engine_prefill_external(self.h, valid.data_ptr(), T, pos_p, nxt_p, self._stream()), "umoe_engine_prefill_external")
         self.captured = False
 
     def start_decode(self, prefill_tokens: torch.Tensor, prefill_steps: List[int], max_tokens: int, min_tokens,
