@@ -167,6 +167,113 @@ def ep_combine(y_back: torch.Tensor, slot_of_ep: torch.Tensor, moe_w: torch.Tens
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# RAGGED exchange (reference core.py:455-488 without its capacity padding).  The padded form above ships ep x S x E_loc rows each way
+# whatever the routing is (204 MB per direction and layer at the training shape, more than the reference's own max-capacity padding);
+# here a rank sends every destination exactly the slot rows of that destination's experts -- they are CONTIGUOUS in the local ragged
+# dispatch order (slots are expert-major, experts are rank-major) -- after a small fixed-size header exchange that carries the row
+# counts: per destination {segment rows, count of each of its experts, start of each expert inside the segment}.  The returned rows
+# land in the owner's own slot order, so the combine (and, in training, the whole backward) runs on the owner exactly as at ep_size 1.
+class RaggedPlan:
+    """Index tables of one ragged exchange (host-computed from the headers; the device tensors live on `device`).
+    in_splits / out_splits: rows sent to / received from every rank (segments, alignment padding included).
+    rows2 [n2]: row of the RECEIVED buffer behind every valid received row, in (local expert, source rank, position) order;
+    pos2  [n2]: where that row sits in the per-expert blocks (block q at offsets2[q], `align`-aligned, counts2[q] rows);
+    list2 [cap2]: gather list of the per-expert blocks into the received buffer (padding rows point at row 0)."""
+
+    def __init__(self, in_splits, out_splits, rows2, pos2, list2, counts2, offsets2, cap2):
+        self.in_splits, self.out_splits = in_splits, out_splits
+        self.n_send, self.n_recv = int(sum(in_splits)), int(sum(out_splits))
+        self.rows2, self.pos2, self.list2, self.counts2, self.offsets2, self.cap2 = rows2, pos2, list2, counts2, offsets2, int(cap2)
+
+
+def ep_ragged_plan(offsets: torch.Tensor, counts: torch.Tensor, n_real: int, ep_size: int, group, align: int = 1, device=None) -> RaggedPlan:
+    """offsets [>= n_real + 1] / counts [>= n_real]: the local ragged dispatch (slot = offsets[e] + position; offsets[n_real] = all slots).
+    One host read of the local tables + one fixed-size header all-to-all; everything else is host arithmetic on a few integers."""
+    import numpy as np
+    dev = offsets.device if device is None else device
+    E_loc = n_real // ep_size
+    offs = offsets[: n_real + 1].detach().cpu().numpy().astype(np.int64)
+    cnts = counts[:n_real].detach().cpu().numpy().astype(np.int64)
+    hdr = np.zeros((ep_size, 1 + 2 * E_loc), dtype=np.int64)
+    for d in range(ep_size):
+        b = offs[d * E_loc]
+        hdr[d, 0] = offs[(d + 1) * E_loc] - b
+        hdr[d, 1: 1 + E_loc] = cnts[d * E_loc: (d + 1) * E_loc]
+        hdr[d, 1 + E_loc:] = offs[d * E_loc: (d + 1) * E_loc] - b
+    send = torch.from_numpy(hdr)
+    if group is None or ep_size == 1 or dist.get_world_size(group) == 1:
+        recv = send.clone()
+    elif dist.get_backend(group) == "nccl":
+        r = torch.empty_like(send, device=dev)
+        dist.all_to_all_single(r, send.to(dev), group=group)
+        recv = r.cpu()
+    else:
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+    rh = recv.numpy()
+    in_splits = [int(v) for v in hdr[:, 0]]
+    out_splits = [int(v) for v in rh[:, 0]]
+    base = np.concatenate([[0], np.cumsum(rh[:, 0])])
+    rows2, pos2, counts2, offsets2 = [], [], [], [0]
+    run = 0
+    for q in range(E_loc):
+        start = run
+        for src in range(ep_size):
+            c = int(rh[src, 1 + q])
+            r0 = int(base[src] + rh[src, 1 + E_loc + q])
+            rows2.append(np.arange(r0, r0 + c, dtype=np.int64))
+            pos2.append(np.arange(run, run + c, dtype=np.int64))
+            run += c
+        counts2.append(run - start)
+        run = (run + align - 1) // align * align
+        offsets2.append(run)
+    cap2 = max(run, align)
+    rows2 = np.concatenate(rows2) if rows2 else np.zeros(0, np.int64)
+    pos2 = np.concatenate(pos2) if pos2 else np.zeros(0, np.int64)
+    list2 = np.zeros(cap2, dtype=np.int32)
+    list2[pos2] = rows2
+    # (offsets2[q] = start of block q; the last entry = end of the last block, like umoe_dispatch_build_aligned)
+    offsets2 = [offsets2[q] if q == 0 else offsets2[q] for q in range(E_loc)] + [offsets2[E_loc]]
+    t = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt).to(dev)
+    return RaggedPlan(in_splits, out_splits, t(rows2, torch.int64), t(pos2, torch.int64), t(list2, torch.int32), t(counts2, torch.int32),
+                      t(offsets2, torch.int32), cap2)
+
+
+def ep_exchange_rows(buf: torch.Tensor, in_splits, out_splits, group) -> torch.Tensor:
+    """Ragged all-to-all of ROWS: buf [sum(in_splits), D] (segment d goes to rank d) -> [sum(out_splits), D] (segment s came from rank s)."""
+    n_in, n_out = int(sum(in_splits)), int(sum(out_splits))
+    assert buf.shape[0] >= n_in
+    buf = buf[:n_in].contiguous()
+    if group is None or dist.get_world_size(group) == 1:
+        return buf.clone()
+    out = torch.empty((n_out,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+    if buf.is_cuda and dist.get_backend(group) == "gloo":      # rehearsal of several ranks on one GPU box: staged through the host
+        h_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h_out, buf.cpu(), output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_to_all_single(out, buf, output_split_sizes=list(out_splits), input_split_sizes=list(in_splits), group=group)
+    return out
+
+
+def ep_moe_ragged(h: torch.Tensor, disp: dict, n_real: int, ep_size: int, group,
+                  expert_fn: Callable[[torch.Tensor, RaggedPlan], torch.Tensor], align: int = 1):
+    """Full ragged exchange around `expert_fn(recv [n_recv, D], plan) -> y2 [cap2, D]` (rows of local expert q at plan.offsets2[q], in
+    (source rank, position) order: gather them from `recv` with plan.list2).  Returns y_slots [n_slots, D] in the OWNER's slot order:
+    combine it with the local slot_of table exactly as at ep_size 1."""
+    plan = ep_ragged_plan(disp["offsets"], disp["counts"], n_real, ep_size, group, align=align, device=h.device)
+    st = disp["slot_token"].long()
+    if st.numel() < plan.n_send:
+        st = torch.nn.functional.pad(st, (0, plan.n_send - st.numel()))
+    xs = h[st[: plan.n_send].clamp(0, max(h.shape[0] - 1, 0))]                  # slot order; alignment padding rows are never used
+    recv = ep_exchange_rows(xs, plan.in_splits, plan.out_splits, group)
+    y2 = expert_fn(recv, plan)
+    ret = torch.zeros((plan.n_recv, h.shape[1]), dtype=h.dtype, device=h.device)
+    ret[plan.rows2] = y2[plan.pos2]
+    return ep_exchange_rows(ret, plan.out_splits, plan.in_splits, group), plan
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def dense_ep_moe(h: torch.Tensor, expert_fn: Callable[[int, torch.Tensor], torch.Tensor], rank: int, size: int, n_real: int,
                  group=None) -> torch.Tensor:
     """The DENSE exchange of the expert-parallel decode engine (csrc/umoe_engine.hip run_moe_ep), restated with
