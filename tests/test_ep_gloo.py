@@ -78,6 +78,43 @@ def _worker(rank, world, port, S, out_q):
         ref_moe = one.moe_layer(h, r["expert_mask"][:, :n_real], r["global_weight"][:, :n_real])
         ok = torch.allclose(moe_out.float(), ref_moe.float(), rtol=2 ** -6, atol=2 ** -9)
         out_q.put((rank, bool(ok), float((moe_out.float() - ref_moe.float()).abs().max())))
+        # the RAGGED exchange (counts in a header, per-destination row ranges; what the HIP block runs): the outputs come back in this rank's
+        # own slot order, so the combine uses the LOCAL slot_of table; also with 8-aligned expert blocks (the training path's dispatch)
+        for align in (1, 8):
+            offs_a, run = [], 0
+            for e in range(n_real):
+                offs_a.append(run)
+                run = (run + int(d["counts"][e]) + align - 1) // align * align
+            offs_a.append(run)
+            offs_a = torch.tensor(offs_a, dtype=torch.int32)
+            st_a = torch.zeros(max(run, 1), dtype=torch.int32)
+            so_a = torch.full((S, n_real), -1, dtype=torch.int32)
+            for e in range(n_real):
+                toks = (r["expert_mask"][:, e] != 0).nonzero().flatten()
+                st_a[int(offs_a[e]): int(offs_a[e]) + len(toks)] = toks.to(torch.int32)
+                so_a[toks, e] = int(offs_a[e]) + torch.arange(len(toks), dtype=torch.int32)
+            disp_a = dict(counts=d["counts"], offsets=offs_a, slot_token=st_a, slot_of=so_a)
+
+            def expert_fn_r(recv, plan):
+                y2 = torch.zeros((plan.cap2, recv.shape[1]), dtype=recv.dtype)
+                for e_loc in range(E_loc):
+                    e = rank * E_loc + e_loc
+                    o, n = int(plan.offsets2[e_loc]), int(plan.counts2[e_loc])
+                    assert o % align == 0
+                    if n:
+                        rows = recv[plan.list2[o: o + n].long()]
+                        y2[o: o + n] = swiglu_mlp(rows, w[EXPERT_FMT.format(e=e, p="gate")], w[EXPERT_FMT.format(e=e, p="up")],
+                                                  w[EXPERT_FMT.format(e=e, p="down")])
+                return y2
+            y_slots, plan = EP.ep_moe_ragged(h, disp_a, n_real, world, dist.group.WORLD, expert_fn_r, align=align)
+            assert y_slots.shape[0] == int(offs_a[n_real]) and plan.n_recv == sum(plan.out_splits)
+            acc3 = torch.zeros(S, 64)
+            for e in range(n_real):
+                so = so_a[:, e].long()
+                sel = so >= 0
+                acc3[sel] += moe_w[sel, e:e + 1] * y_slots[so[sel]].float()
+            ok3 = torch.equal(acc3.to(torch.bfloat16), moe_out)          # the same rows, the same order: bit-identical to the padded exchange
+            out_q.put((rank + 20 + (100 if align == 8 else 0), bool(ok3), 0.0))
         # the DENSE exchange of the decode engine (every row visits every expert, the owner selects by its mask):
         # layout contract of csrc/umoe_engine.hip run_moe_ep, restated in ep.dense_ep_moe
         def one_expert(e, xx):
@@ -109,12 +146,14 @@ def test_ep_exchange_world2_gloo(S):
     ps = [ctx.Process(target=_worker, args=(r, 2, port, S, q)) for r in range(2)]
     for p in ps:
         p.start()
-    res = [q.get(timeout=120) for _ in range(6)]
+    res = [q.get(timeout=120) for _ in range(10)]
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
     oks = [r for r in res if r[0] in (0, 1)]
     assert len(oks) == 2 and all(r[1] for r in oks), oks
+    ragged = [r for r in res if r[0] in (20, 21, 120, 121)]
+    assert len(ragged) == 4 and all(r[1] for r in ragged), ragged
     dense = [r for r in res if r[0] in (10, 11)]
     assert len(dense) == 2 and all(r[1] for r in dense), dense
     assert all(r[1] == 2.0 for r in res if r[0] == "max")

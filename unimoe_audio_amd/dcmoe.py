@@ -224,10 +224,14 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         I_d, I_s = self.dynamic_intermediate_size, self.shared_intermediate_size
         ep = int(self.dynamic_real_moe.ep_size)
         if ep > 1:
-            y_back, slot_of_ep = EP.ep_moe(x, disp, n_real, ep, self.dynamic_real_moe.deepspeed_moe.ep_group,
-                                           lambda recv, cnt: self._local_experts(recv, cnt, pk))
+            # ragged exchange (ep.py): every destination gets exactly its experts' slot rows; the outputs come back in THIS rank's slot
+            # order, so the combine reads them with the local slot_of table as at ep_size 1
+            y_back, _ = EP.ep_moe_ragged(x, disp, n_real, ep, self.dynamic_real_moe.deepspeed_moe.ep_group,
+                                         lambda recv, plan: self._local_experts_ragged(recv, plan, pk))
             y_sh = self._shared_experts(x, pk) if n_fix else None
-            out = ops.combine(y_back, slot_of_ep, moe_w, y_sh, global_w, None, n_dyn, n_fix)
+            if y_back.shape[0] == 0:
+                y_back = torch.zeros((1, D), dtype=x.dtype, device=x.device)
+            out = ops.combine(y_back, disp["slot_of"], moe_w, y_sh, global_w, None, n_dyn, n_fix)
         else:
             Imax = max(I_d, I_s if n_fix else 0)
             slots = S * n_real
@@ -272,39 +276,33 @@ class UniMoEAudioSparseMoeBlock(nn.Module):
         return out, logits, top_k, expert_mask, global_w.to(hidden_states.dtype), aux
 
     # ---- expert-parallel pieces -----------------------------------------------------------------------------------
-    def _local_experts(self, recv: torch.Tensor, recv_cnt: torch.Tensor, pk) -> torch.Tensor:
-        """recv [ep, S, E_loc, D] rows routed to this rank's experts -> y of the same shape (grouped SwiGLU on the
-        compacted rows of all source ranks; one group per local expert)."""
-        ep, S, E_loc, D = recv.shape
-        I_d = self.dynamic_intermediate_size
-        mask2 = EP.ep_recv_mask(recv_cnt, S)
-        d2 = ops.dispatch_build(mask2, E_loc)
-        T2 = ep * S
-        gu, dn = [], []
-        for e in range(E_loc):
-            off, cnt = d2["offsets"][e:e + 1], d2["counts"][e:e + 1]
-            gu.append(dict(w=pk["exp_gu"][e], rows=d2["slot_token"], row_off=off, count=cnt, n_blocks=2 * I_d // 16, k=D,
-                           a_col_off=e * D))
-            dn.append(dict(w=pk["exp_dn"][e], row_off=off, count=cnt, n_blocks=D // 16, k=I_d))
-        a2 = recv.reshape(T2, E_loc * D)
-        hbuf = torch.empty((T2 * E_loc, I_d), dtype=torch.bfloat16, device=recv.device)
-        ybuf = torch.zeros((T2 * E_loc + 1, D), dtype=torch.bfloat16, device=recv.device)    # last row = zeros for -1
-        if T2 >= TILED_MIN_ROWS:
+    def _local_experts_ragged(self, recv: torch.Tensor, plan, pk) -> torch.Tensor:
+        """recv [n_recv, D]: the rows every rank routed to this rank's experts (ragged exchange, ep.RaggedPlan) -> y2 [cap2, D], the outputs
+        of local expert q at rows [offsets2[q], offsets2[q] + counts2[q]) in (source rank, position) order.  The expert GEMMs gather their
+        rows from `recv` through plan.list2: no re-laid copy of the received rows."""
+        E_loc = len(self._experts())
+        D, I_d = recv.shape[1], self.dynamic_intermediate_size
+        cap2 = plan.cap2
+        if recv.shape[0] == 0:
+            recv = torch.zeros((1, D), dtype=recv.dtype, device=recv.device)
+        hbuf = torch.empty((cap2, I_d), dtype=torch.bfloat16, device=recv.device)
+        ybuf = torch.zeros((cap2, D), dtype=torch.bfloat16, device=recv.device)
+        off, cnt = plan.offsets2, plan.counts2
+        if cap2 >= TILED_MIN_ROWS:
             # many rows (an expert-parallel PREFILL): the tiled MFMA kernel on the local experts' own nn.Linear tensors -- per row the
-            # arithmetic of the ep_size 1 block's tiled path (a row's result does not depend on which other rows share its tile), so
-            # the KV cache an expert-parallel prefill leaves is bit-identical to the single-GPU one
+            # arithmetic of the ep_size 1 block's tiled path (a row's result does not depend on which other rows share its tile)
             ex = self._experts()
-            tg_gu = [dict(w=ex[e].gate_proj.weight.data, w2=ex[e].up_proj.weight.data, rows=d2["slot_token"], row_off=d2["offsets"][e:e + 1],
-                          count=d2["counts"][e:e + 1], a_col_off=e * D) for e in range(E_loc)]
-            tg_dn = [dict(w=ex[e].down_proj.weight.data, row_off=d2["offsets"][e:e + 1], count=d2["counts"][e:e + 1]) for e in range(E_loc)]
-            ops.tiled_gemm(tg_gu, a2, hbuf, max_rows=T2, epilogue=ops.EPI_SWIGLU)
-            ops.tiled_gemm(tg_dn, hbuf, ybuf, max_rows=T2, epilogue=ops.EPI_BF16)
+            tg_gu = [dict(w=ex[q].gate_proj.weight.data, w2=ex[q].up_proj.weight.data, rows=plan.list2, row_off=off[q:q + 1], count=cnt[q:q + 1])
+                     for q in range(E_loc)]
+            tg_dn = [dict(w=ex[q].down_proj.weight.data, row_off=off[q:q + 1], count=cnt[q:q + 1]) for q in range(E_loc)]
+            ops.tiled_gemm(tg_gu, recv, hbuf, max_rows=cap2, epilogue=ops.EPI_SWIGLU)
+            ops.tiled_gemm(tg_dn, hbuf, ybuf, max_rows=cap2, epilogue=ops.EPI_BF16)
         else:
-            ops.grouped_gemm(ops.GroupTable(gu, recv.device), a2, hbuf, max_rows=T2, epilogue=ops.EPI_SWIGLU, n_valid=I_d)
-            ops.grouped_gemm(ops.GroupTable(dn, recv.device), hbuf, ybuf, max_rows=T2, epilogue=ops.EPI_BF16, n_valid=D)
-        so = d2["slot_of"].long()                                             # [T2, E_loc], -1 = no row
-        idx = torch.where(so >= 0, so, torch.full_like(so, T2 * E_loc))
-        return ybuf[idx.reshape(-1)].reshape(ep, S, E_loc, D)
+            gu = [dict(w=pk["exp_gu"][q], rows=plan.list2, row_off=off[q:q + 1], count=cnt[q:q + 1], n_blocks=2 * I_d // 16, k=D) for q in range(E_loc)]
+            dn = [dict(w=pk["exp_dn"][q], row_off=off[q:q + 1], count=cnt[q:q + 1], n_blocks=D // 16, k=I_d) for q in range(E_loc)]
+            ops.grouped_gemm(ops.GroupTable(gu, recv.device), recv, hbuf, max_rows=cap2, epilogue=ops.EPI_SWIGLU, n_valid=I_d)
+            ops.grouped_gemm(ops.GroupTable(dn, recv.device), hbuf, ybuf, max_rows=cap2, epilogue=ops.EPI_BF16, n_valid=D)
+        return ybuf
 
     def _shared_experts(self, x: torch.Tensor, pk) -> torch.Tensor:
         S, D = x.shape
@@ -487,74 +485,62 @@ class _DCMoETrainFn(torch.autograd.Function):
 
 
 # ---- expert-parallel training (core.py:455-488 under autograd: two all-to-alls forward, the same two backward) ----------------------
-# Layout of an exchange slab: [ep (destination / source rank)][S (position)][E_loc][D]; expert e = rank * E_loc + e_loc keeps the rows of
-# source rank `src` compacted at positions < count (unimoe_audio_amd/ep.py).  Every index below is arithmetic on device tensors: no
-# boolean indexing, no host read of a count.
-def _slot_to_slab(offsets, counts, n_exp, E_loc, S, cap):
-    """for slot row j of an aligned dispatch over n_exp experts: flat row ((e // E_loc) * S + pos) * E_loc + e % E_loc of the slab that
-    carries expert e's rows of this rank, and whether the slot holds a row at all (alignment padding does not)."""
-    j = torch.arange(cap, device=offsets.device)
-    offs, cnts = offsets[: n_exp + 1].long(), counts[:n_exp].long()
-    e = torch.bucketize(j, offs[1: n_exp + 1].contiguous(), right=True).clamp(max=n_exp - 1)
-    pos = j - offs[e]
-    valid = (pos >= 0) & (pos < cnts[e])
-    flat = ((e // E_loc) * S + pos.clamp(0, S - 1)) * E_loc + (e % E_loc)
-    return flat, valid, e
-
-
+# RAGGED exchange (ep.py RaggedPlan): a rank sends every destination exactly the slot rows of that destination's experts (contiguous in
+# the local 8-aligned dispatch order), after a fixed-size header all-to-all with the counts; the outputs -- and in the backward the input
+# gradients -- come back in the owner's own slot order, so everything on the owner (combine, combine backward, permute backward) is the
+# ep_size 1 code.  On the experts' rank the received rows are re-laid once into per-expert 8-aligned blocks in (source rank, position)
+# order -- the order the padded exchange of round 2 produced, so the weight gradients keep their summation order.  Bytes per direction
+# and layer at the training shape: ~ tokens * k / N * 4 KiB per pair of ranks instead of S-row slabs (204 MB per rank).
 def _ep_experts_fwd(blk, x, disp, ex, ep, E_loc, n_real, S, D, I_d, cap, ybuf):
     grp = blk.dynamic_real_moe.deepspeed_moe.ep_group
     bf, dev = torch.bfloat16, x.device
-    send, send_cnt = EP.ep_pack(x, disp["counts"], disp["offsets"], disp["slot_token"], n_real, ep)      # [ep, S, E_loc, D]
-    recv = EP._a2a(torch.empty_like(send), send, grp)                                                    # first all-to-all, core.py:467
-    recv_cnt = EP._a2a(torch.empty_like(send_cnt), send_cnt, grp)
-    T2 = ep * S
-    d2 = ops.dispatch_build_aligned(EP.ep_recv_mask(recv_cnt, S), E_loc, 8)      # the received rows, grouped per local expert
-    cap2 = ops._r8(d2["cap"])
-    j = torch.arange(cap2, device=dev)
-    offs2, cnts2 = d2["offsets"][: E_loc + 1].long(), d2["counts"][:E_loc].long()
-    e2 = torch.bucketize(j, offs2[1: E_loc + 1].contiguous(), right=True).clamp(max=E_loc - 1)
-    valid2 = ((j - offs2[e2]) >= 0) & ((j - offs2[e2]) < cnts2[e2])
-    st2 = torch.nn.functional.pad(d2["slot_token"].long(), (0, max(0, cap2 - d2["slot_token"].numel())))[:cap2]
-    src2 = st2.clamp(0, T2 - 1) * E_loc + e2                                     # row of recv.reshape(T2 * E_loc, D) behind slot j
-    xs2 = recv.reshape(T2 * E_loc, D)[src2] * valid2[:, None].to(bf)
+    plan = EP.ep_ragged_plan(disp["offsets"], disp["counts"], n_real, ep, grp, align=8, device=dev)
+    st = disp["slot_token"].long()
+    if st.numel() < plan.n_send:
+        st = torch.nn.functional.pad(st, (0, plan.n_send - st.numel()))
+    xs = x[st[: plan.n_send].clamp(0, S - 1)]                                     # slot order; alignment padding rows are never used
+    recv = EP.ep_exchange_rows(xs, plan.in_splits, plan.out_splits, grp)         # first all-to-all, core.py:467
+    cap2 = plan.cap2
+    xs2 = torch.zeros((cap2, D), dtype=bf, device=dev)
+    if plan.rows2.numel():
+        xs2[plan.pos2] = recv[plan.rows2]
     hbuf2 = torch.empty((cap2, I_d), dtype=bf, device=dev)
     gu2 = torch.empty((cap2, 2 * I_d), dtype=bf, device=dev)
-    ybuf2 = torch.zeros((cap2 + 1, D), dtype=bf, device=dev)                     # last row = zeros: the target of "no row"
-    g_gu = [dict(w=ex[q][0], w2=ex[q][1], row_off=d2["offsets"][q:q + 1], count=d2["counts"][q:q + 1]) for q in range(E_loc)]
-    g_dn = [dict(w=ex[q][2], row_off=d2["offsets"][q:q + 1], count=d2["counts"][q:q + 1]) for q in range(E_loc)]
-    ops.tiled_gemm(g_gu, xs2, hbuf2, max_rows=T2, epilogue=ops.EPI_SWIGLU, aux_out=gu2)
-    ops.tiled_gemm(g_dn, hbuf2, ybuf2, max_rows=T2, epilogue=ops.EPI_BF16)
-    so2 = d2["slot_of"].long()                                                   # [T2, E_loc], -1 = no row
-    y_full = ybuf2[torch.where(so2 >= 0, so2, torch.full_like(so2, cap2)).reshape(-1)].reshape(ep, S, E_loc, D)
-    back = EP._a2a(torch.empty_like(y_full), y_full.contiguous(), grp)           # second all-to-all, core.py:480
-    flat, valid, _ = _slot_to_slab(disp["offsets"], disp["counts"], n_real, E_loc, S, cap)
-    ybuf[:cap] = back.reshape(-1, D)[flat] * valid[:, None].to(bf)
-    return dict(grp=grp, xs2=xs2, hbuf2=hbuf2, gu2=gu2, d2=d2, cap2=cap2, src2=src2, valid2=valid2, so2=so2, flat=flat, valid=valid, T2=T2)
+    ybuf2 = torch.zeros((cap2, D), dtype=bf, device=dev)
+    off2, cnt2 = plan.offsets2, plan.counts2
+    g_gu = [dict(w=ex[q][0], w2=ex[q][1], row_off=off2[q:q + 1], count=cnt2[q:q + 1]) for q in range(E_loc)]
+    g_dn = [dict(w=ex[q][2], row_off=off2[q:q + 1], count=cnt2[q:q + 1]) for q in range(E_loc)]
+    ops.tiled_gemm(g_gu, xs2, hbuf2, max_rows=cap2, epilogue=ops.EPI_SWIGLU, aux_out=gu2)
+    ops.tiled_gemm(g_dn, hbuf2, ybuf2, max_rows=cap2, epilogue=ops.EPI_BF16)
+    ret = torch.zeros((plan.n_recv, D), dtype=bf, device=dev)
+    if plan.rows2.numel():
+        ret[plan.rows2] = ybuf2[plan.pos2]
+    back = EP.ep_exchange_rows(ret, plan.out_splits, plan.in_splits, grp)        # second all-to-all, core.py:480: the owner's slot order
+    ybuf[:cap].zero_()
+    ybuf[: back.shape[0]] = back
+    return dict(grp=grp, plan=plan, xs2=xs2, hbuf2=hbuf2, gu2=gu2)
 
 
 def _ep_experts_bwd(st, ex, dy, dxe, disp, ep, E_loc, n_real, S, D, I_d, cap):
-    bf, dev, grp = torch.bfloat16, dy.device, st["grp"]
-    # gradients of the returned rows travel to the experts' owners ...
-    pos = torch.arange(S, device=dev)
-    offs, cnts = disp["offsets"][:n_real].long(), disp["counts"][:n_real].long()
-    live = pos[None, :] < cnts[:, None]                                          # [n_real, S]
-    slots = (offs[:, None] + pos[None, :]).clamp(max=cap - 1)
-    dy_send = dy[:cap][slots.reshape(-1)].reshape(n_real, S, D) * live[..., None].to(bf)
-    dy_send = dy_send.reshape(ep, E_loc, S, D).permute(0, 2, 1, 3).contiguous()  # [ep, S, E_loc, D]
-    dy_recv = EP._a2a(torch.empty_like(dy_send), dy_send, grp)
-    T2, cap2, d2 = st["T2"], st["cap2"], st["d2"]
-    dy2 = dy_recv.reshape(T2 * E_loc, D)[st["src2"]] * st["valid2"][:, None].to(bf)
-    dxs2 = torch.zeros((cap2 + 1, D), dtype=bf, device=dev)
+    bf, dev, grp, plan = torch.bfloat16, dy.device, st["grp"], st["plan"]
+    cap2 = plan.cap2
+    # gradients of the returned rows travel to the experts' owners (the forward's first exchange, same segments) ...
+    dy_recv = EP.ep_exchange_rows(dy[:cap], plan.in_splits, plan.out_splits, grp)
+    dy2 = torch.zeros((cap2, D), dtype=bf, device=dev)
+    if plan.rows2.numel():
+        dy2[plan.pos2] = dy_recv[plan.rows2]
+    dxs2 = torch.zeros((cap2, D), dtype=bf, device=dev)
     ident = torch.arange(cap2, dtype=torch.int32, device=dev)
     dwg, dwu, dwd = ops.experts_swiglu_bwd([tuple(ex[q]) for q in range(E_loc)], x=st["xs2"], h=st["hbuf2"], gu=st["gu2"], dy=dy2,
-                                           dx_slots=dxs2[:cap2], D=D, I=I_d, max_rows=T2, counts=d2["counts"], offsets=d2["offsets"],
+                                           dx_slots=dxs2, D=D, I=I_d, max_rows=cap2, counts=plan.counts2, offsets=plan.offsets2,
                                            slot_token=ident)
-    # ... and the gradients of the rows they received travel back to the rows' owners
-    so2 = st["so2"]
-    d_recv = dxs2[torch.where(so2 >= 0, so2, torch.full_like(so2, cap2)).reshape(-1)].reshape(ep, S, E_loc, D)
-    d_back = EP._a2a(torch.empty_like(d_recv), d_recv.contiguous(), grp)
-    dxe[:cap] = d_back.reshape(-1, D)[st["flat"]] * st["valid"][:, None].to(bf)
+    # ... and the gradients of the rows they received travel back to the rows' owners, into their slot order
+    d_ret = torch.zeros((plan.n_recv, D), dtype=bf, device=dev)
+    if plan.rows2.numel():
+        d_ret[plan.rows2] = dxs2[plan.pos2]
+    d_back = EP.ep_exchange_rows(d_ret, plan.out_splits, plan.in_splits, grp)
+    dxe[:cap].zero_()
+    dxe[: d_back.shape[0]] = d_back
     return dwg, dwu, dwd
 
 
