@@ -29,8 +29,9 @@ def test_ep_task_lists_cover_every_unit_once(n_wg, R):
     assert ok
     E_loc, S = 8 // R, 16
     halves = 2 if R == 8 else 1                                       # at 8 row tiles a down pass takes four of them
-    cover = {A: np.zeros(2 * 86, int), B: np.zeros((E_loc, 172), int), CC: np.zeros((E_loc, halves, 128), int), D: np.zeros((2, 128), int)}
-    legal_b = {2: {1, 2, 3, 4}, 4: {1, 2}, 8: {1}}[R]
+    cover = {A: np.zeros(2 * 86, int), B: np.zeros((E_loc, halves, 172), int), CC: np.zeros((E_loc, halves, 128), int), D: np.zeros((2, 128), int)}
+    legal_b = {2: {1, 2, 3, 4}, 4: {1, 2}, 8: {1, 2}}[R]
+    RT = 2 * R if n_wg >= 128 else R                                  # with roles: re-lay riders [0, R), push riders [R, 2R)
     legal_c = {1, 2, 3, 4}
     counted = 0
     for w in range(n_wg):
@@ -45,8 +46,8 @@ def test_ep_task_lists_cover_every_unit_once(n_wg, R):
                 assert 1 <= n <= 7
                 cover[A][first:first + n] += 1
             elif kind == B:
-                assert n in legal_b and first + n <= 172
-                cover[B][grp, first:first + n] += 1
+                assert n in legal_b and first + n <= 172 and (grp & 3) < E_loc and (grp >> 2) < halves
+                cover[B][grp & 3, grp >> 2, first:first + n] += 1
             elif kind == CC:
                 assert n in legal_c and first + n <= 128 and (grp & 3) < E_loc and (grp >> 2) < halves
                 cover[CC][grp & 3, grp >> 2, first:first + n] += 1
@@ -54,9 +55,9 @@ def test_ep_task_lists_cover_every_unit_once(n_wg, R):
                 assert 1 <= n <= 10 and first + n <= 128
                 cover[D][grp, first:first + n] += 1
             elif kind == TILE:
-                assert w == grp < R
+                assert (w == grp < R and n == (2 if n_wg >= 128 else 3)) or (n_wg >= 128 and R <= w < RT and grp == w - R and n == 1)
             elif kind == ROUTER:
-                assert R <= w < R + S and first == w - R
+                assert RT <= w < RT + S and first == w - RT
         # order: rider | A .. publish | B .. publish | C .. count-in, with D behind C (every workgroup takes every phase: D hides the
         # return flight) or in front of it (roles: D only needs A, C hangs on everybody's B)
         core = [k for k in kinds if k not in (TILE, ROUTER)]

@@ -117,5 +117,13 @@ def test_video_text_to_music_writes_a_wav(tmp_path):
     assert len(out) == 1 and os.path.isfile(out[0])
     with wave.open(out[0], "rb") as wf:
         assert wf.getframerate() == 16000 and wf.getnframes() >= 15999
-    with pytest.raises(ValueError):
-        app.video_text_to_music("clip.mp4", "x", str(tmp_path))                # file decoding is not available offline
+    # the full multimodal path (vision tower + 3-D positions) through the same API
+    out2 = app.video_text_to_music(frames, "slow strings", str(tmp_path), max_audio_seconds=1, min_audio_seconds=0, save_name="vig", vision_in_generate=True)
+    assert len(out2) == 1 and os.path.isfile(out2[0])
+    # a file path: decoded when a decoder is importable; here none is, and the error SAYS what to pass instead (a missing file is its own error)
+    with pytest.raises(FileNotFoundError):
+        app.video_text_to_music("clip.mp4", "x", str(tmp_path))
+    fake = tmp_path / "clip.mp4"
+    fake.write_bytes(b"not a video")
+    with pytest.raises(ValueError, match="pass the frames"):
+        app.video_text_to_music(str(fake), "x", str(tmp_path))

@@ -57,8 +57,11 @@ struct epf_args {
 
 static_assert(sizeof(epf_args) + sizeof(umoe_router_args) + sizeof(umoe_rider_pub) + 16 <= 4096, "moe_ep_kernel: kernel arguments exceed 4 KiB");
 
-// ---- tile rider: push the own raw rows to rank j (REAL exchange: j != rank; loopback: into the own slab, tile j), then make tile j ----
-__device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rider_pub& pub, const int j, char* smem, const int tid) {
+// ---- tile rider: push the own raw rows to rank j (REAL exchange: j != rank; loopback: into the own slab, tile j) and / or make tile j.
+// With enough workgroups the two halves are DIFFERENT workgroups (a rank's push does not depend on its peers' rows: the re-lay workgroup
+// polls from the first microsecond on); with few (ranks sharing a card) one workgroup does both, push first. ----
+__device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rider_pub& pub, const int j, char* smem, const int tid, const bool do_push,
+                                               const bool do_pack) {
     constexpr int KB = 64, TPR = 32;
     const int m = tid / TPR, sub = tid % TPR;
     const bool valid = m < P.S.S;
@@ -67,7 +70,7 @@ __device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rid
     const bool own = !P.loopback && j == P.rank;
     const uint16_t* xsrc = P.S.a + (size_t)(valid ? m : 0) * P.S.lda;
     uint4 buf[8];
-    if (!own) {
+    if (!own && do_push) {
         // my rows -> tile (loopback: j, else my rank) of rank j's dispatch slab; one flag word per source tile
         const int dt = P.loopback ? j : P.rank;
         char* dst = P.peer_base[j] + P.disp_off + (size_t)dt * tile_bytes;
@@ -82,7 +85,10 @@ __device__ __forceinline__ void epf_tile_rider(const epf_args& P, const umoe_rid
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(umoe_ep_flag(P.peer_base[j], 0, dt, 0), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        // rank j's rows (loopback: what I just stored) arrive in MY slab, tile j
+    }
+    if (!do_pack) return;
+    if (!own) {
+        // rank j's rows (loopback: what this rank's push stored) arrive in MY slab, tile j
         if (tid == 0) umoe_ep_wait(umoe_ep_flag(P.peer_base[P.rank], 0, j, 0), epoch, pub.err);
         __syncthreads();
         char* src = P.peer_base[P.rank] + P.disp_off + (size_t)j * tile_bytes;
@@ -271,12 +277,12 @@ __device__ __forceinline__ void epf_mt(const epf_args& P, const int grp, const i
 #define EPF_END 0u
 #define EPF_A 1u          // shared gate/up: `first` = flat pair index over the shared groups, units = pairs (1..7)
 #define EPF_PUB_A 2u
-#define EPF_B 3u          // local gate/up: group = local expert, first = pair, units = pairs (NT / 2)
+#define EPF_B 3u          // local gate/up: group = local expert | tile half << 2 (8 tiles: a pass takes 4), first = pair, units = pairs (NT / 2)
 #define EPF_PUB_B 4u
 #define EPF_C 5u          // local down: group = local expert | tile half << 2 (8 tiles: a pass takes 4), first = block, units = blocks (1..4)
 #define EPF_SIG_C 6u
 #define EPF_D 7u          // shared down: group = shared expert, first = block, units = blocks (1..10)
-#define EPF_TILE 8u       // rider: group = tile / peer j
+#define EPF_TILE 8u       // rider: group = tile / peer j, units = 1 push | 2 re-lay (3: both, push first)
 #define EPF_ROUTER 9u     // rider: first = token
 
 template <int MT>
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
         const int grp = (int)((tw >> 24) & 15u), first = (int)((tw >> 8) & 0xffffu), n = (int)(tw & 255u);
         if (ti) __syncthreads();        // (the reduction slab of the previous task is the staging area of this one)
         if (kind == EPF_TILE) {
-            epf_tile_rider(P, pub, grp, smem, tid);
+            epf_tile_rider(P, pub, grp, smem, tid, (n & 1) != 0, (n & 2) != 0);      // units: bit 0 push, bit 1 re-lay
         } else if (kind == EPF_ROUTER) {
             float* rl = reinterpret_cast<float*>(smem + lds_gemm);
             if (tid < 256) {
@@ -339,18 +345,26 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
         } else if (kind == EPF_B) {
             // the operand-order tiles of every rank: waited for INSIDE the first pass, behind its weight requests (replicated flag lines)
             uint32_t* wf = P.tile_ready + (b % UMOE_FLAG_REPL) * 16;
-            const int nw = tiles_seen ? 0 : MT;
+            const int nw = tiles_seen ? 0 : MT;      // (all MT tile flags, whichever tiles this pass takes: one wait per workgroup)
             tiles_seen = true;
-            const uint16_t* w = P.w_lgu[grp];
-            constexpr int NTB = 16 / MT;          // blocks per pass: 8 / 4 / 2 at 2 / 4 / 8 tiles
+            const int ex = grp & 3, tile0 = (grp >> 2) * 4;      // (task group field: local expert | tile half << 2)
+            const uint16_t* w = P.w_lgu[ex];
             const int fb = MT * 16 * P.D * 2;
-            if (2 * n == NTB) epf_mt<NTB, MT, 1, (NTB >= 8 ? 4 : 8), 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u, 0);
-            else if constexpr (NTB >= 4) {
-                if (2 * n == NTB / 2) epf_mt<NTB / 2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u, 0);
-                else if constexpr (NTB >= 8) {
-                    if (n == 3) epf_mt<6, MT, 1, 4, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u, 0);
-                    else epf_mt<2, MT, 1, 8, 2, true>(P, grp, 2 * first, P.D >> 5, w, P.xgp, 0, fb, smem, tid, pub, wf, nw, 4u, 0);
+            // one pass = NT weight blocks x MTB row tiles with NT * MTB <= 16 accumulator tiles.  At 8 row tiles a pass takes HALF of them
+            // and two pairs instead of all eight and one: 512 KiB of intake per pass instead of 640 (a pass's time IS its intake, ~50 GB/s
+            // per CU of L2-resident fragments), the weights of a pair are then read by two workgroups (the second from L2 / MALL)
+            constexpr int MTB = MT >= 8 ? 4 : MT;
+            if constexpr (MTB == 2) {
+                switch (n) {
+                    case 4: epf_mt<8, 2, 1, 4, 2, true>(P, ex, 2 * first, P.D >> 5, w, P.xgp, tile0, fb, smem, tid, pub, wf, nw, 4u, tile0); break;
+                    case 3: epf_mt<6, 2, 1, 4, 2, true>(P, ex, 2 * first, P.D >> 5, w, P.xgp, tile0, fb, smem, tid, pub, wf, nw, 4u, tile0); break;
+                    case 2: epf_mt<4, 2, 1, 8, 2, true>(P, ex, 2 * first, P.D >> 5, w, P.xgp, tile0, fb, smem, tid, pub, wf, nw, 4u, tile0); break;
+                    default: epf_mt<2, 2, 1, 8, 2, true>(P, ex, 2 * first, P.D >> 5, w, P.xgp, tile0, fb, smem, tid, pub, wf, nw, 4u, tile0); break;
                 }
+            } else {
+                // (rings: 4 k-steps of 4 weight blocks + 4 k-steps of 4 fragments = 128 VGPRs beside the 64 of the accumulators)
+                if (n >= 2) epf_mt<4, 4, 1, 4, 4, true>(P, ex, 2 * first, P.D >> 5, w, P.xgp, tile0, fb, smem, tid, pub, wf, nw, 4u, tile0);
+                else epf_mt<2, 4, 1, 8, 4, true>(P, ex, 2 * first, P.D >> 5, w, P.xgp, tile0, fb, smem, tid, pub, wf, nw, 4u, tile0);
             }
         } else if (kind == EPF_C) {
             // the workgroups that produced this expert's h tiles: waited for inside the first pass on this expert, behind its weight requests
@@ -420,7 +434,8 @@ __global__ __launch_bounds__(512, 1) void moe_ep_kernel(const epf_args P, const 
 //     ~100 GB/s per CU; UMOE_EPF_NS overrides it);
 //   * phase C (local down + return stores) on EVERY workgroup, one pass each where the units allow it: it hangs on ALL of phase B, so
 //     its own duration sits fully on the critical path.
-// Workgroup order: [0, R) tile riders (local role, dispatched first: everything hangs on them), [R, R + n_s) shared role, its first S also
+// Workgroup order: [0, R) re-lay riders and [R, 2R) push riders (dispatched first: everything hangs on them; a rank's push does not
+// depend on its peers' rows, so the re-lay workgroups poll from the first microsecond on), [2R, 2R + n_s) shared role, its first S also
 // route one own row each, then the local role.  With few workgroups (ranks sharing a card in the tests) every workgroup takes a share
 // of every phase instead: rider | A | B | C | D.
 struct EpfPlan {
@@ -449,12 +464,13 @@ static void epf_deal(int units, const std::vector<int>& wgs, int rot, std::vecto
 static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_sh, int n_fix, EpfPlan& pl) {
     pl.ok = false;
     pl.n_wg = n_wg;
-    const int riders = R + S;
+    const bool roles = n_wg >= 128;
+    const int RT = roles ? 2 * R : R;            // tile riders: re-lay workgroups [0, R) and, with roles, push workgroups [R, 2R)
+    const int riders = RT + S;
     if (n_wg < riders + 1 || n_wg > 256 || E_loc < 1 || E_loc > UMOE_MT_MAXG || n_fix < 1 || n_fix > 4 || !(R == 2 || R == 4 || R == 8) || D != 2048 ||
         I_dyn % 32 || I_sh % 32 || (I_sh / 32) % 2 == 0)       // (the shared experts' down slices run on flat_down<., 1>: odd k-steps)
         return;
     // ---- who takes which phase
-    const bool roles = n_wg >= 128;
     std::vector<int> wa, wb, wc, wd;      // workgroups of phases A, B, C, D in the order their units are dealt
     int n_s = 0;
     if (roles) {
@@ -462,18 +478,19 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
         const double dcost = n_fix * (D / 16) * (double)(I_sh / 32) * hbm;      // shared down
         const double bcost = E_loc * (I_dyn / 16) * (4.0 * (D / 32) * hbm + R * 2.0 * (D / 32) * l2);
         n_s = (int)(n_wg * dcost / (dcost + bcost) + 0.5);
-        n_s = std::max(n_s, n_wg - E_loc * (I_dyn / 16));      // (no more B workgroups than there are pairs: at 8 tiles a pass is one pair)
+        n_s = std::max(n_s, n_wg - (E_loc * (I_dyn / 16) + 1) / 2 * (R >= 8 ? 2 : 1));      // (no more B workgroups than there are full passes at 8 tiles)
         n_s = std::max(n_s, (n_fix * (D / 16) + 3) / 4);       // (<= 4 down blocks per shared workgroup: its chain must end before phase C starts)
         if (const char* v = getenv("UMOE_EPF_NS")) n_s = atoi(v);
         n_s = std::max(n_s, S);
-        n_s = std::min(n_s, n_wg - R - 1);
-        for (int w = R + S; w < n_wg; ++w) wa.push_back(w);                 // everybody but the riders
-        for (int w = R + n_s; w < n_wg; ++w) wb.push_back(w);
-        for (int w = 0; w < R; ++w) wb.push_back(w);                         // the tile riders last in the deal: remainder units go to the others first
-        for (int w = R + S; w < R + n_s; ++w) wd.push_back(w);               // the router riders last in the deal, too
-        for (int w = R; w < R + S; ++w) wd.push_back(w);
-        for (int w = R; w < n_wg; ++w) wc.push_back(w);
-        for (int w = 0; w < R; ++w) wc.push_back(w);
+        n_s = std::min(n_s, n_wg - RT - 1);
+        for (int w = RT + S; w < n_wg; ++w) wa.push_back(w);                // everybody but the re-lay and the router riders ...
+        for (int w = R; w < RT; ++w) wa.push_back(w);                        // ... the push riders last in the deal (they lose ~3 us first)
+        for (int w = RT + n_s; w < n_wg; ++w) wb.push_back(w);
+        for (int w = 0; w < RT; ++w) wb.push_back(w);                        // the tile riders last in the deal: remainder units go to the others first
+        for (int w = RT + S; w < RT + n_s; ++w) wd.push_back(w);             // the router riders last in the deal, too
+        for (int w = RT; w < RT + S; ++w) wd.push_back(w);
+        for (int w = RT; w < n_wg; ++w) wc.push_back(w);
+        for (int w = 0; w < RT; ++w) wc.push_back(w);
     } else {
         for (int w = 0; w < n_wg; ++w) { wa.push_back(w); wb.push_back(w); wc.push_back(w); wd.push_back(w); }
     }
@@ -512,20 +529,21 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
         for (int g = 0; g < n_fix; ++g)
             if (pl.proda_base[g] < 0 || pl.proda_n[g] > 512) return;
     }
-    // ---- B: local experts' pairs, expert-major; task sizes from the kernel's pass shapes (NT * MT <= 16)
+    // ---- B: local experts' pairs as (expert, tile half, pair) units -- at 8 tiles a pass takes four of them and two pairs --; 1..4 pairs per
+    // pass at 2 tiles, 1..2 at 4 and at 8
     {
-        const int PP = I_dyn / 16, P = E_loc * PP;
+        const int PP = I_dyn / 16, H = R >= 8 ? 2 : 1, P = E_loc * H * PP;
         clear();
         epf_deal(P, wb, 0, first, count);
-        const int pmax = 8 / R;      // pairs per pass: 4 / 2 / 1
+        const int pmax = R >= 8 ? 2 : 8 / R;
         for (int g = 0; g < E_loc; ++g) { pl.prodb_base[g] = -1; pl.prodb_n[g] = 0; }
         for (int w : wb) {
             int f = first[w], c = count[w];
             bool any = false;
             while (c > 0) {
-                const int g = f / PP, lp = f % PP;
-                const int k = std::min(std::min(c, pmax), PP - lp);      // 1..4 pairs at 2 tiles, 1..2 at 4, 1 at 8: every size has a pass shape
-                lb[w].push_back(epf_task(EPF_B, g, lp, k));
+                const int g = f / (H * PP), hf = (f / PP) % H, lp = f % PP;
+                const int k = std::min(std::min(c, pmax), PP - lp);
+                lb[w].push_back(epf_task(EPF_B, g | (hf << 2), lp, k));
                 if (pl.prodb_base[g] < 0) pl.prodb_base[g] = pos_b[w];
                 pl.prodb_n[g] = pos_b[w] - pl.prodb_base[g] + 1;
                 f += k; c -= k;
@@ -576,8 +594,9 @@ static void epf_plan(int n_wg, int R, int E_loc, int S, int D, int I_dyn, int I_
     pl.tasks.assign((size_t)n_wg * UMOE_EPF_MAXT, 0u);
     for (int w = 0; w < n_wg; ++w) {
         std::vector<uint32_t> l;
-        if (w < R) l.push_back(epf_task(EPF_TILE, w, 0, 0));
-        else if (w < R + S) l.push_back(epf_task(EPF_ROUTER, 0, w - R, 0));
+        if (w < R) l.push_back(epf_task(EPF_TILE, w, 0, roles ? 2 : 3));          // re-lay tile w (few workgroups: push to rank w first)
+        else if (w < RT) l.push_back(epf_task(EPF_TILE, w - R, 0, 1));              // push the own rows to rank w - R
+        else if (w < RT + S) l.push_back(epf_task(EPF_ROUTER, 0, w - RT, 0));
         // with roles: A | B or D | C (D only needs A; C hangs on every workgroup's B); without: A | B | C | D (D hides the return flight)
         l.insert(l.end(), la[w].begin(), la[w].end());
         l.insert(l.end(), lb[w].begin(), lb[w].end());
