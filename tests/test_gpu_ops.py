@@ -825,17 +825,33 @@ def test_dcmoe_expert_parallel_two_virtual_ranks(dev):
     bar = threading.Barrier(world)
     box = {}
 
-    def fake_a2a(out, inp, group):
+    # the block's ragged exchange (ep.py) goes through two module-level functions: the header all-to-all and the row all-to-all with split
+    # sizes; here both are thread rendezvous between the two "ranks" of this one process
+    def fake_hdr(send, group, ep_size, dev_):
         r = group[1]
-        box[r] = inp
+        box[("h", r)] = send
         bar.wait()
+        out = torch.stack([box[("h", src)][r] for src in range(world)])
+        bar.wait()
+        return out
+
+    def fake_rows(buf, in_splits, out_splits, n_out, group):
+        r = group[1]
+        box[("r", r)] = (buf, in_splits)
+        torch.cuda.synchronize()
+        bar.wait()
+        parts = []
         for src in range(world):
-            out[src].copy_(box[src][r])
+            b_src, sp = box[("r", src)]
+            o = sum(sp[:r])
+            parts.append(b_src[o: o + sp[r]])
+            assert sp[r] == out_splits[src]
+        out = torch.cat(parts) if parts else buf.new_zeros((0, buf.shape[1]))
         torch.cuda.synchronize()
         bar.wait()
         return out
-    orig = EP._a2a
-    EP._a2a = fake_a2a
+    orig = (EP._hdr_exchange, EP._rows_exchange)
+    EP._hdr_exchange, EP._rows_exchange = fake_hdr, fake_rows
     outs, errs = [None] * world, []
 
     def run(r):
@@ -850,7 +866,7 @@ def test_dcmoe_expert_parallel_two_virtual_ranks(dev):
         [t.start() for t in th]
         [t.join() for t in th]
     finally:
-        EP._a2a = orig
+        EP._hdr_exchange, EP._rows_exchange = orig
     assert not errs, errs
     for r in range(world):
         with torch.no_grad():

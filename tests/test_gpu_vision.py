@@ -168,6 +168,9 @@ def test_generate_drops_the_pixels_like_the_reference_unless_asked(dev):
         dec = DecoderOutput(pre.clone(), psteps, dev)
         extra = dict(pixel_values_videos=px.to(dev), video_grid_thw=grid, second_per_grid_ts=sec) if pix else {}
         codes, lengths = gm.generate(ids, am, dec, max_tokens, 4, vision_in_generate=vig, **extra, **kw)
-        outs.append((codes.cpu(), lengths.cpu()))
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    assert not torch.equal(outs[0][0], outs[2][0])
+        # (the logits of the last decode step: a tiny random model may emit the same codes in every mode, its logits still tell the modes apart)
+        lg = gm._engine.copy_buffer("logits", torch.float32, (2 * B, cfg.codec_channels * cfg.codec_vocab_size)).cpu()
+        outs.append((codes.cpu(), lengths.cpu(), dec.generated_tokens.cpu(), lg))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][3], outs[1][3])
+    assert not torch.equal(outs[0][3], outs[2][3])

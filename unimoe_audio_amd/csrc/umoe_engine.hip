@@ -91,6 +91,9 @@ struct umoe_engine {
     int expert_launch = 0;       // what the last dense decode layer enqueued for its experts: 0 launch per GEMM, 1 box-grid fused, 2 flat, 3 the
                                  // one-launch expert-parallel MoE half (umoe_engine_info)
     int n_cu = 0;                // compute units of the device (UMOE_FAKE_CUS overrides: tests of the co-residency guards)
+    bool fuse_o = true;          // UMOE_FUSE_O: with the flat expert launch, o_proj + residual is computed INSIDE it (half a 16-feature tile per
+                                 // workgroup, handed over by flags; the expert weight stream starts behind the half tile's own requests): four
+                                 // launches per layer.  0: o_proj as its own launch
     bool flat_moe = true;        // UMOE_FLAT_MOE: both expert GEMMs as ONE workgroup per CU with a byte-balanced static schedule
                                  // (umoe_moe_flat.hip); 0 / shapes that do not fit: the box-grid launch below
     bool fuse_moe = true;        // UMOE_FUSE_MOE: gate/up and down projections of a dense decode layer in ONE launch (umoe_moe_fused)
@@ -339,6 +342,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
     }
     if (const char* v = getenv("UMOE_FLAT_MOE")) e->flat_moe = atoi(v) != 0;
     if (const char* v = getenv("UMOE_EP_FLAT")) e->ep_flat = atoi(v) != 0;
+    if (const char* v = getenv("UMOE_FUSE_O")) e->fuse_o = atoi(v) != 0;
     if (const char* v = getenv("UMOE_DENSE_EXPERTS")) e->dense_experts = atoi(v) != 0;
     if (const char* v = getenv("UMOE_TILED_PREFILL")) e->tiled_prefill = atoi(v) != 0;
     if (const char* v = getenv("UMOE_FUSE_ROUTER")) e->fuse_router = atoi(v) != 0;
@@ -833,6 +837,17 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     o.groups = g + 1; o.groups_host = gh + 1; o.num_groups = 1; o.max_rows = n_tok; o.max_n_blocks = D / 16; o.max_k = HD;
     o.a = e->attn_out; o.lda = HD; o.resid = e->x; o.out = e->x1; o.ldo = D; o.n_valid = D;
     o.prologue = UMOE_PRO_PLAIN; o.epilogue = UMOE_EPI_BF16_RESID;
+    // decode with the flat expert launch: o_proj is computed INSIDE that launch (umoe_moe_flat with the o_proj arguments); the conditions are
+    // those under which the flat launch is taken below (the same flags and shapes; should it refuse after all, o_proj is launched there)
+    bool o_in_flat = false;
+    {
+        const char* fv = getenv("UMOE_FLAT_MOE");
+        const bool flat = fv ? atoi(fv) != 0 : e->flat_moe;
+        const bool densef = dense_mode(e, n_tok) && !e->ep_decode(n_tok);
+        o_in_flat = e->fuse_o && flat && densef && T == 1 && !tiled && e->fuse_router && e->rider_pub && e->fuse_moe && e->n_cu > 0 && c.n_dyn == 9 && c.n_fix == 2 &&
+                    D == 2048 && HD == 2048 && n_tok <= 16 &&
+                    umoe_moe_flat_feasible(e->n_cu < 256 ? e->n_cu : 256, n_tok, D, c.inter_dyn, c.inter_shared, c.n_real, c.n_fix);
+    }
     if (tiled) {
         umoe_tgroup_t tg{};
         tg.w = L.w.rm_o; tg.static_count = n_tok; tg.n = D; tg.k = HD; tg.ldw = HD;
@@ -840,12 +855,14 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         ta.groups = &tg; ta.num_groups = 1; ta.max_rows = n_tok; ta.a = e->attn_out; ta.lda = HD; ta.resid = e->x; ta.out = e->x1;
         ta.ldo = D; ta.epilogue = UMOE_EPI_BF16_RESID;
         rc = umoe_tiled_gemm(&ta, s);
-    } else {
+    } else if (!o_in_flat) {
         rc = umoe_grouped_gemm(&o, s);
+    } else {
+        rc = 0;
     }
     if (rc) return rc;
-    PROF(K_OPROJ);
-    if (e->probe_x1 && n_tok == c.rows)
+    if (!o_in_flat) PROF(K_OPROJ);
+    if (e->probe_x1 && n_tok == c.rows && !o_in_flat)
         UMOE_HIP(hipMemcpyAsync(e->probe_x1 + (size_t)l * c.rows * D, e->x1, (size_t)c.rows * D * 2, hipMemcpyDeviceToDevice, s));
     if (e->ep_decode(n_tok)) return run_moe_ep(e, l, n_tok, s);
     // 5. RMSNorm + router                                         model.py:240, core.py:246-291
@@ -873,6 +890,10 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
     const bool flat_ok = dense && e->flat_moe && e->fuse_moe && e->n_cu > 0 && c.n_dyn == 9 && c.n_fix == 2 &&
                          umoe_moe_flat_feasible(e->n_cu < 256 ? e->n_cu : 256, n_tok, D, c.inter_dyn, c.inter_shared, c.n_real, c.n_fix);
     const bool pub_riders = fuse_router && e->rider_pub && (box_fits || flat_ok);
+    if (o_in_flat && !(pub_riders && e->fuse_moe && flat_ok)) {      // (cannot happen with the conditions above; never run a layer without its o_proj)
+        if ((rc = umoe_grouped_gemm(&o, s))) return rc;
+        o_in_flat = false;
+    }
     if (pub_riders) {
         rc = 0;                  // no launch here: the riders write h2 inside the gate/up launch and hand it over (ra.h_out stays h2)
     } else if (fuse_router) {
@@ -958,8 +979,13 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
             const char* fv = getenv("UMOE_FLAT_MOE");      // (read per enqueue: the step graph captures the choice; A/B scripts toggle it)
             const bool flat = fv ? atoi(fv) != 0 : e->flat_moe;
             const int n_wg = e->n_cu < 256 ? e->n_cu : 256;
-            if (flat && n_wg > 0) rc = umoe_moe_flat(&gu, &dn, e->ep_words + 64, 512 - 64, n_wg, s);
+            if (flat && n_wg > 0) rc = umoe_moe_flat(&gu, &dn, e->ep_words + 64, 512 - 64, n_wg, s, o_in_flat ? &o : nullptr, e->ep_words + 2688);
             e->expert_launch = rc == 0 ? 2 : 0;
+            if (rc == 1 && o_in_flat) {      // the flat launch refused after all: o_proj as its own launch in front of whatever runs instead
+                if ((rc = umoe_grouped_gemm(&o, s))) return rc;
+                rc = 1;
+                o_in_flat = false;
+            }
         }
         if (rc == 1 && box_fits) {
             rc = umoe_moe_fused(&gu, &dn, e->ep_words + 64, 512 - 64, s);
@@ -971,6 +997,8 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
             rc = umoe_grouped_gemm(&dn, s);
         }
         if (rc) return rc;
+        if (o_in_flat && e->probe_x1 && n_tok == c.rows)      // (x1 was made inside the launch)
+            UMOE_HIP(hipMemcpyAsync(e->probe_x1 + (size_t)l * c.rows * D, e->x1, (size_t)c.rows * D * 2, hipMemcpyDeviceToDevice, s));
         PROF(K_GATEUP);          // (the fused launch is booked as gate/up: zero down launches tell the reader which form ran)
     } else {
         rc = umoe_grouped_gemm(&dn, s);

@@ -89,9 +89,96 @@ __device__ __forceinline__ uint32_t flat_epoch(const umoe_rider_pub& pub) {
     return __builtin_nontemporal_load(pub.step) * (uint32_t)pub.layers + (uint32_t)pub.layer + 1u;
 }
 
+// ---- o_proj half tiles (arithmetic of wstream_body<1, 16, PLAIN, BF16_RESID, 4> per feature: K split in four 16-step slices summed in order,
+// bf16 rounding, residual add, bf16 rounding).  Half tile ht = features [8 ht, 8 ht + 8): the A operand's 16 rows are those 8 features twice
+// (an output row depends on its own A row only), the valid outputs are rows 0..7.  The caller requested its first expert-weight chunk BEFORE
+// this runs: the weight stream is in flight through the half tile and the wait. ----
+// o_proj INSIDE the launch (half > 0; umoe_moe_flat with an o_proj argument): the raw rows x1 = x + o_proj(attention rows) do not exist when the
+// launch starts -- every workgroup computes HALF of a 16-feature tile of them first, hands it over, and requests its first expert weights in
+// front of the wait: the o_proj launch, its boundary and its cold start leave the chain.  A kernel argument of its OWN (growing flat_args by
+// these fields made hipcc copy that whole 2.7 KB block into scratch).
+struct flat_o {
+    const uint16_t* rows;      // merged attention rows [S][lda_rows]
+    const uint16_t* w;         // WP16 o_proj weights [D / 16 blocks][64 k-steps]
+    const uint16_t* resid;     // residual stream x [S][lda]
+    uint16_t* x1;              // = flat_args.a: the raw rows, written here
+    uint32_t* flags;           // [4 replicas][256] words: half tile ht published (epochs)
+    int lda_rows, lda, S, half, n_wg;      // half = half tiles (2 * D / 16; 0 = o_proj is its own launch), n_wg = workgroups of the launch
+};
+__device__ __forceinline__ void flat_oproj_half(const flat_o O, const umoe_rider_pub& pub, const unsigned b, char* smem, const int tid) {
+    constexpr int KB = 64, TPR = 32;
+    constexpr int QS = (KB * 16 + 255) & ~255, RS = QS * 4;
+    const int lane = tid & 63, h = lane >> 4, mm = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = wave & 3;                                         // waves 4..7 repeat the work of 0..3 (no branch around a load); only 0..3 count
+    const uint32_t epoch = flat_epoch(pub);
+    const int m = tid / TPR, sub = tid % TPR;
+    const bool valid = m < O.S;
+    for (int ht = (int)b; ht < O.half; ht += O.n_wg) {
+        const int t = ht >> 1, half = ht & 1;
+        const uint16_t* src = O.rows + (size_t)(valid ? m : 0) * O.lda_rows;
+        uint4 buf[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) buf[n] = ld16(src + ((n >> 1) * KB + sub + TPR * (n & 1)) * 8);
+        const flat_u32x4* wp = reinterpret_cast<const flat_u32x4*>(O.w) + ((size_t)t * KB) * 64 + (h * 16 + 8 * half + (mm & 7));
+        flat_u32x4 wo[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wo[u] = __builtin_nontemporal_load(wp + (size_t)(16 * ws + u) * 64);
+        const int col = 16 * t + 8 * half + 4 * (h & 1);
+        const uint2 rv2 = *reinterpret_cast<const uint2*>(O.resid + (size_t)(mm < O.S ? mm : 0) * O.lda + col);
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (valid) st16(smem + m * RS + flat_lds_chunk_off(QS, n >> 1, sub + TPR * (n & 1), m), buf[n]);
+        __syncthreads();
+        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const char* bbase = smem + mm * RS;
+        uint4 bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) bv[u] = *reinterpret_cast<const uint4*>(bbase + flat_lds_chunk_off(QS, h, 16 * ws + u, mm));
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wo[u]), __builtin_bit_cast(bf16x8_t, bv[u]), acc, 0, 0, 0);
+        __syncthreads();
+        f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
+        if (wave < 4) red[wave * 64 + lane] = acc;
+        __syncthreads();
+        if (wave == 0 && h < 2 && mm < O.S) {
+            f32x4_t s4 = red[lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f32x4_t v = red[w * 64 + lane];
+                s4[0] += v[0]; s4[1] += v[1]; s4[2] += v[2]; s4[3] += v[3];
+            }
+            uint16_t y[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = rbf(s4[j] + 0.f);
+                const uint32_t rw = j < 2 ? rv2.x : rv2.y;
+                const float rv = __uint_as_float((j & 1) ? (rw & 0xffff0000u) : (rw << 16));
+                x = rv + x;
+                y[j] = f2bf(x);
+            }
+            const auto xrs = __builtin_amdgcn_make_buffer_rsrc(O.x1, 0, O.S * O.lda * 2, 0x00020000);
+            const flat_u32x2 v2 = {(uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16)};
+            __builtin_amdgcn_raw_buffer_store_b64(v2, xrs, (mm * O.lda + col) * 2, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < 4)
+            __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(O.flags + tid * 256 + ht)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every row of x1 is complete when all half tiles are: lane i polls half tile i (replicated lines), bounded
+    if (tid < O.half) flat_wait(O.flags + (b & 3u) * 256 + tid, epoch, pub.err, 6u);
+    __syncthreads();
+}
+
+// oph (a kernel argument: scalar branches) 0: the raw rows `a` exist when the launch starts; 1: they are made INSIDE this launch -- the o_proj
+// half tile, the hand-off and the wait sit between this slice's first weight request and its row loads; 2: made inside the launch, half tile
+// and wait already done by the caller (the router riders).  ONE instantiation per NP serves all three: a second set of instantiations made
+// hipcc copy the whole 2.7 KB kernel-argument block into scratch (private_segment_fixed_size 36 -> 2736).
 template <int NP, bool PUBLISH = true>
 __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider_pub& pub, const int fp0, const unsigned b, char* smem, flat_stamps& st,
-                                            const int tid_in) {      // tid_in = threadIdx.x (a caller that loops over slices passes an opaque copy: see umoe_moe_ep.hip)
+                                            const int tid_in, const int oph = 0, const flat_o O = flat_o{}) {      // tid_in = threadIdx.x (a caller that loops over slices passes an opaque copy: see umoe_moe_ep.hip)
     constexpr int NT = 2 * NP, WV = 8, KB = 64;
     const int tid = tid_in, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: every guard around an MFMA is a scalar branch
@@ -130,53 +217,77 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
         const uint16_t* src = A.a + (size_t)(valid ? m : 0) * A.lda;
         char* dst = smem + m * RS;
         char* nw_lds = smem + 16 * RS;
-        uint4 buf[8];
+        // normalise + stage the 16 rows from the slices the threads hold (`buf`, `nw1`: the row chunks and the norm weights of this thread).
+        // Called at the end of BOTH request orders below, so that each keeps its own counted waits: a common tail behind the join made
+        // the path that requests the rows first wait for the weight chunk behind them.
+        auto norm_stage = [&](uint4 (&buf)[8], const uint4 nw1) {
+            st16(nw_lds + (tid & (4 * KB - 1)) * 16, nw1);      // (both halves of the workgroup store the same 4 KiB)
+            float q4[4];
 #pragma unroll
-        for (int n = 0; n < 8; ++n) buf[n] = ld16(src + ((n >> 1) * KB + sub + TPR * (n & 1)) * 8);
-        // (straight-line loads only: a branch around a load makes hipcc wait for vmcnt(0), i.e. for the weight chunk behind the rows)
-        const uint4 nw1 = ld16(A.norm_w + (tid & (4 * KB - 1)) * 8);
-        // (measured and rejected: BOTH register stages requested here.  A CU issues about 1 KiB of vector loads per 100 cycles, so the
-        //  second stage's 14 requests per wave only delayed the point where the rows are staged -- 8.6 -> 12.1 us -- and bought nothing:
-        //  3.020 vs 3.015 ms/step.  The launch runs at the CU's request rate from its first request on.)
-        __builtin_amdgcn_sched_barrier(0);
-        load_chunk(w0, i0);
-        __builtin_amdgcn_sched_barrier(0);
-        FSTAMP(1);
-        st16(nw_lds + (tid & (4 * KB - 1)) * 16, nw1);      // (both halves of the workgroup store the same 4 KiB)
-        float q4[4];
+            for (int hq = 0; hq < 4; ++hq) {
+                float c2[2];
 #pragma unroll
-        for (int hq = 0; hq < 4; ++hq) {
-            float c2[2];
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    float f[8];
+                    unpack8(buf[hq * 2 + k2], f);
+                    float cs = 0.f;
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
-                float f[8];
-                unpack8(buf[hq * 2 + k2], f);
-                float cs = 0.f;
+                    for (int j = 0; j < 8; ++j) cs += f[j] * f[j];
+                    c2[k2] = cs;
+                }
+                float v = c2[0] + c2[1];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) cs += f[j] * f[j];
-                c2[k2] = cs;
+                for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+                q4[hq] = v;
             }
-            float v = c2[0] + c2[1];
+            const float ss = ((q4[0] + q4[1]) + q4[2]) + q4[3];
+            const float rs = rsqrtf(ss / (float)(KB * 32) + A.rms_eps);
+            __syncthreads();
+            FSTAMP(2);
+            // keep the row slice packed (32 registers) between the sum of squares and the scaling
 #pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-            q4[hq] = v;
-        }
-        const float ss = ((q4[0] + q4[1]) + q4[2]) + q4[3];
-        const float rs = rsqrtf(ss / (float)(KB * 32) + A.rms_eps);
-        __syncthreads();
-        FSTAMP(2);
-        // keep the row slice packed (32 registers) between the sum of squares and the scaling
+            for (int n = 0; n < 8; ++n) asm volatile("" : "+v"(buf[n].x), "+v"(buf[n].y), "+v"(buf[n].z), "+v"(buf[n].w));
 #pragma unroll
-        for (int n = 0; n < 8; ++n) asm volatile("" : "+v"(buf[n].x), "+v"(buf[n].y), "+v"(buf[n].z), "+v"(buf[n].w));
+            for (int n = 0; n < 8; ++n) {
+                const int h = n >> 1, i = sub + TPR * (n & 1);
+                float f[8], w[8];
+                unpack8(buf[n], f);
+                unpack8(*reinterpret_cast<const uint4*>(nw_lds + (h * KB + i) * 16), w);
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int h = n >> 1, i = sub + TPR * (n & 1);
-            float f[8], w[8];
-            unpack8(buf[n], f);
-            unpack8(*reinterpret_cast<const uint4*>(nw_lds + (h * KB + i) * 16), w);
+                for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
+                if (valid) st16(dst + flat_lds_chunk_off(QS, h, i, m), pack8(f));
+            }
+        };
+        if (oph != 0) {
+            // o_proj inside the launch: the first weight chunk goes out FIRST (nothing it needs is missing), the half tile, its hand-off and
+            // the wait for everybody's follow while it flies; then the rows (every load of handed-over bytes an sc1 load)
+            load_chunk(w0, i0);
+            if (oph == 1) flat_oproj_half(O, pub, b, smem, tid);
+            uint4 buf[8];
+            const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.a), 0, A.S * A.lda * 2, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = w[j] * rbf(f[j] * rs);
-            if (valid) st16(dst + flat_lds_chunk_off(QS, h, i, m), pack8(f));
+            for (int n = 0; n < 8; ++n) {
+                const flat_u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rrs, (int)(((size_t)(valid ? m : 0) * A.lda + ((n >> 1) * KB + sub + TPR * (n & 1)) * 8) * 2), 0, 16);
+                buf[n] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+            }
+            const uint4 nw1 = ld16(A.norm_w + (tid & (4 * KB - 1)) * 8);
+            FSTAMP(1);
+            norm_stage(buf, nw1);
+        } else {
+            // the rows exist (the previous launch wrote them): rows first, the weight stream right behind them; normalise while the chunk flies
+            uint4 buf[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) buf[n] = ld16(src + ((n >> 1) * KB + sub + TPR * (n & 1)) * 8);
+            // (straight-line loads only: a branch around a load makes hipcc wait for vmcnt(0), i.e. for the weight chunk behind the rows)
+            const uint4 nw1 = ld16(A.norm_w + (tid & (4 * KB - 1)) * 8);
+            // (measured and rejected: BOTH register stages requested here.  A CU issues about 1 KiB of vector loads per 100 cycles, so the
+            //  second stage's 14 requests per wave only delayed the point where the rows are staged -- 8.6 -> 12.1 us -- and bought nothing:
+            //  3.020 vs 3.015 ms/step.  The launch runs at the CU's request rate from its first request on.)
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(w0, i0);
+            __builtin_amdgcn_sched_barrier(0);
+            FSTAMP(1);
+            norm_stage(buf, nw1);
         }
     }
     __syncthreads();

@@ -29,7 +29,7 @@
 
 #define FLAT_RIDER_LDS 512      // bytes of LDS behind the GEMM area for the riders' partial sums (router4_body: 4 + 4 * 16 floats)
 
-__global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, const umoe_router_args ra, const umoe_rider_pub pub, const int lds_gemm) {
+__global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, const umoe_router_args ra, const umoe_rider_pub pub, const int lds_gemm, const flat_o O) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned b = blockIdx.x;
     const unsigned eg = A.gu[b], ed = A.dn[b];
@@ -42,7 +42,10 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
     }
 #endif
     const int token = (int)(eg >> 16) - 1;
+    const bool oph = O.half > 0;            // o_proj inside this launch (kernel argument: a scalar branch)
     if (token >= 0) {
+        // (the router reads the raw rows: with o_proj inside the launch the rider takes its half tile and the wait first, no prefetch behind it)
+        if (oph) flat_oproj_half(O, pub, b, smem, (int)threadIdx.x);
         // rider: the Top-P router of row `token` (its own RMSNorm + gate GEMV on waves 0..3, then wave 0 alone walks the serial chain while
         // the other waves go on to the GEMM).  Nobody in this launch waits for it: its tables feed the combine of a LATER launch.
         // Waves 4..7 only keep the two barriers of router4_body company.
@@ -59,11 +62,13 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
         }
     }
     const int fp0 = (int)(eg & 2047u), np = (int)((eg >> 11) & 7u);
+    if (oph && token >= 0) __syncthreads();      // (the half tile's reduction slab is the staging area of the rows)
+    const int ophm = oph ? (token >= 0 ? 2 : 1) : 0;
     switch (np) {
-        case 4: flat_gateup<4>(A, pub, fp0, b, smem, st, (int)threadIdx.x); break;
-        case 5: flat_gateup<5>(A, pub, fp0, b, smem, st, (int)threadIdx.x); break;
-        case 6: flat_gateup<6>(A, pub, fp0, b, smem, st, (int)threadIdx.x); break;
-        case 7: flat_gateup<7>(A, pub, fp0, b, smem, st, (int)threadIdx.x); break;
+        case 4: flat_gateup<4>(A, pub, fp0, b, smem, st, (int)threadIdx.x, ophm, O); break;
+        case 5: flat_gateup<5>(A, pub, fp0, b, smem, st, (int)threadIdx.x, ophm, O); break;
+        case 6: flat_gateup<6>(A, pub, fp0, b, smem, st, (int)threadIdx.x, ophm, O); break;
+        case 7: flat_gateup<7>(A, pub, fp0, b, smem, st, (int)threadIdx.x, ophm, O); break;
         default: break;
     }
     for (int sl = 0; sl < FLAT_SLICES; ++sl) {
@@ -285,7 +290,8 @@ static void flat_knobs(FlatShape& sh) {
 }
 
 // Returns 0 (launched), 1 (shapes / CU count do not allow it: nothing launched), < 0 error.
-int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* flags, int flag_words, int n_wg, hipStream_t s) {
+int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* flags, int flag_words, int n_wg, hipStream_t s,
+                  const umoe_gemm_args* oproj, uint32_t* o_flags) {
     UMOE_REQUIRE(gu && dn && flags, "umoe_moe_flat: null argument");
     const int G = gu->num_groups;
     if (!(gu->fused_router && gu->rider_pub && gu->groups_host && dn->groups_host && G == dn->num_groups && G <= FLAT_MAXG && gu->prologue == UMOE_PRO_PLAIN &&
@@ -350,6 +356,21 @@ int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* 
         kb_dn_max = std::max(kb_dn_max, sh.dn_kb[i]);
     }
     for (int i = G; i <= FLAT_MAXG; ++i) A.pair0[i] = P;
+    flat_o O;
+    memset(&O, 0, sizeof(O));
+    if (oproj) {
+        // o_proj + residual inside the launch: its output rows are this launch's raw rows
+        if (!(o_flags && oproj->groups_host && oproj->num_groups == 1 && oproj->epilogue == UMOE_EPI_BF16_RESID && oproj->prologue == UMOE_PRO_PLAIN &&
+              oproj->ksplit <= 1 && oproj->resid && oproj->a && oproj->out == (void*)r->x && oproj->ldo == r->D && oproj->max_rows == r->S && r->D == 2048 &&
+              (oproj->lda & 7) == 0))
+            return 1;
+        const umoe_group_t& og = oproj->groups_host[0];
+        if (og.rows || og.count || og.row_off || og.a_row_base || og.a_col_off || og.out_row_base || og.bias || og.static_count != r->S || og.k != 2048 ||
+            og.n_blocks * 16 != r->D || 2 * og.n_blocks > 256)
+            return 1;
+        O.rows = oproj->a; O.lda_rows = oproj->lda; O.w = og.w; O.resid = oproj->resid; O.flags = o_flags;
+        O.x1 = reinterpret_cast<uint16_t*>(oproj->out); O.lda = r->D; O.S = r->S; O.half = 2 * og.n_blocks; O.n_wg = n_wg;
+    }
     memcpy(A.gu, pl.gu, sizeof(uint32_t) * n_wg);
     memcpy(A.dn, pl.dn, sizeof(uint32_t) * n_wg);
     const umoe_rider_pub pub = *reinterpret_cast<const umoe_rider_pub*>(gu->rider_pub);
@@ -366,7 +387,7 @@ int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* 
     }
     umoe_router_args rr = *r;
     rr.h_out = nullptr;          // nobody reads normalised rows from memory: every workgroup makes its own copy in LDS
-    moe_flat_kernel<<<dim3((unsigned)n_wg), 512, lds + FLAT_RIDER_LDS, s>>>(A, rr, pub, (int)lds);
+    moe_flat_kernel<<<dim3((unsigned)n_wg), 512, lds + FLAT_RIDER_LDS, s>>>(A, rr, pub, (int)lds, O);
     UMOE_LAUNCH_CHECK();
     return 0;
 }

@@ -200,17 +200,7 @@ def ep_ragged_plan(offsets: torch.Tensor, counts: torch.Tensor, n_real: int, ep_
         hdr[d, 0] = offs[(d + 1) * E_loc] - b
         hdr[d, 1: 1 + E_loc] = cnts[d * E_loc: (d + 1) * E_loc]
         hdr[d, 1 + E_loc:] = offs[d * E_loc: (d + 1) * E_loc] - b
-    send = torch.from_numpy(hdr)
-    if group is None or ep_size == 1 or dist.get_world_size(group) == 1:
-        recv = send.clone()
-    elif dist.get_backend(group) == "nccl":
-        r = torch.empty_like(send, device=dev)
-        dist.all_to_all_single(r, send.to(dev), group=group)
-        recv = r.cpu()
-    else:
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=group)
-    rh = recv.numpy()
+    rh = _hdr_exchange(torch.from_numpy(hdr), group, ep_size, dev).numpy()
     in_splits = [int(v) for v in hdr[:, 0]]
     out_splits = [int(v) for v in rh[:, 0]]
     base = np.concatenate([[0], np.cumsum(rh[:, 0])])
@@ -239,11 +229,29 @@ def ep_ragged_plan(offsets: torch.Tensor, counts: torch.Tensor, n_real: int, ep_
                       t(offsets2, torch.int32), cap2)
 
 
+def _hdr_exchange(send: torch.Tensor, group, ep_size: int, dev) -> torch.Tensor:
+    """The fixed-size header all-to-all ([ep, 1 + 2 E_loc] int64 host tensor: row d goes to rank d).  A module-level function so that
+    single-process rehearsals can substitute a rendezvous for the collective (tests/test_gpu_ops.py)."""
+    if group is None or ep_size == 1 or dist.get_world_size(group) == 1:
+        return send.clone()
+    if dist.get_backend(group) == "nccl":
+        r = torch.empty_like(send, device=dev)
+        dist.all_to_all_single(r, send.to(dev), group=group)
+        return r.cpu()
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv
+
+
 def ep_exchange_rows(buf: torch.Tensor, in_splits, out_splits, group) -> torch.Tensor:
     """Ragged all-to-all of ROWS: buf [sum(in_splits), D] (segment d goes to rank d) -> [sum(out_splits), D] (segment s came from rank s)."""
     n_in, n_out = int(sum(in_splits)), int(sum(out_splits))
     assert buf.shape[0] >= n_in
     buf = buf[:n_in].contiguous()
+    return _rows_exchange(buf, list(in_splits), list(out_splits), n_out, group)
+
+
+def _rows_exchange(buf: torch.Tensor, in_splits, out_splits, n_out: int, group) -> torch.Tensor:
     if group is None or dist.get_world_size(group) == 1:
         return buf.clone()
     out = torch.empty((n_out,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
