@@ -844,7 +844,9 @@ static int run_layer(umoe_engine* e, int l, int n_tok, int T, int splits, hipStr
         const char* fv = getenv("UMOE_FLAT_MOE");
         const bool flat = fv ? atoi(fv) != 0 : e->flat_moe;
         const bool densef = dense_mode(e, n_tok) && !e->ep_decode(n_tok);
-        o_in_flat = e->fuse_o && flat && densef && T == 1 && !tiled && e->fuse_router && e->rider_pub && e->fuse_moe && e->n_cu > 0 && c.n_dyn == 9 && c.n_fix == 2 &&
+        const char* ov = getenv("UMOE_FUSE_O");      // (read per enqueue like UMOE_FLAT_MOE: A/B scripts toggle it between captures)
+        const bool fuse_o = ov ? atoi(ov) != 0 : e->fuse_o;
+        o_in_flat = fuse_o && flat && densef && T == 1 && !tiled && e->fuse_router && e->rider_pub && e->fuse_moe && e->n_cu > 0 && c.n_dyn == 9 && c.n_fix == 2 &&
                     D == 2048 && HD == 2048 && n_tok <= 16 &&
                     umoe_moe_flat_feasible(e->n_cu < 256 ? e->n_cu : 256, n_tok, D, c.inter_dyn, c.inter_shared, c.n_real, c.n_fix);
     }
