@@ -236,7 +236,7 @@ int umoe_moe_fused(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t*
 // device's CU count: every workgroup must be resident), the riders are the first S of them.  `gu` / `dn` as for umoe_moe_fused (any
 // nt); `flags`: >= n_wg device words.  Returns 1 (nothing launched) when the shapes or n_wg do not allow a schedule.
 // `oproj` (optional): the o_proj + residual GEMM whose output rows ARE gu's raw rows (fused_router->x): it is computed inside the launch, half
-// a 16-feature tile per workgroup, handed over through `o_flags` (4 x 256 device words, monotonic epochs); K = D = 2048 only.
+// a 16-feature tile per workgroup, handed over through `o_flags` (8 x 256 device words, monotonic epochs); K = D = 2048 only.
 int umoe_moe_flat(const umoe_gemm_args* gu, const umoe_gemm_args* dn, uint32_t* flags, int flag_words, int n_wg, hipStream_t s,
                   const umoe_gemm_args* oproj = nullptr, uint32_t* o_flags = nullptr);
 bool umoe_moe_flat_feasible(int n_wg, int S, int D, int I_dyn, int I_sh, int n_real, int n_fix);

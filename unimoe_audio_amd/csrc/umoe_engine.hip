@@ -314,7 +314,7 @@ extern "C" int umoe_engine_create(const umoe_engine_cfg* cfg, umoe_engine** out)
         return -2;
     }
     // [0] decode steps taken, [1] sticky hand-off error, [16..32) row flags of the rider hand-off (umoe_gemm_args.rider_pub)
-    if (hipMalloc(&e->ep_words, 16384) != hipSuccess || hipMemset(e->ep_words, 0, 16384) != hipSuccess) {
+    if (hipMalloc(&e->ep_words, 32768) != hipSuccess || hipMemset(e->ep_words, 0, 32768) != hipSuccess) {
         umoe_set_error("umoe_engine_create: hipMalloc failed (state words)");
         umoe_engine_destroy(e);
         return -2;
@@ -629,7 +629,7 @@ static int run_moe_ep_flat(umoe_engine* e, int l, int n_tok, hipStream_t s) {
     d.xgp = e->xgp; d.hpk = e->hpk;
     d.h_sh = e->hbuf; d.ldh = Imax; d.h_row0 = c.n_real * n_tok;
     d.y_sh = e->ybuf; d.ldy = D; d.y_row0 = c.n_real * n_tok;
-    d.flags = e->ep_words + 2048; d.flag_words = 4096 - 2048;
+    d.flags = e->ep_words + 2048; d.flag_words = 2688 - 2048;
     d.round = e->ep_words + 2;
     if ((rc = umoe_moe_ep(&d, s))) return rc;
     e->expert_launch = 3;

@@ -102,7 +102,7 @@ struct flat_o {
     const uint16_t* w;         // WP16 o_proj weights [D / 16 blocks][64 k-steps]
     const uint16_t* resid;     // residual stream x [S][lda]
     uint16_t* x1;              // = flat_args.a: the raw rows, written here
-    uint32_t* flags;           // [4 replicas][256] words: half tile ht published (epochs)
+    uint32_t* flags;           // [8 replicas][256] words: half tile ht published (epochs)
     int lda_rows, lda, S, half, n_wg;      // half = half tiles (2 * D / 16; 0 = o_proj is its own launch), n_wg = workgroups of the launch
 };
 __device__ __forceinline__ void flat_oproj_half(const flat_o O, const umoe_rider_pub& pub, const unsigned b, char* smem, const int tid) {
@@ -164,11 +164,36 @@ __device__ __forceinline__ void flat_oproj_half(const flat_o O, const umoe_rider
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid < 4)
+        if (tid < 8)
             __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(O.flags + tid * 256 + ht)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // every row of x1 is complete when all half tiles are: lane i polls half tile i (replicated lines), bounded
-    if (tid < O.half) flat_wait(O.flags + (b & 3u) * 256 + tid, epoch, pub.err, 6u);
+}
+
+// every row of x1 is complete when all half tiles are.  ONE wave polls, four flags per lane (one 16-byte sc1 load per lane: the 256 flags of a
+// replica are one 1 KiB wave-load), eight replicas: the first version -- every thread of every workgroup polling its own word of four replicas
+// -- was 65 k polling loads per round on 16 cache lines and cost more than the launch boundary it replaced.  Bounded like flat_wait.
+__device__ __forceinline__ void flat_oproj_wait(const flat_o O, const umoe_rider_pub& pub, const unsigned b, const int tid) {
+    if (tid < 64) {
+        const uint32_t epoch = flat_epoch(pub);
+        const auto frs = __builtin_amdgcn_make_buffer_rsrc(O.flags + (b & 7u) * 256, 0, 1024, 0x00020000);
+        umoe_gu32* err = reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(pub.err));
+        const bool mine = 4 * tid < O.half;
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned spins = 0;; ++spins) {
+            const flat_u32x4 f4 = __builtin_amdgcn_raw_buffer_load_b128(frs, tid * 16, 0, 16);
+            const bool ok = !mine || ((int32_t)(f4[0] - epoch) >= 0 && (int32_t)(f4[1] - epoch) >= 0 && (int32_t)(f4[2] - epoch) >= 0 && (int32_t)(f4[3] - epoch) >= 0);
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((spins & 1023u) == 1023u) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (wall_clock64() - t0 > 200000000ull) {      // 2 s
+                    uint32_t zero = 0u;
+                    if (tid == 0) __hip_atomic_compare_exchange_strong(err, &zero, 6u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
     __syncthreads();
 }
 
@@ -261,8 +286,11 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
         if (oph != 0) {
             // o_proj inside the launch: the first weight chunk goes out FIRST (nothing it needs is missing), the half tile, its hand-off and
             // the wait for everybody's follow while it flies; then the rows (every load of handed-over bytes an sc1 load)
-            load_chunk(w0, i0);
+            // (the chunk is requested BEHIND the half tile's publish, in front of the wait: in front of the half tile the publish's drain
+            //  -- s_waitcnt vmcnt(0) counts loads too -- waited for the chunk)
             if (oph == 1) flat_oproj_half(O, pub, b, smem, tid);
+            load_chunk(w0, i0);
+            if (oph == 1) flat_oproj_wait(O, pub, b, tid);
             uint4 buf[8];
             const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.a), 0, A.S * A.lda * 2, 0x00020000);
 #pragma unroll

@@ -45,7 +45,10 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
     const bool oph = O.half > 0;            // o_proj inside this launch (kernel argument: a scalar branch)
     if (token >= 0) {
         // (the router reads the raw rows: with o_proj inside the launch the rider takes its half tile and the wait first, no prefetch behind it)
-        if (oph) flat_oproj_half(O, pub, b, smem, (int)threadIdx.x);
+        if (oph) {
+            flat_oproj_half(O, pub, b, smem, (int)threadIdx.x);
+            flat_oproj_wait(O, pub, b, (int)threadIdx.x);
+        }
         // rider: the Top-P router of row `token` (its own RMSNorm + gate GEMV on waves 0..3, then wave 0 alone walks the serial chain while
         // the other waves go on to the GEMM).  Nobody in this launch waits for it: its tables feed the combine of a LATER launch.
         // Waves 4..7 only keep the two barriers of router4_body company.
