@@ -480,10 +480,10 @@ def test_router_riding_in_the_gate_up_launch_is_bit_identical(dev, monkeypatch):
     # fourth: the hand-off off (RMSNorm launch in front, gate/up and down as plain launches); fifth: gate/up and down as two launches
     # instead of one expert launch; sixth: the combine as a launch of its own instead of riding in the next layer's QKV launch;
     # seventh: the box-grid fused expert launch instead of the flat one
-    # eighth: o_proj as its own launch instead of half tiles inside the flat expert launch (the default, third)
-    for fuse, mode, pub, fm, cq, flat, fo in (("0", "0", "1", "1", "1", "1", "1"), ("1", "1", "1", "1", "1", "1", "1"), ("1", "0", "1", "1", "1", "1", "1"),
-                                              ("1", "0", "0", "1", "1", "1", "1"), ("1", "0", "1", "0", "1", "1", "1"), ("1", "0", "1", "1", "0", "1", "1"),
-                                              ("1", "0", "1", "1", "1", "0", "1"), ("1", "0", "1", "1", "1", "1", "0")):
+    # eighth: o_proj as half tiles inside the flat expert launch instead of its own launch (the default, third)
+    for fuse, mode, pub, fm, cq, flat, fo in (("0", "0", "1", "1", "1", "1", "0"), ("1", "1", "1", "1", "1", "1", "0"), ("1", "0", "1", "1", "1", "1", "0"),
+                                              ("1", "0", "0", "1", "1", "1", "0"), ("1", "0", "1", "0", "1", "1", "0"), ("1", "0", "1", "1", "0", "1", "0"),
+                                              ("1", "0", "1", "1", "1", "0", "0"), ("1", "0", "1", "1", "1", "1", "1")):
         monkeypatch.setenv("UMOE_FUSE_O", fo)
         monkeypatch.setenv("UMOE_FUSE_CQ", cq)
         monkeypatch.setenv("UMOE_FUSE_MOE", fm)

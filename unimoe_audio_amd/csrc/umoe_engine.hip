@@ -91,9 +91,11 @@ struct umoe_engine {
     int expert_launch = 0;       // what the last dense decode layer enqueued for its experts: 0 launch per GEMM, 1 box-grid fused, 2 flat, 3 the
                                  // one-launch expert-parallel MoE half (umoe_engine_info)
     int n_cu = 0;                // compute units of the device (UMOE_FAKE_CUS overrides: tests of the co-residency guards)
-    bool fuse_o = true;          // UMOE_FUSE_O: with the flat expert launch, o_proj + residual is computed INSIDE it (half a 16-feature tile per
-                                 // workgroup, handed over by flags; the expert weight stream starts behind the half tile's own requests): four
-                                 // launches per layer.  0: o_proj as its own launch
+    bool fuse_o = false;         // UMOE_FUSE_O=1: with the flat expert launch, o_proj + residual is computed INSIDE it (half a 16-feature tile per
+                                 // workgroup, handed over by flags; the first expert weight stage is requested inside the half tile): four
+                                 // launches per layer, bit-identical -- and 0.05 ms/step SLOWER in all three forms measured (3.170 / 3.064 /
+                                 // 3.069 vs 3.02 / 3.01 / 3.01 ms): the hand-off (publish, 2048-flag wait, row staging) costs the
+                                 // launch more than the o_proj launch it removes.  Off by default; kept selectable and parity-tested
     bool flat_moe = true;        // UMOE_FLAT_MOE: both expert GEMMs as ONE workgroup per CU with a byte-balanced static schedule
                                  // (umoe_moe_flat.hip); 0 / shapes that do not fit: the box-grid launch below
     bool fuse_moe = true;        // UMOE_FUSE_MOE: gate/up and down projections of a dense decode layer in ONE launch (umoe_moe_fused)

@@ -91,8 +91,7 @@ __device__ __forceinline__ uint32_t flat_epoch(const umoe_rider_pub& pub) {
 
 // ---- o_proj half tiles (arithmetic of wstream_body<1, 16, PLAIN, BF16_RESID, 4> per feature: K split in four 16-step slices summed in order,
 // bf16 rounding, residual add, bf16 rounding).  Half tile ht = features [8 ht, 8 ht + 8): the A operand's 16 rows are those 8 features twice
-// (an output row depends on its own A row only), the valid outputs are rows 0..7.  The caller requested its first expert-weight chunk BEFORE
-// this runs: the weight stream is in flight through the half tile and the wait. ----
+// (an output row depends on its own A row only), the valid outputs are rows 0..7. ----
 // o_proj INSIDE the launch (half > 0; umoe_moe_flat with an o_proj argument): the raw rows x1 = x + o_proj(attention rows) do not exist when the
 // launch starts -- every workgroup computes HALF of a 16-feature tile of them first, hands it over, and requests its first expert weights in
 // front of the wait: the o_proj launch, its boundary and its cold start leave the chain.  A kernel argument of its OWN (growing flat_args by
@@ -105,7 +104,18 @@ struct flat_o {
     uint32_t* flags;           // [8 replicas][256] words: half tile ht published (epochs)
     int lda_rows, lda, S, half, n_wg;      // half = half tiles (2 * D / 16; 0 = o_proj is its own launch), n_wg = workgroups of the launch
 };
-__device__ __forceinline__ void flat_oproj_half(const flat_o O, const umoe_rider_pub& pub, const unsigned b, char* smem, const int tid) {
+// PREFETCH: the caller's first weight chunk (pw0 <- pwp at k-step ic0) is requested inside: by waves 1..7 as soon as the half tile's own loads
+// have landed, by wave 0 -- whose drain in front of the publish would wait for it (vmcnt counts loads and stores, in order) -- behind the
+// publish.  The weight stream then runs through the half tile, its hand-off and the wait.  (Both register stages here: 68-102 spilled
+// registers -- the normalisation of the rows runs with the stages live.)
+template <int NT, bool PREFETCH>
+__device__ __forceinline__ void flat_oproj_half(const flat_o O, const umoe_rider_pub& pub, const unsigned b, char* smem, const int tid,
+                                                const flat_u32x4* const (&pwp)[NT], flat_u32x4 (&pw0)[NT], const int ic0) {
+    auto prefetch = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pw0[t] = __builtin_nontemporal_load(pwp[t] + (size_t)ic0 * 64);
+    };
+    bool first = true;
     constexpr int KB = 64, TPR = 32;
     constexpr int QS = (KB * 16 + 255) & ~255, RS = QS * 4;
     const int lane = tid & 63, h = lane >> 4, mm = lane & 15;
@@ -126,18 +136,35 @@ __device__ __forceinline__ void flat_oproj_half(const flat_o O, const umoe_rider
         for (int u = 0; u < 16; ++u) wo[u] = __builtin_nontemporal_load(wp + (size_t)(16 * ws + u) * 64);
         const int col = 16 * t + 8 * half + 4 * (h & 1);
         const uint2 rv2 = *reinterpret_cast<const uint2*>(O.resid + (size_t)(mm < O.S ? mm : 0) * O.lda + col);
+        uint32_t rvx, rvy;
 #pragma unroll
         for (int n = 0; n < 8; ++n)
             if (valid) st16(smem + m * RS + flat_lds_chunk_off(QS, n >> 1, sub + TPR * (n & 1), m), buf[n]);
+        if constexpr (PREFETCH) {
+            // everything this half tile loaded has to be in its registers HERE (the asm operands make hipcc place its wait in front of the
+            // prefetch: behind it, a wait for these older loads would be a wait for the younger weight chunks too)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(wo[u]));
+            uint32_t r0 = rv2.x, r1 = rv2.y;
+            asm volatile("" : "+v"(r0), "+v"(r1));
+            rvx = r0; rvy = r1;
+            if (first && wave != 0) prefetch();
+        } else {
+            rvx = rv2.x; rvy = rv2.y;
+        }
         __syncthreads();
         f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const char* bbase = smem + mm * RS;
-        uint4 bv[16];
+        // (fragments four at a time: the two weight stages of the caller are live here, all sixteen at once spilled)
 #pragma unroll
-        for (int u = 0; u < 16; ++u) bv[u] = *reinterpret_cast<const uint4*>(bbase + flat_lds_chunk_off(QS, h, 16 * ws + u, mm));
+        for (int u0 = 0; u0 < 16; u0 += 4) {
+            uint4 bv[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wo[u]), __builtin_bit_cast(bf16x8_t, bv[u]), acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) bv[u] = *reinterpret_cast<const uint4*>(bbase + flat_lds_chunk_off(QS, h, 16 * ws + u0 + u, mm));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wo[u0 + u]), __builtin_bit_cast(bf16x8_t, bv[u]), acc, 0, 0, 0);
+        }
         __syncthreads();
         f32x4_t* red = reinterpret_cast<f32x4_t*>(smem);
         if (wave < 4) red[wave * 64 + lane] = acc;
@@ -153,7 +180,7 @@ __device__ __forceinline__ void flat_oproj_half(const flat_o O, const umoe_rider
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float x = rbf(s4[j] + 0.f);
-                const uint32_t rw = j < 2 ? rv2.x : rv2.y;
+                const uint32_t rw = j < 2 ? rvx : rvy;
                 const float rv = __uint_as_float((j & 1) ? (rw & 0xffff0000u) : (rw << 16));
                 x = rv + x;
                 y[j] = f2bf(x);
@@ -162,10 +189,17 @@ __device__ __forceinline__ void flat_oproj_half(const flat_o O, const umoe_rider
             const flat_u32x2 v2 = {(uint32_t)y[0] | ((uint32_t)y[1] << 16), (uint32_t)y[2] | ((uint32_t)y[3] << 16)};
             __builtin_amdgcn_raw_buffer_store_b64(v2, xrs, (mm * O.lda + col) * 2, 0, 16);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // only wave 0 stored (and only it has nothing else in flight)
         __syncthreads();
         if (tid < 8)
             __hip_atomic_store(reinterpret_cast<umoe_gu32*>(reinterpret_cast<uintptr_t>(O.flags + tid * 256 + ht)), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (PREFETCH) {
+            if (first && wave == 0) prefetch();
+        }
+        first = false;
+    }
+    if constexpr (PREFETCH) {
+        if (first) prefetch();      // (a workgroup without a half tile)
     }
 }
 
@@ -286,11 +320,14 @@ __device__ __forceinline__ void flat_gateup(const flat_args& A, const umoe_rider
         if (oph != 0) {
             // o_proj inside the launch: the first weight chunk goes out FIRST (nothing it needs is missing), the half tile, its hand-off and
             // the wait for everybody's follow while it flies; then the rows (every load of handed-over bytes an sc1 load)
-            // (the chunk is requested BEHIND the half tile's publish, in front of the wait: in front of the half tile the publish's drain
-            //  -- s_waitcnt vmcnt(0) counts loads too -- waited for the chunk)
-            if (oph == 1) flat_oproj_half(O, pub, b, smem, tid);
-            load_chunk(w0, i0);
-            if (oph == 1) flat_oproj_wait(O, pub, b, tid);
+            // oph 1: the first register stage is requested inside the half tile (flat_oproj_half); oph 2 (router riders: half tile and
+            // wait done by the caller): here
+            if (oph == 1) {
+                flat_oproj_half<NT, true>(O, pub, b, smem, tid, wp, w0, min(i0, i1 - 1));
+                flat_oproj_wait(O, pub, b, tid);
+            } else {
+                load_chunk(w0, i0);
+            }
             uint4 buf[8];
             const auto rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(A.a), 0, A.S * A.lda * 2, 0x00020000);
 #pragma unroll

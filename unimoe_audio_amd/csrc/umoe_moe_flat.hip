@@ -46,7 +46,9 @@ __global__ __launch_bounds__(512, 1) void moe_flat_kernel(const flat_args A, con
     if (token >= 0) {
         // (the router reads the raw rows: with o_proj inside the launch the rider takes its half tile and the wait first, no prefetch behind it)
         if (oph) {
-            flat_oproj_half(O, pub, b, smem, (int)threadIdx.x);
+            const flat_u32x4* const nowp[1] = {nullptr};
+            flat_u32x4 now0[1];
+            flat_oproj_half<1, false>(O, pub, b, smem, (int)threadIdx.x, nowp, now0, 0);
             flat_oproj_wait(O, pub, b, (int)threadIdx.x);
         }
         // rider: the Top-P router of row `token` (its own RMSNorm + gate GEMV on waves 0..3, then wave 0 alone walks the serial chain while
