@@ -246,6 +246,37 @@ typedef struct {
 } umoe_tgemm_args;
 int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream);
 
+/* Weight-gradient form of the tiled GEMM: both operands are row-major with the CONTRACTION index as the row (tokens / expert slots), as
+ * autograd holds activations and their gradients -- dW = dY^T X without transposed copies (torch.nn.functional.linear backward,
+ * core.py:21-49 through the expert MLPs and every nn.Linear of model.py:672-871):
+ *   out_g[m][n] = sum over k in the group's window of  P[k][p_col_off + m] * Q[k][q_col_off + n]      (bf16 in, fp32 sum, bf16 out)
+ * The window is static (k_off, k) or read on the device (k_off_dev / k_count_dev: an expert's slot range from
+ * umoe_dispatch_build_aligned).  k_split > 1 (static windows, groups that tile one dense [rows][ldo] output with n == ldo): the window is
+ * cut into k_split parts whose fp32 partial outputs (ws, part_stride floats apart, umoe_tiled_gemm_tn_workspace_bytes) are summed in
+ * fixed order -- for products with too few 256 x 256 output tiles to fill the chip. */
+typedef struct {
+    const uint16_t* p; int ldp;   /* optional per-group operands (NULL: the launch's) */
+    const uint16_t* q; int ldq;
+    void* out;                    /* optional per-group output base (NULL: the launch's) */
+    int p_col_off, q_col_off;     /* column of P that is output row 0 / column of Q that is output column 0 (multiples of 8) */
+    int m, n;                     /* output rows / columns (multiples of 8) */
+    int k_off, k;                 /* static window [k_off, k_off + k) */
+    const int32_t* k_off_dev;     /* device scalars, both or neither */
+    const int32_t* k_count_dev;
+    int out_row_base, out_col_off;
+} umoe_tn_group_t;
+typedef struct {
+    const umoe_tn_group_t* groups;   /* HOST array, num_groups <= 12 */
+    int num_groups;
+    const uint16_t* p; int ldp;      /* [rows][ldp] bf16: its columns become output ROWS */
+    const uint16_t* q; int ldq;      /* [rows][ldq] bf16: its columns become output COLUMNS */
+    void* out; int ldo;              /* bf16 [*, ldo] */
+    int k_split;                     /* 0 / 1: none */
+    void* ws; long part_stride;      /* k_split > 1: fp32 workspace of k_split * part_stride floats, part_stride = rows * ldo of the output */
+} umoe_tgemm_tn_args;
+size_t umoe_tiled_gemm_tn_workspace_bytes(const umoe_tgemm_tn_args* a);
+int umoe_tiled_gemm_tn(const umoe_tgemm_tn_args* a, umoe_stream_t stream);
+
 /* Named wrappers required by the scope table; thin calls of umoe_grouped_gemm.
  * umoe_grouped_swiglu_fwd: routed experts, core.py:406-416 + :34-49 on ragged rows.
  * umoe_shared_swiglu_fwd : shared experts, core.py:344-351 + :16-31. */

@@ -80,7 +80,7 @@ def test_ctypes_mirrors_have_the_size_and_offsets_of_the_c_structs(tmp_path):
     import subprocess
     from unimoe_audio_amd import _lib as L
     pairs = L.STRUCT_MIRRORS
-    assert len(pairs) == 14
+    assert len(pairs) == 16
     for cname, cls in pairs.items():                       # the built library agrees too (checked again at every load)
         assert int(L.lib().umoe_struct_size(cname.encode())) == C.sizeof(cls), cname
     assert int(L.lib().umoe_struct_size(b"no_such_struct")) == 0

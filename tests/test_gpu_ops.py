@@ -68,6 +68,69 @@ def test_tiled_gemm_plain_bias_resid_f32(dev, S, K, N):
         assert (y4.float() - y.float()).abs().max() <= 2 ** -6 * ref.abs().max()
 
 
+@pytest.mark.parametrize("T,M,N,G,ksplit", [(6240, 2560, 2048, 1, 1),       # dense weight gradient (QKV), full training width
+                                            (1000, 264, 520, 1, 1),        # ragged last tiles, K tail (1000 = 31 * 32 + 8)
+                                            (31, 256, 256, 1, 1),          # fewer rows than one K tile
+                                            (4099, 1376, 2048, 2, 1),      # two static groups with windows of their own
+                                            (6240, 2048, 2048, 1, 3),      # K split with the fixed-order fp32 reduction
+                                            (5000, 528, 264, 1, 4)])
+def test_tiled_gemm_tn_static_windows(dev, T, M, N, G, ksplit):
+    """umoe_tiled_gemm_tn: out[m][n] = sum_k P[k][m] Q[k][n] straight from row-major activations (transposing LDS reads) against an fp32
+    torch reference, and BIT-IDENTICAL to umoe_tiled_gemm over transposed copies when the window is not split (same K tiles of 32 rows in
+    the same order; inside a tile the MFMA adds the same 32 products)."""
+    from unimoe_audio_amd import ops
+    g = torch.Generator().manual_seed(T + M + N)
+    Pm = (torch.randn(G * T, M + 16, generator=g) * 0.5).to(torch.bfloat16).to(dev)     # operands are column windows of wider buffers
+    Qm = (torch.randn(G * T, N + 8, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    out = torch.full((G * M, N), 7.0, dtype=torch.bfloat16, device=dev)
+    groups = [dict(m=M, n=N, p_col_off=8, q_col_off=8, k_off=i * T, k=T, out_row_base=i * M) for i in range(G)]
+    ops.tiled_gemm_tn(groups, Pm, Qm, out, k_split=ksplit)
+    for i in range(G):
+        Pg, Qg = Pm[i * T:(i + 1) * T, 8:8 + M], Qm[i * T:(i + 1) * T, 8:8 + N]
+        ref = Pg.float().t() @ Qg.float()
+        got = out[i * M:(i + 1) * M].float()
+        scale = float(ref.abs().max())
+        assert (got - ref).abs().max() <= 2 ** -7 * scale + 1e-3, (i, float((got - ref).abs().max()), scale)
+        if ksplit == 1 and T % 8 == 0:
+            nt = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.tiled_gemm([dict(w=ops.transpose(Qg.contiguous()), static_count=M)], ops.transpose(Pg.contiguous()), nt, max_rows=M)
+            if M >= 1024 and (M // 256) * (N // 256) >= 128:       # the 256 x 256 ping-pong kernel ran: same tiles, same order
+                assert torch.equal(nt, out[i * M:(i + 1) * M])
+            else:
+                assert (nt.float() - got).abs().max() <= 2 ** -7 * scale + 1e-3
+
+
+@pytest.mark.parametrize("E,D,I,counts", [(8, 2048, 2752, [2700, 0, 3111, 8, 1, 2999, 4096, 2048]),
+                                          (3, 512, 264, [40, 300, 31])])
+def test_tiled_gemm_tn_expert_windows_on_device(dev, E, D, I, counts):
+    """The routed experts' weight gradients as ONE grouped launch: per-expert slot windows (offset, count) read on the device, an expert
+    without tokens gets zeros, the rows behind a window are never read (they hold NaN here)."""
+    from unimoe_audio_amd import ops
+    g = torch.Generator().manual_seed(E * 31 + D)
+    offs, tot = [], 0
+    for c in counts:
+        offs.append(tot)
+        tot += (c + 7) & ~7                                  # 8-aligned slot ranges (umoe_dispatch_build_aligned)
+    dgu = (torch.randn(tot, 2 * I, generator=g) * 0.5).to(torch.bfloat16)
+    xe = (torch.randn(tot, D, generator=g) * 0.5).to(torch.bfloat16)
+    for c, o in zip(counts, offs):                           # padding rows of a slot range
+        dgu[o + c:o + ((c + 7) & ~7)] = float("nan")
+        xe[o + c:o + ((c + 7) & ~7)] = float("nan")
+    dgu_d, xe_d = dgu.to(dev), xe.to(dev)
+    cnt = torch.tensor(counts, dtype=torch.int32, device=dev)
+    off = torch.tensor(offs, dtype=torch.int32, device=dev)
+    for half in (0, 1):                                      # gate / up halves of (dG | dU)
+        out = torch.full((E, I, D), 3.0, dtype=torch.bfloat16, device=dev)
+        groups = [dict(m=I, n=D, p_col_off=half * I, k_off_dev=off[e:e + 1], k_count_dev=cnt[e:e + 1], out_row_base=e * I) for e in range(E)]
+        ops.tiled_gemm_tn(groups, dgu_d, xe_d, out.view(E * I, D))
+        for e in range(E):
+            c, o = counts[e], offs[e]
+            ref = dgu[o:o + c, half * I:(half + 1) * I].float().t() @ xe[o:o + c].float()
+            got = out[e].float().cpu()
+            assert torch.isfinite(got).all()
+            assert (got - ref).abs().max() <= 2 ** -7 * float(ref.abs().max()) + 1e-3, (half, e)
+
+
 @pytest.mark.parametrize("S,D,I,E,p_sel", [(700, 256, 352, 4, 0.4),
                                            (2600, 512, 1024, 8, 0.25)])   # 704 / 176 tiles of 256 x 256: ping-pong variant, ragged order
 def test_tiled_gemm_ragged_swiglu_groups(dev, S, D, I, E, p_sel):

@@ -60,6 +60,16 @@ class TGemmArgs(C.Structure):
                 ("ldo", i32), ("epilogue", i32), ("aux_out", vp), ("ld_aux", i32)]
 
 
+class TnGroup(C.Structure):
+    _fields_ = [("p", vp), ("ldp", i32), ("q", vp), ("ldq", i32), ("out", vp), ("p_col_off", i32), ("q_col_off", i32), ("m", i32), ("n", i32),
+                ("k_off", i32), ("k", i32), ("k_off_dev", vp), ("k_count_dev", vp), ("out_row_base", i32), ("out_col_off", i32)]
+
+
+class TGemmTnArgs(C.Structure):
+    _fields_ = [("groups", vp), ("num_groups", i32), ("p", vp), ("ldp", i32), ("q", vp), ("ldq", i32), ("out", vp), ("ldo", i32),
+                ("k_split", i32), ("ws", vp), ("part_stride", C.c_long)]
+
+
 class SwigluBwdArgs(C.Structure):
     _fields_ = [("num_groups", i32), ("w_gate", C.POINTER(vp)), ("w_up", C.POINTER(vp)), ("w_down", C.POINTER(vp)), ("D", i32), ("I", i32),
                 ("counts", vp), ("offsets", vp), ("slot_token", vp), ("max_rows", i32), ("slot_rows", i32), ("row_base", i32),
@@ -129,7 +139,7 @@ EXPORTS = [
     "umoe_codec_embed_sum", "umoe_codec_embed_sum_bwd", "umoe_mul_noise", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_codec_ce_fwd", "umoe_codec_ce_bwd", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
     "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
-    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm", "umoe_dispatch_build_aligned", "umoe_transpose_slots", "umoe_swiglu_bwd",
+    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm", "umoe_tiled_gemm_tn", "umoe_tiled_gemm_tn_workspace_bytes", "umoe_dispatch_build_aligned", "umoe_transpose_slots", "umoe_swiglu_bwd",
     "umoe_unpermute_combine_bwd", "umoe_permute_bwd", "umoe_router_bwd", "umoe_rmsnorm_residual_bwd", "umoe_aux_loss_bwd", "umoe_attn_softmax_fwd", "umoe_attn_softmax_bwd", "umoe_qkv_mrope_bwd",
     "umoe_swiglu_bwd_workspace_bytes", "umoe_grouped_swiglu_bwd", "umoe_shared_swiglu_bwd",
     "umoe_attn_prefill_bwd_workspace_bytes", "umoe_attn_prefill_bwd",
@@ -144,7 +154,7 @@ MAX_EP = 8
 
 def _mirrors():
     return {"umoe_router_args": RouterArgs, "umoe_group_t": Group, "umoe_gemm_args": GemmArgs, "umoe_tgroup_t": TGroup,
-            "umoe_tgemm_args": TGemmArgs, "umoe_swiglu_bwd_args": SwigluBwdArgs, "umoe_attn_bwd_args": AttnBwdArgs,
+            "umoe_tgemm_args": TGemmArgs, "umoe_tn_group_t": TnGroup, "umoe_tgemm_tn_args": TGemmTnArgs, "umoe_swiglu_bwd_args": SwigluBwdArgs, "umoe_attn_bwd_args": AttnBwdArgs,
             "umoe_combine_args": CombineArgs, "umoe_rope_args": RopeArgs, "umoe_attn_args": AttnArgs, "umoe_sample_args": SampleArgs,
             "umoe_engine_cfg": EngineCfg, "umoe_layer_weights": LayerWeights, "umoe_decode_io": DecodeIO}
 
@@ -199,6 +209,9 @@ def lib():
         L.umoe_attn_softmax_fwd.argtypes = [vp, i32, i32, i32, i32, i32, f32, vp, i32, vp]
         L.umoe_attn_softmax_bwd.argtypes = [vp, vp, i32, i32, i32, i32, f32, vp, vp]
         L.umoe_qkv_mrope_bwd.argtypes = [C.POINTER(RopeArgs), vp, vp, vp, vp, vp]
+        L.umoe_tiled_gemm_tn.argtypes = [C.POINTER(TGemmTnArgs), vp]
+        L.umoe_tiled_gemm_tn_workspace_bytes.argtypes = [C.POINTER(TGemmTnArgs)]
+        L.umoe_tiled_gemm_tn_workspace_bytes.restype = C.c_size_t
         L.umoe_swiglu_bwd_workspace_bytes.argtypes = [C.POINTER(SwigluBwdArgs)]
         L.umoe_swiglu_bwd_workspace_bytes.restype = C.c_size_t
         L.umoe_grouped_swiglu_bwd.argtypes = [C.POINTER(SwigluBwdArgs), vp]

@@ -17,7 +17,7 @@ extern "C" int umoe_abi_version(void) { return 1; }
 extern "C" size_t umoe_struct_size(const char* name) {
     if (!name) return 0;
 #define UMOE_SZ(t) if (!strcmp(name, #t)) return sizeof(t);
-    UMOE_SZ(umoe_router_args) UMOE_SZ(umoe_group_t) UMOE_SZ(umoe_gemm_args) UMOE_SZ(umoe_tgroup_t) UMOE_SZ(umoe_tgemm_args)
+    UMOE_SZ(umoe_router_args) UMOE_SZ(umoe_group_t) UMOE_SZ(umoe_gemm_args) UMOE_SZ(umoe_tgroup_t) UMOE_SZ(umoe_tgemm_args) UMOE_SZ(umoe_tn_group_t) UMOE_SZ(umoe_tgemm_tn_args)
     UMOE_SZ(umoe_swiglu_bwd_args) UMOE_SZ(umoe_attn_bwd_args) UMOE_SZ(umoe_combine_args) UMOE_SZ(umoe_rope_args) UMOE_SZ(umoe_attn_args)
     UMOE_SZ(umoe_sample_args) UMOE_SZ(umoe_engine_cfg) UMOE_SZ(umoe_layer_weights) UMOE_SZ(umoe_decode_io)
 #undef UMOE_SZ

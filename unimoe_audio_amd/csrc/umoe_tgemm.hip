@@ -808,6 +808,43 @@ extern "C" int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream) {
         if (g.n > max_n) max_n = g.n;
     }
     hipStream_t s = (hipStream_t)stream;
+#ifdef UMOE_TGTIME
+    // diagnostics build (make tg: libumoe_hip_tg.so) with UMOE_TGEMM_TIME=1: every call is timed on its own (events + synchronise) and
+    // printed with its shape
+    static int timed = -1;
+    if (timed < 0) timed = getenv("UMOE_TGEMM_TIME") ? 1 : 0;
+    static thread_local bool inside = false;
+    if (timed && !inside) {
+        inside = true;
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, s);
+        const int rc = umoe_tiled_gemm(a, stream);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        double flop = 0;
+        long rows_total = 0;
+        for (int i = 0; i < a->num_groups; ++i) {
+            const umoe_tgroup_t& g = a->groups[i];
+            int cnt = g.static_count, kk = g.k;
+            if (g.count) (void)hipMemcpy(&cnt, g.count, 4, hipMemcpyDeviceToHost);
+            if (g.k_count) (void)hipMemcpy(&kk, g.k_count, 4, hipMemcpyDeviceToHost);
+            rows_total += cnt;
+            flop += 2.0 * cnt * (double)g.n * kk * (a->epilogue == UMOE_EPI_SWIGLU ? 2 : 1);
+        }
+        const umoe_tgroup_t& g0 = a->groups[0];
+        fprintf(stderr, "TG epi=%d groups=%d max_rows=%d rows=%ld n=%d k=%d ragged=%d kwin=%d gather=%d pp=%d us=%.1f tflops=%.0f\n", a->epilogue, a->num_groups,
+                a->max_rows, rows_total, max_n, g0.k, g0.count != nullptr, g0.k_count != nullptr, g0.rows != nullptr, (int)tgemm_pp_pays(a, max_n), ms * 1e3,
+                flop / (ms * 1e-3) * 1e-12);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        inside = false;
+        return rc;
+    }
+#endif
     switch (a->epilogue) {
         case UMOE_EPI_BF16: return launch_tgemm<UMOE_EPI_BF16>(a, max_n, s);
         case UMOE_EPI_BF16_RESID:

@@ -1,0 +1,309 @@
+// Weight-gradient GEMM that contracts over the ROW index of both operands ("TN"), so dW = dY^T X runs on the activations as autograd holds
+// them -- no transposed copies (round 2: umoe_transpose_slots wrote dY^T, H^T, (dG|dU)^T and X^T of every layer first, 9 % of the step).
+//
+//   out_g[m][n] = sum over k in [k_off_g, k_off_g + k_count_g) of  P[k][p_col_off_g + m] * Q[k][q_col_off_g + n]      (bf16 in, fp32 sum)
+//
+// P, Q row-major with k (tokens / expert slots) as the row index.  Same tile, wave layout, LDS-DMA ring and barrier schedule as
+// tgemm_pp_kernel (umoe_tgemm.hip: 256 x 256 output tile, 8 waves in two groups one barrier apart, K tiles of 32, ring of 4 slots, the
+// DMA three tiles ahead, counted vmcnt) -- what differs is the LDS image and the operand read:
+//  * a unit is 32 k-rows x 256 columns (512-byte rows).  One global_load_lds_dwordx4 of a wave writes 1 KiB = two k-rows; a row PAIR is
+//    followed by 64 bytes of padding (pair stride 1088 B) and the 16-byte chunks of the odd row of a pair are stored with chunk index ^ 2
+//    (on the SOURCE address: the DMA writes linearly);
+//  * MFMA operands come out of the k-major image by ds_read_b64_tr_b16 (hardware transpose: per 16-lane group, lane 4q+p supplies the
+//    address of row q, columns 4p..4p+3; lane i receives column i of the four rows): two reads per 16x16x32 operand.  Lane group h takes
+//    rows 4h..4h+3 with the first read and 16+4h.. with the second, i.e. k-slot (h, e) of the MFMA is row 4h+e (e < 4) / 16+4h+e-4 -- the
+//    same for both operands, and a permutation of k inside a tile does not change the sum;
+//    a 32-lane half of the read then touches eight consecutive rows = four pairs whose 32-byte granules fall on bank groups
+//    {0,1}+2t (pad) with the XOR choosing inside the pair: every bank once.
+//  * the 16-column fragments of a wave are STRIDED over the tile (Q side: columns 16 (4j + wc), P side: 16 (2i + wr)) so that the XOR bit
+//    is a wave constant and every fragment is one base register + an immediate offset.
+// Results: the fp32 sums run over the same 32-row tiles in the same order as tgemm_pp_kernel over transposed copies, and inside a tile
+// the MFMA adds the same 32 products -- tests/test_gpu_ops.py compares the two bit for bit.
+// Roofline: MFMA (2.5 PFLOP/s dense bf16).
+#include "umoe_common.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+#define TN_MAXG 12
+struct tn_pack { umoe_tn_group_t g[TN_MAXG]; };
+__device__ __attribute__((aligned(16))) uint4 tn_zero16;
+typedef unsigned int tn_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int tn_u32x4 __attribute__((ext_vector_type(4)));
+
+// One MFMA operand = two transposing reads (rows 4h.. and 16 + 4h..: eight row pairs = 8 * 1088 bytes further).  Inline assembly, not
+// __builtin_amdgcn_ds_read_tr16_b64: hipcc (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of the builtin while an LDS-DMA is in flight (it
+// carries no memory operand, so the wait-count pass assumes it may read what the DMA writes) -- that drains the three-tile prefetch in
+// every phase.  The asm reads are invisible to that pass: the s_waitcnt lgkmcnt(0) + sched_barrier in front of the MFMAs are explicit.
+template <int OFF>
+__device__ __forceinline__ bf16x8_t tn_frag(const unsigned addr) {
+    tn_u32x2 a, b;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a) : "v"(addr), "n"(OFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b) : "v"(addr), "n"(OFF + 8 * 1088));
+    return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(a, b, 0, 1, 2, 3));
+}
+template <int N, int STEP, int OFF0>
+__device__ __forceinline__ void tn_frags(bf16x8_t (&f)[N], const unsigned addr) {
+    if constexpr (N >= 1) f[0] = tn_frag<OFF0>(addr);
+    if constexpr (N >= 2) f[1] = tn_frag<OFF0 + STEP>(addr);
+    if constexpr (N >= 3) f[2] = tn_frag<OFF0 + 2 * STEP>(addr);
+    if constexpr (N >= 4) f[3] = tn_frag<OFF0 + 3 * STEP>(addr);
+}
+
+template <int NS, bool F32OUT>
+__global__ __launch_bounds__(512, 2) void tgemm_tn_kernel(const umoe_tgemm_tn_args p, const tn_pack gp, const int nx, const int ny, const int nz, const int ragged_order,
+                                                           const unsigned total_wgs, const int ksplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PAIR = 1088, UNIT = 16 * PAIR, SLOT = 2 * UNIT;
+    constexpr int AH = NS - 1;
+    // XCD-aware tile order as in tgemm_pp_kernel (1-D launch, lin % 8 = the workgroup's XCD)
+    int bx, by, bz;
+    {
+        const unsigned lin = blockIdx.x, xcd = lin & 7, seq = lin >> 3;
+        if (ragged_order) {
+            const unsigned rr = seq / (unsigned)nx;
+            bx = (int)(seq - rr * (unsigned)nx);
+            const unsigned RR = rr * 8 + xcd;
+            if (RR >= (unsigned)(ny * nz)) return;
+            bz = (int)(RR / (unsigned)ny);
+            by = (int)(RR - (unsigned)bz * (unsigned)ny);
+        } else {
+            const unsigned nwg = total_wgs, q = nwg >> 3, r = nwg & 7;
+            const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
+            bx = (int)(id % (unsigned)nx);
+            const unsigned RR = id / (unsigned)nx;
+            bz = (int)(RR / (unsigned)ny);
+            by = (int)(RR - (unsigned)bz * (unsigned)ny);
+        }
+    }
+    // K split (static groups that would not fill the chip): z index = group * ksplit + part, part takes K tiles [part * per, ...)
+    const int part = bz % ksplit;
+    const umoe_tn_group_t g = gp.g[bz / ksplit];
+    const int m0 = by * 256, n0 = bx * 256;
+    if (m0 >= g.m || n0 >= g.n) return;
+    int koff = g.k_off_dev ? *g.k_off_dev : g.k_off;
+    int K = g.k_count_dev ? *g.k_count_dev : g.k;
+    if (ksplit > 1) {
+        const int per = (((K + 31) >> 5) + ksplit - 1) / ksplit * 32;      // whole 32-row tiles per part
+        const int lo = part * per;
+        const int hi = lo + per < K ? lo + per : K;
+        koff += lo;
+        K = hi > lo ? hi - lo : 0;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- LDS-DMA sources: this wave stages the row pairs `wave` and `wave + 8` of every unit
+    const char* zero = reinterpret_cast<const char*>(&tn_zero16);
+    const int rodd = lane >> 5;
+    const int cl = (lane & 31) ^ (rodd << 1);               // logical 16-byte chunk (8 columns) this lane fetches
+    const uint16_t* Pb = g.p ? g.p : p.p;
+    const uint16_t* Qb = g.q ? g.q : p.q;
+    const long ldp = g.p ? g.ldp : p.ldp, ldq = g.q ? g.ldq : p.ldq;
+    long pdel[2], qdel[2];
+    int rrow[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        rrow[q] = 2 * (wave + 8 * q) + rodd;
+        const int mc = m0 + 8 * cl, nc = n0 + 8 * cl;
+        pdel[q] = mc < g.m ? reinterpret_cast<const char*>(Pb + (long)(koff + rrow[q]) * ldp + g.p_col_off + mc) - zero : 0;
+        qdel[q] = nc < g.n ? reinterpret_cast<const char*>(Qb + (long)(koff + rrow[q]) * ldq + g.q_col_off + nc) - zero : 0;
+    }
+    const long pstep = 64 * ldp, qstep = 64 * ldq;          // bytes per K tile (32 rows)
+    auto stage = [&](const long (&del)[2], const long step, const int unit_off, const int tile) {
+        char* base = smem + (tile % NS) * SLOT + unit_off;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const long live = (tile * 32 + rrow[q] < K) ? -1L : 0L;       // rows behind the window read zeros (also the tiles staged past the end)
+            const long d = del[q] == 0 ? 0 : ((del[q] + (long)tile * step) & live);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(zero + d),
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * q) * PAIR), 16, 0, 0);
+        }
+    };
+    const char* pptr[2];
+    const char* qptr[2];
+    long pinc[2], qinc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        pinc[q] = pdel[q] ? pstep : 0;
+        qinc[q] = qdel[q] ? qstep : 0;
+        pptr[q] = zero + pdel[q] + AH * pinc[q];
+        qptr[q] = zero + qdel[q] + AH * qinc[q];
+    }
+    auto stage_run = [&](const char* (&ptr)[2], const long (&inc)[2], const int unit_off, const int slot_off) {
+        char* base = smem + slot_off + unit_off;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr[q],
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * q) * PAIR), 16, 0, 0);
+            ptr[q] += inc[q];
+        }
+    };
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // operand reads: lane (h, 4 rq + rp) supplies row 4h + rq, columns 4 rp .. 4 rp + 3 of the fragment
+    const int h = lane >> 4, c16 = lane & 15, rq = c16 >> 2, rp = c16 & 3;
+    const int rowoff = (2 * h + (rq >> 1)) * PAIR + (rq & 1) * 512 + (rp & 1) * 8;
+    const int qbase = rowoff + (((2 * wc + (rp >> 1)) ^ ((rq & 1) << 1)) << 4);                // fragment j: + 128 j
+    const int pbase = UNIT + rowoff + (((2 * wr + (rp >> 1)) ^ ((rq & 1) << 1)) << 4);         // fragment i: + 64 i
+
+    const unsigned lds0 = (unsigned)reinterpret_cast<size_t>(smem);      // LDS byte offset of the ring (low half of the generic pointer)
+    const int KT = (K + 31) >> 5;
+#pragma unroll
+    for (int u = 0; u < AH; ++u) {
+        stage(qdel, qstep, 0, u);
+        stage(pdel, pstep, UNIT, u);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind group 0 from here on
+    auto tile_step = [&](const int v, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int so = (v % NS) * SLOT;
+        const int sn = ((v + AH) % NS) * SLOT;
+        const unsigned Qf = lds0 + so + qbase;
+        const unsigned Pf = lds0 + so + pbase;
+        bf16x8_t wf[4], af[4];
+        // ---- phase 2v: Q fragments + first half of the P fragments; stage Q(v + AH)
+        tn_frags<4, 128, 0>(wf, Qf);
+        tn_frags<4, 64, 0>(af, Pf);
+        if (STEADY) stage_run(qptr, qinc, 0, sn);
+        else stage(qdel, qstep, 0, v + AH);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2v + 1: second half of the P fragments; stage P(v + AH); tile v + 1 has landed after the wait
+        tn_frags<4, 64, 256>(af, Pf);
+        if (STEADY) stage_run(pptr, pinc, UNIT, sn);
+        else stage(pdel, pstep, UNIT, v + AH);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    const int v_steady = KT - (AH + 1) > 0 ? KT - (AH + 1) : 0;
+    int v = 0;
+    for (; v < v_steady; ++v) tile_step(v, std::true_type{});
+    for (; v < KT; ++v) tile_step(v, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-tile DMAs of the last iterations must not outlive the workgroup
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- store: lane holds 4 consecutive output columns (n) of one output row (m)
+    const long orow_base = (long)g.out_row_base + m0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = 16 * (2 * i + wr) + c16;
+        if (m0 + r >= g.m) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + 16 * (4 * j + wc) + 4 * h;
+            if (col >= g.n) continue;
+            if constexpr (F32OUT) {
+                float* o = reinterpret_cast<float*>(g.out ? g.out : p.out) + (size_t)part * p.part_stride + (orow_base + r) * (long)p.ldo + g.out_col_off + col;
+                *reinterpret_cast<float4*>(o) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+            } else {
+                uint16_t* o = reinterpret_cast<uint16_t*>(g.out ? g.out : p.out) + (orow_base + r) * (long)p.ldo + g.out_col_off + col;
+                *reinterpret_cast<uint2*>(o) = make_uint2((uint32_t)f2bf(acc[j][i][0]) | ((uint32_t)f2bf(acc[j][i][1]) << 16),
+                                                          (uint32_t)f2bf(acc[j][i][2]) | ((uint32_t)f2bf(acc[j][i][3]) << 16));
+            }
+        }
+    }
+}
+
+// fixed-order sum of the K-split partials: out = bf16(part 0 + part 1 + ...)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ parts, const long part_stride, const int nparts, const long n4, uint16_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = reinterpret_cast<const float4*>(parts)[i];
+    for (int k = 1; k < nparts; ++k) {
+        const float4 t = reinterpret_cast<const float4*>(parts + (size_t)k * part_stride)[i];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    reinterpret_cast<uint2*>(out)[i] = make_uint2((uint32_t)f2bf(s.x) | ((uint32_t)f2bf(s.y) << 16), (uint32_t)f2bf(s.z) | ((uint32_t)f2bf(s.w) << 16));
+}
+
+template <bool F32OUT>
+static int launch_tn(const umoe_tgemm_tn_args* a, int max_m, int max_n, int ragged, int ksplit, hipStream_t s) {
+    constexpr int NS = 4;
+    constexpr int lds = NS * 2 * 16 * 1088;
+    tn_pack gp;
+    memset(&gp, 0, sizeof(gp));
+    memcpy(gp.g, a->groups, sizeof(umoe_tn_group_t) * a->num_groups);
+    static bool configured = false;
+    if (!configured) {
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_tn_kernel<NS, F32OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    const int nx = ceil_div(max_n, 256), ny = ceil_div(max_m, 256), nz = a->num_groups * ksplit;
+    const long nwg = ragged ? (long)nx * (((long)ny * nz + 7) & ~7L) : (long)nx * ny * nz;
+    UMOE_REQUIRE(nwg < (1L << 31), "umoe_tiled_gemm_tn: too many tiles (%ld)", nwg);
+    tgemm_tn_kernel<NS, F32OUT><<<dim3((unsigned)nwg), 512, lds, s>>>(*a, gp, nx, ny, nz, ragged, (unsigned)nwg, ksplit);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t umoe_tiled_gemm_tn_workspace_bytes(const umoe_tgemm_tn_args* a) {
+    if (!a || a->k_split <= 1) return 0;
+    return (size_t)a->k_split * (size_t)a->part_stride * sizeof(float);
+}
+
+extern "C" int umoe_tiled_gemm_tn(const umoe_tgemm_tn_args* a, umoe_stream_t stream) {
+    UMOE_REQUIRE(a && a->groups && a->out, "umoe_tiled_gemm_tn: null argument");
+    UMOE_REQUIRE(a->num_groups > 0 && a->num_groups <= TN_MAXG, "umoe_tiled_gemm_tn: 1..%d groups per launch (got %d)", TN_MAXG, a->num_groups);
+    UMOE_REQUIRE((a->ldo & 3) == 0, "umoe_tiled_gemm_tn: ldo must be a multiple of 4");
+    int max_m = 0, max_n = 0, ragged = 0;
+    for (int i = 0; i < a->num_groups; ++i) {
+        const umoe_tn_group_t& g = a->groups[i];
+        const uint16_t* P = g.p ? g.p : a->p;
+        const uint16_t* Q = g.q ? g.q : a->q;
+        const int ldp = g.p ? g.ldp : a->ldp, ldq = g.q ? g.ldq : a->ldq;
+        UMOE_REQUIRE(P && Q && ldp % 8 == 0 && ldq % 8 == 0 && (reinterpret_cast<size_t>(P) & 15) == 0 && (reinterpret_cast<size_t>(Q) & 15) == 0,
+                     "umoe_tiled_gemm_tn: group %d: operands must be 16-byte aligned with leading dimensions that are multiples of 8", i);
+        UMOE_REQUIRE(g.m > 0 && g.n > 0 && g.m % 8 == 0 && g.n % 8 == 0 && g.p_col_off % 8 == 0 && g.q_col_off % 8 == 0 && (g.out_col_off & 3) == 0,
+                     "umoe_tiled_gemm_tn: group %d: m, n, column offsets must be multiples of 8 (m=%d n=%d)", i, g.m, g.n);
+        UMOE_REQUIRE((g.k_off_dev == nullptr) == (g.k_count_dev == nullptr), "umoe_tiled_gemm_tn: group %d: k_off_dev and k_count_dev come together", i);
+        UMOE_REQUIRE(g.k_count_dev || (g.k >= 0 && g.k_off >= 0), "umoe_tiled_gemm_tn: group %d: bad static window", i);
+        if (g.m > max_m) max_m = g.m;
+        if (g.n > max_n) max_n = g.n;
+        ragged |= g.k_count_dev != nullptr && a->num_groups > 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int ks = a->k_split > 1 ? a->k_split : 1;
+    if (ks == 1) return launch_tn<false>(a, max_m, max_n, ragged, 1, s);
+    // K split: fp32 partial slabs [k_split][part_stride] in the caller's workspace, summed in fixed order
+    UMOE_REQUIRE(a->ws && ks <= 16, "umoe_tiled_gemm_tn: k_split needs a workspace (umoe_tiled_gemm_tn_workspace_bytes), k_split <= 16");
+    UMOE_REQUIRE(a->part_stride % 4 == 0 && (reinterpret_cast<size_t>(a->ws) & 15) == 0, "umoe_tiled_gemm_tn: part_stride %% 4, 16-byte aligned workspace");
+    umoe_tgemm_tn_args b = *a;
+    umoe_tn_group_t gs[TN_MAXG];
+    memcpy(gs, a->groups, sizeof(umoe_tn_group_t) * a->num_groups);
+    for (int i = 0; i < a->num_groups; ++i) {
+        UMOE_REQUIRE(!gs[i].out, "umoe_tiled_gemm_tn: k_split with per-group output pointers is not supported");
+        UMOE_REQUIRE(((long)gs[i].out_row_base + gs[i].m) * (long)a->ldo <= a->part_stride, "umoe_tiled_gemm_tn: part_stride smaller than the output");
+    }
+    b.groups = gs;
+    b.out = a->ws;
+    if (int rc = launch_tn<true>(&b, max_m, max_n, 0, ks, s)) return rc;
+    const long n4 = a->part_stride / 4;
+    tn_reduce_kernel<<<dim3((unsigned)((n4 + 255) / 256)), 256, 0, s>>>(reinterpret_cast<const float*>(a->ws), a->part_stride, ks, n4, reinterpret_cast<uint16_t*>(a->out));
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}

@@ -447,6 +447,37 @@ def tiled_gemm(groups: Sequence[dict], a: torch.Tensor, out: torch.Tensor, *, ma
     return out
 
 
+def tiled_gemm_tn(groups: Sequence[dict], p: torch.Tensor, q: torch.Tensor, out: torch.Tensor, *, k_split: int = 1):
+    """out_g[m][n] = sum_k p[k][p_col_off + m] * q[k][q_col_off + n] over the group's row window (umoe_tiled_gemm_tn): the weight-gradient
+    product dW = dY^T X on row-major activations, no transposed copies.  Group dict: m, n, optional p / q / out tensors of its own,
+    p_col_off, q_col_off, k_off + k (static window) or k_off_dev + k_count_dev (int32 device scalars), out_row_base, out_col_off."""
+    arr = (L.TnGroup * len(groups))()
+    keep = []
+    for i, g in enumerate(groups):
+        for k in ("p", "q"):
+            t = g.get(k)
+            if t is not None:
+                keep.append(t)
+                setattr(arr[i], k, t.data_ptr())
+                setattr(arr[i], "ld" + k, t.stride(0))
+        for k in ("out", "k_off_dev", "k_count_dev"):
+            t = g.get(k)
+            if t is not None:
+                keep.append(t)
+                setattr(arr[i], k, t.data_ptr())
+        for k in ("p_col_off", "q_col_off", "m", "n", "k_off", "k", "out_row_base", "out_col_off"):
+            setattr(arr[i], k, int(g.get(k, 0)))
+    args = L.TGemmTnArgs(groups=C.cast(arr, C.c_void_p), num_groups=len(groups), p=_pv(p), ldp=p.stride(0), q=_pv(q), ldq=q.stride(0),
+                         out=_pv(out), ldo=out.stride(-2), k_split=k_split)
+    ws = None
+    if k_split > 1:
+        args.part_stride = out.numel()
+        ws = torch.empty(L.lib().umoe_tiled_gemm_tn_workspace_bytes(C.byref(args)), dtype=torch.uint8, device=out.device)
+        args.ws = ws.data_ptr()
+    L.check(L.lib().umoe_tiled_gemm_tn(C.byref(args), _stream()), "umoe_tiled_gemm_tn")
+    return out
+
+
 def tlinear(x: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, resid=None, out_f32=False) -> torch.Tensor:
     """y = x @ w^T (+bias) (+resid) with row-major w [N, K]: the tiled MFMA path for many rows."""
     S = x.shape[0]
