@@ -266,13 +266,13 @@ typedef struct {
     int out_row_base, out_col_off;
 } umoe_tn_group_t;
 typedef struct {
-    const umoe_tn_group_t* groups;   /* HOST array, num_groups <= 12 */
+    const umoe_tn_group_t* groups;   /* HOST array, num_groups <= 24 */
     int num_groups;
     const uint16_t* p; int ldp;      /* [rows][ldp] bf16: its columns become output ROWS */
     const uint16_t* q; int ldq;      /* [rows][ldq] bf16: its columns become output COLUMNS */
     void* out; int ldo;              /* bf16 [*, ldo] */
-    int k_split;                     /* 0 / 1: none */
-    void* ws; long part_stride;      /* k_split > 1: fp32 workspace of k_split * part_stride floats, part_stride = rows * ldo of the output */
+    int k_split;                     /* 0 / 1: none; > 1: that many parts; < 0: chosen by the library (1..8, from the tile count and K) */
+    void* ws; long part_stride;      /* k_split > 1 or < 0: fp32 workspace (umoe_tiled_gemm_tn_workspace_bytes), part_stride = rows * ldo of the output */
 } umoe_tgemm_tn_args;
 size_t umoe_tiled_gemm_tn_workspace_bytes(const umoe_tgemm_tn_args* a);
 int umoe_tiled_gemm_tn(const umoe_tgemm_tn_args* a, umoe_stream_t stream);

@@ -73,14 +73,16 @@ def test_tiled_gemm_plain_bias_resid_f32(dev, S, K, N):
                                             (31, 256, 256, 1, 1),          # fewer rows than one K tile
                                             (4099, 1376, 2048, 2, 1),      # two static groups with windows of their own
                                             (6240, 2048, 2048, 1, 3),      # K split with the fixed-order fp32 reduction
-                                            (5000, 528, 264, 1, 4)])
+                                            (5000, 528, 264, 1, 4),
+                                            (520, 2816, 3072, 1, 1),       # 132 tiles: the transposed-copy path runs the 256 x 256 kernel too
+                                            (1304, 12324, 256, 1, -1)])    # m not a multiple of 8 (codec head), split chosen by the library
 def test_tiled_gemm_tn_static_windows(dev, T, M, N, G, ksplit):
     """umoe_tiled_gemm_tn: out[m][n] = sum_k P[k][m] Q[k][n] straight from row-major activations (transposing LDS reads) against an fp32
     torch reference, and BIT-IDENTICAL to umoe_tiled_gemm over transposed copies when the window is not split (same K tiles of 32 rows in
     the same order; inside a tile the MFMA adds the same 32 products)."""
     from unimoe_audio_amd import ops
     g = torch.Generator().manual_seed(T + M + N)
-    Pm = (torch.randn(G * T, M + 16, generator=g) * 0.5).to(torch.bfloat16).to(dev)     # operands are column windows of wider buffers
+    Pm = (torch.randn(G * T, ((M + 7) & ~7) + 16, generator=g) * 0.5).to(torch.bfloat16).to(dev)     # operands are column windows of wider buffers
     Qm = (torch.randn(G * T, N + 8, generator=g) * 0.5).to(torch.bfloat16).to(dev)
     out = torch.full((G * M, N), 7.0, dtype=torch.bfloat16, device=dev)
     groups = [dict(m=M, n=N, p_col_off=8, q_col_off=8, k_off=i * T, k=T, out_row_base=i * M) for i in range(G)]
@@ -91,10 +93,10 @@ def test_tiled_gemm_tn_static_windows(dev, T, M, N, G, ksplit):
         got = out[i * M:(i + 1) * M].float()
         scale = float(ref.abs().max())
         assert (got - ref).abs().max() <= 2 ** -7 * scale + 1e-3, (i, float((got - ref).abs().max()), scale)
-        if ksplit == 1 and T % 8 == 0:
+        if ksplit == 1 and T % 8 == 0 and M % 8 == 0:
             nt = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             ops.tiled_gemm([dict(w=ops.transpose(Qg.contiguous()), static_count=M)], ops.transpose(Pg.contiguous()), nt, max_rows=M)
-            if M >= 1024 and (M // 256) * (N // 256) >= 128:       # the 256 x 256 ping-pong kernel ran: same tiles, same order
+            if M >= 1024 and -(-M // 256) * -(-N // 256) >= 128:   # the 256 x 256 ping-pong kernel ran: same K tiles, same k slots
                 assert torch.equal(nt, out[i * M:(i + 1) * M])
             else:
                 assert (nt.float() - got).abs().max() <= 2 ** -7 * scale + 1e-3

@@ -909,28 +909,36 @@ inline int r8(int n) { return (n + 7) & ~7; }
 
 // layout of the workspace of umoe_grouped_swiglu_bwd / umoe_shared_swiglu_bwd (sizes in bf16 elements)
 static size_t swiglu_bwd_carve(const umoe_swiglu_bwd_args* a, void* ws, size_t cap, uint16_t** wdT, uint16_t** wguT, uint16_t** dh,
-                               uint16_t** dgu, uint16_t** dyT, uint16_t** hT, uint16_t** dguT, uint16_t** xeT, int* ldT_out) {
+                               uint16_t** dgu, uint16_t** xe, float** tn_ws) {
     WsCarver k(ws, cap);
     const int G = a->num_groups, D = a->D, I = a->I;
-    // transposed buffers: ragged groups keep the slot index as column; static groups get private 8-aligned column ranges
-    const int ldT = a->counts ? r8(a->slot_rows) : G * r8(a->max_rows);
     *wdT = k.take<uint16_t>((size_t)G * I * r8(D));        // per group [I][r8(D)]
     *wguT = k.take<uint16_t>((size_t)G * D * 2 * I);       // per group [D][2I]
     *dh = k.take<uint16_t>((size_t)a->slot_rows * I);
     *dgu = k.take<uint16_t>((size_t)a->slot_rows * 2 * I);
-    *dyT = k.take<uint16_t>((size_t)D * ldT);
-    *hT = k.take<uint16_t>((size_t)I * ldT);
-    *dguT = k.take<uint16_t>((size_t)2 * I * ldT);
-    *xeT = k.take<uint16_t>((size_t)D * ldT);
-    *ldT_out = ldT;
+    // routed experts: the gathered input rows in slot order (the weight-gradient product reads its operands by row window);
+    // shared experts: fp32 partial outputs of the K-split weight-gradient products (up to 8 parts of the (dWg | dWu) slab)
+    *xe = a->counts ? k.take<uint16_t>((size_t)a->slot_rows * D) : nullptr;
+    *tn_ws = a->counts ? nullptr : k.take<float>((size_t)8 * 2 * G * I * D);
     return (k.off + 255) & ~(size_t)255;
 }
 
 extern "C" size_t umoe_swiglu_bwd_workspace_bytes(const umoe_swiglu_bwd_args* a) {
     if (!a) return 0;
-    uint16_t *p0, *p1, *p2, *p3, *p4, *p5, *p6, *p7;
-    int ldT;
-    return swiglu_bwd_carve(a, nullptr, 0, &p0, &p1, &p2, &p3, &p4, &p5, &p6, &p7, &ldT);
+    uint16_t *p0, *p1, *p2, *p3, *p4;
+    float* p5;
+    return swiglu_bwd_carve(a, nullptr, 0, &p0, &p1, &p2, &p3, &p4, &p5);
+}
+
+// xe[off_g + r] = x[slot_token[off_g + r]], r < counts[g]: the routed experts' input rows in slot order (rows behind a count are never read)
+__global__ __launch_bounds__(256) void gather_slots_kernel(const uint16_t* __restrict__ x, const int ldx, const int D, const int32_t* __restrict__ slot_token,
+                                                           const int32_t* __restrict__ counts, const int32_t* __restrict__ offsets, uint16_t* __restrict__ out) {
+    const int g = blockIdx.y, cnt = counts[g], off = offsets[g];
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < cnt; r += gridDim.x * 4) {
+        const uint16_t* src = x + (size_t)slot_token[off + r] * ldx;
+        uint16_t* dst = out + (size_t)(off + r) * D;
+        for (int c = threadIdx.x & 63; c < (D >> 3); c += 64) st16(dst + c * 8, ld16(src + c * 8));
+    }
 }
 
 // backward of down(silu(gate x) * up x) over groups of rows (core.py:16-49,406-416):
@@ -944,9 +952,9 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     UMOE_REQUIRE(a->D % 8 == 0 && a->I % 8 == 0 && a->max_rows > 0 && a->slot_rows > 0, "umoe_*_swiglu_bwd: D and I must be multiples of 8");
     UMOE_REQUIRE((a->counts == nullptr) == (a->offsets == nullptr), "umoe_*_swiglu_bwd: counts and offsets come together");
     const bool ragged = a->counts != nullptr;
-    uint16_t *wdT, *wguT, *dh, *dgu, *dyT, *hT, *dguT, *xeT;
-    int ldT;
-    const size_t need = swiglu_bwd_carve(a, a->ws, a->ws_bytes, &wdT, &wguT, &dh, &dgu, &dyT, &hT, &dguT, &xeT, &ldT);
+    uint16_t *wdT, *wguT, *dh, *dgu, *xe;
+    float* tn_ws;
+    const size_t need = swiglu_bwd_carve(a, a->ws, a->ws_bytes, &wdT, &wguT, &dh, &dgu, &xe, &tn_ws);
     UMOE_REQUIRE(a->ws_bytes >= need, "umoe_*_swiglu_bwd: workspace too small (%zu < %zu bytes)", a->ws_bytes, need);
     const int G = a->num_groups, D = a->D, I = a->I, S = a->max_rows;
     int rc;
@@ -992,67 +1000,68 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     ta = umoe_tgemm_args{};
     ta.groups = tg; ta.num_groups = G; ta.max_rows = S; ta.a = dgu; ta.lda = 2 * I; ta.out = a->dx_slots; ta.ldo = a->lddx; ta.epilogue = UMOE_EPI_BF16;
     if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
-    // transposed slot buffers for the weight gradients
-    const int Sp = r8(S);
-    auto slots_t = [&](const uint16_t* src, int ld, int C, uint16_t* dst) -> int {
-        if (ragged) return umoe_transpose_slots_compact(src, ld, C, nullptr, a->counts, a->offsets, G, S, dst, stream);   // per-expert blocks
-        for (int g = 0; g < G; ++g) {
-            const size_t r0 = (size_t)a->row_base + (size_t)g * S;
-            if (int rc2 = umoe_transpose_slots(src + r0 * ld, ld, C, nullptr, nullptr, nullptr, 1, S, dst + (size_t)g * Sp, ldT, stream)) return rc2;
-        }
-        return 0;
-    };
-    if ((rc = slots_t(a->dy, a->lddy, D, dyT))) return rc;
-    if ((rc = slots_t(a->h, a->ldh, I, hT))) return rc;
-    if ((rc = slots_t(dgu, 2 * I, 2 * I, dguT))) return rc;
-    if (ragged) {
-        if ((rc = umoe_transpose_slots_compact(a->x, a->ldx, D, a->slot_token, a->counts, a->offsets, G, S, xeT, stream))) return rc;
-    } else {
-        for (int g = 0; g < G; ++g)
-            if ((rc = umoe_transpose_slots(a->x, a->ldx, D, nullptr, nullptr, nullptr, 1, S, xeT + (size_t)g * Sp, ldT, stream))) return rc;
-    }
-    // dWd_g [D][I] = dyT[:, cols_g] * hT[:, cols_g]^T ; dWg_g [I][D] = dgT * xeT^T ; dWu_g = duT * xeT^T.
-    // When the caller's gradient buffers of a kind are one stacked allocation ([G][rows][cols], as ops.experts_swiglu_bwd makes
-    // them) the G products of that kind are ONE grouped launch (per-group contraction window and output row base): 8 x 88
-    // tiles fill the chip with the 256 x 256 variant, one expert's 88 tiles alone run on the small tiles at ~400 TFLOP/s.
-    // ragged: the transposed buffers are per-expert COMPACT blocks (rows roundup8(count) apart instead of the whole slot range:
-    // scripts/wgrad_bench.py, 296 -> 239 us per launch); a_total / w_total = total rows of the two operands
-    auto window = [&](umoe_tgroup_t& t, int g, int a_total, int w_total) {
-        if (ragged) { t.k_off = a->offsets + g; t.k_count = a->counts + g; t.k = 8; t.k_compact_a = a_total; t.k_compact_w = w_total; }
-        else { t.k = Sp; t.a_col_off = g * Sp; }       // zero-padded private column range
-    };
+    // Weight gradients straight from the row-major slot buffers (umoe_tiled_gemm_tn; round 2 wrote dY^T, H^T, (dG|dU)^T and X^T first):
+    //   dWd_g [D][I] = dY_g^T H_g ; (dWg_g ; dWu_g) [I][D] = (dG_g | dU_g)^T X_g
+    // routed experts: ONE grouped launch per product kind with the experts' slot windows read on the device (gate and up together:
+    // 2 G groups); shared experts: static windows, the K split chosen by the library when the outputs of a launch are one stacked slab
+    // (ops.experts_swiglu_bwd allocates them so).
     auto stacked = [&](uint16_t* const* ptrs, size_t elems) {
         for (int g = 1; g < G; ++g)
             if (ptrs[g] != ptrs[0] + (size_t)g * elems) return false;
         return true;
     };
-    auto products = [&](const uint16_t* wT, int n, int rows, const uint16_t* aT, int a_row_base, int a_total, uint16_t* const* outs) -> int {
-        // out_g [rows][n] = aT[a_row_base + r][cols_g] . wT[c][cols_g]
-        umoe_tgemm_args b{};
-        b.max_rows = rows; b.a = aT; b.lda = ldT; b.ldo = n; b.epilogue = UMOE_EPI_BF16;
-        if (stacked(outs, (size_t)rows * n)) {
-            memset(tg, 0, sizeof(tg));
-            for (int g = 0; g < G; ++g) {
-                tg[g].w = wT + (ragged ? 0 : g * Sp); tg[g].n = n; tg[g].ldw = ldT; tg[g].static_count = rows; tg[g].a_row_base = a_row_base;
-                tg[g].out_row_base = g * rows;
-                window(tg[g], g, a_total, n);
-            }
-            b.groups = tg; b.num_groups = G; b.out = outs[0];
-            return umoe_tiled_gemm(&b, stream);
-        }
+    umoe_tn_group_t tn[24];
+    if (ragged) {
+        gather_slots_kernel<<<dim3((unsigned)(S < 2048 ? ceil_div(S, 4) : 512), (unsigned)G), 256, 0, (hipStream_t)stream>>>(a->x, a->ldx, D, a->slot_token, a->counts, a->offsets, xe);
+        UMOE_LAUNCH_CHECK();
+        umoe_tgemm_tn_args b{};
+        memset(tn, 0, sizeof(tn));
         for (int g = 0; g < G; ++g) {
-            umoe_tgroup_t t1{};
-            t1.w = wT + (ragged ? 0 : g * Sp); t1.n = n; t1.ldw = ldT; t1.static_count = rows; t1.a_row_base = a_row_base;
-            window(t1, g, a_total, n);
-            b.groups = &t1; b.num_groups = 1; b.out = outs[g];
-            if (int rc2 = umoe_tiled_gemm(&b, stream)) return rc2;
+            tn[g].m = D; tn[g].n = I; tn[g].k_off_dev = a->offsets + g; tn[g].k_count_dev = a->counts + g; tn[g].out = a->dw_down[g];
         }
-        return 0;
-    };
-    if ((rc = products(hT, I, D, dyT, 0, D, a->dw_down))) return rc;
-    if ((rc = products(xeT, D, I, dguT, 0, 2 * I, a->dw_gate))) return rc;
-    if ((rc = products(xeT, D, I, dguT, I, 2 * I, a->dw_up))) return rc;
-    return 0;
+        b.groups = tn; b.num_groups = G; b.p = a->dy; b.ldp = a->lddy; b.q = a->h; b.ldq = a->ldh; b.out = a->dw_down[0]; b.ldo = I;
+        if ((rc = umoe_tiled_gemm_tn(&b, stream))) return rc;
+        memset(tn, 0, sizeof(tn));
+        for (int g = 0; g < G; ++g) {
+            tn[g].m = I; tn[g].n = D; tn[g].k_off_dev = a->offsets + g; tn[g].k_count_dev = a->counts + g; tn[g].out = a->dw_gate[g];
+            tn[G + g] = tn[g];
+            tn[G + g].p_col_off = I; tn[G + g].out = a->dw_up[g];
+        }
+        b.groups = tn; b.num_groups = 2 * G; b.p = dgu; b.ldp = 2 * I; b.q = xe; b.ldq = D; b.out = a->dw_gate[0]; b.ldo = D;
+        return umoe_tiled_gemm_tn(&b, stream);
+    }
+    // shared experts: group g owns the slot rows [row_base + g S, + S) of dY / H / (dG|dU) and reads x by identity (rows 0 .. S-1)
+    const bool down_slab = stacked(a->dw_down, (size_t)D * I);
+    const bool gu_slab = stacked(a->dw_gate, (size_t)I * D) && stacked(a->dw_up, (size_t)I * D) && a->dw_up[0] == a->dw_gate[0] + (size_t)G * I * D;
+    {
+        umoe_tgemm_tn_args b{};
+        memset(tn, 0, sizeof(tn));
+        for (int g = 0; g < G; ++g) {
+            const size_t r0 = (size_t)a->row_base + (size_t)g * S;
+            tn[g].m = D; tn[g].n = I; tn[g].k = S;
+            tn[g].p = a->dy + r0 * a->lddy; tn[g].ldp = a->lddy; tn[g].q = a->h + r0 * a->ldh; tn[g].ldq = a->ldh;
+            if (down_slab) tn[g].out_row_base = g * D; else tn[g].out = a->dw_down[g];
+        }
+        b.groups = tn; b.num_groups = G; b.p = a->dy; b.ldp = a->lddy; b.q = a->h; b.ldq = a->ldh; b.out = a->dw_down[0]; b.ldo = I;
+        if (down_slab) { b.k_split = -1; b.ws = tn_ws; b.part_stride = (long)G * D * I; }
+        if ((rc = umoe_tiled_gemm_tn(&b, stream))) return rc;
+    }
+    {
+        umoe_tgemm_tn_args b{};
+        memset(tn, 0, sizeof(tn));
+        for (int g = 0; g < G; ++g) {
+            const size_t r0 = (size_t)a->row_base + (size_t)g * S;
+            tn[g].m = I; tn[g].n = D; tn[g].k = S;
+            tn[g].p = dgu + r0 * 2 * I; tn[g].ldp = 2 * I;
+            if (gu_slab) tn[g].out_row_base = g * I; else tn[g].out = a->dw_gate[g];
+            tn[G + g] = tn[g];
+            tn[G + g].p_col_off = I;
+            if (gu_slab) tn[G + g].out_row_base = (G + g) * I; else tn[G + g].out = a->dw_up[g];
+        }
+        b.groups = tn; b.num_groups = 2 * G; b.p = dgu; b.ldp = 2 * I; b.q = a->x; b.ldq = a->ldx; b.out = a->dw_gate[0]; b.ldo = D;
+        if (gu_slab) { b.k_split = -1; b.ws = tn_ws; b.part_stride = (long)2 * G * I * D; }
+        return umoe_tiled_gemm_tn(&b, stream);
+    }
 }
 
 extern "C" int umoe_grouped_swiglu_bwd(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) {

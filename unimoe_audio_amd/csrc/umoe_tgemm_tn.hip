@@ -11,21 +11,21 @@
 //    (on the SOURCE address: the DMA writes linearly);
 //  * MFMA operands come out of the k-major image by ds_read_b64_tr_b16 (hardware transpose: per 16-lane group, lane 4q+p supplies the
 //    address of row q, columns 4p..4p+3; lane i receives column i of the four rows): two reads per 16x16x32 operand.  Lane group h takes
-//    rows 4h..4h+3 with the first read and 16+4h.. with the second, i.e. k-slot (h, e) of the MFMA is row 4h+e (e < 4) / 16+4h+e-4 -- the
-//    same for both operands, and a permutation of k inside a tile does not change the sum;
-//    a 32-lane half of the read then touches eight consecutive rows = four pairs whose 32-byte granules fall on bank groups
-//    {0,1}+2t (pad) with the XOR choosing inside the pair: every bank once.
+//    LDS rows 4h..4h+3 with the first read and 16+4h.. with the second; a 32-lane half of a read then touches eight consecutive LDS rows
+//    = four pairs whose 32-byte granules fall on bank groups {0,1}+2t (pad) with the XOR choosing inside the pair: every bank once.
+//    The DMA puts window row 8h+e of a K tile into LDS row 4h+e (e < 4) / 16+4h+e-4, so k-slot (h, e) of the MFMA holds window row 8h+e
+//    exactly as in tgemm_pp_kernel over a transposed copy;
 //  * the 16-column fragments of a wave are STRIDED over the tile (Q side: columns 16 (4j + wc), P side: 16 (2i + wr)) so that the XOR bit
 //    is a wave constant and every fragment is one base register + an immediate offset.
 // Results: the fp32 sums run over the same 32-row tiles in the same order as tgemm_pp_kernel over transposed copies, and inside a tile
-// the MFMA adds the same 32 products -- tests/test_gpu_ops.py compares the two bit for bit.
+// every MFMA gets the same operands in the same k slots -- tests/test_gpu_ops.py compares the two bit for bit (no K split).
 // Roofline: MFMA (2.5 PFLOP/s dense bf16).
 #include "umoe_common.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
-#define TN_MAXG 12
+#define TN_MAXG 24
 struct tn_pack { umoe_tn_group_t g[TN_MAXG]; };
 __device__ __attribute__((aligned(16))) uint4 tn_zero16;
 typedef unsigned int tn_u32x2 __attribute__((ext_vector_type(2)));
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void tgemm_tn_kernel(const umoe_tgemm_tn_ar
     int rrow[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        rrow[q] = 2 * (wave + 8 * q) + rodd;
+        rrow[q] = 8 * (wave >> 1) + 4 * q + 2 * (wave & 1) + rodd;      // LDS row 4h + e (pairs 0..7) / 16 + 4h + e - 4 (pairs 8..15) <- window row 8h + e
         const int mc = m0 + 8 * cl, nc = n0 + 8 * cl;
         pdel[q] = mc < g.m ? reinterpret_cast<const char*>(Pb + (long)(koff + rrow[q]) * ldp + g.p_col_off + mc) - zero : 0;
         qdel[q] = nc < g.n ? reinterpret_cast<const char*>(Qb + (long)(koff + rrow[q]) * ldq + g.q_col_off + nc) - zero : 0;
@@ -261,9 +261,43 @@ static int launch_tn(const umoe_tgemm_tn_args* a, int max_m, int max_n, int ragg
     return 0;
 }
 
+// K split of a launch (k_split < 0: chosen here).  Model fitted on MI355X (scripts/tn_bench.py): a workgroup needs 20 us + 0.55 us per
+// 32-row K tile, the launch takes ceil(workgroups / CUs) rounds of that, the reduction 3 us + its bytes at 5 TB/s.
+static int tn_effective_split(const umoe_tgemm_tn_args* a) {
+    if (a->k_split >= 0) return a->k_split > 1 ? a->k_split : 1;
+    long tiles = 0, elems = 0;
+    int kmax = 0;
+    for (int i = 0; i < a->num_groups; ++i) {
+        const umoe_tn_group_t& g = a->groups[i];
+        if (g.k_count_dev || g.out || g.out_col_off || g.n != a->ldo) return 1;      // device windows are balanced by their number; split needs one dense slab
+        tiles += (long)ceil_div(g.m, 256) * ceil_div(g.n, 256);
+        elems += (long)g.m * g.n;
+        if (g.k > kmax) kmax = g.k;
+    }
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const int KT = (kmax + 31) / 32;
+    int best = 1;
+    double best_t = 1e30;
+    for (int ks = 1; ks <= 8; ++ks) {
+        if (ks > 1 && KT / ks < 16) break;
+        const double rounds = (double)((tiles * ks + cus - 1) / cus);
+        const double t = rounds * (20.0 + 0.55 * ((KT + ks - 1) / ks)) + (ks > 1 ? 3.0 + (4.0 * ks + 2.0) * elems / 5.0e6 : 0.0);
+        if (t < best_t - 1e-9) { best_t = t; best = ks; }
+    }
+    return best;
+}
+
 extern "C" size_t umoe_tiled_gemm_tn_workspace_bytes(const umoe_tgemm_tn_args* a) {
-    if (!a || a->k_split <= 1) return 0;
-    return (size_t)a->k_split * (size_t)a->part_stride * sizeof(float);
+    if (!a || !a->groups || a->num_groups <= 0 || a->num_groups > TN_MAXG) return 0;
+    const int ks = a->k_split < 0 ? 8 : a->k_split;          // (auto: room for the largest split the model can choose)
+    if (ks <= 1) return 0;
+    return (size_t)ks * (size_t)a->part_stride * sizeof(float);
 }
 
 extern "C" int umoe_tiled_gemm_tn(const umoe_tgemm_tn_args* a, umoe_stream_t stream) {
@@ -278,8 +312,11 @@ extern "C" int umoe_tiled_gemm_tn(const umoe_tgemm_tn_args* a, umoe_stream_t str
         const int ldp = g.p ? g.ldp : a->ldp, ldq = g.q ? g.ldq : a->ldq;
         UMOE_REQUIRE(P && Q && ldp % 8 == 0 && ldq % 8 == 0 && (reinterpret_cast<size_t>(P) & 15) == 0 && (reinterpret_cast<size_t>(Q) & 15) == 0,
                      "umoe_tiled_gemm_tn: group %d: operands must be 16-byte aligned with leading dimensions that are multiples of 8", i);
-        UMOE_REQUIRE(g.m > 0 && g.n > 0 && g.m % 8 == 0 && g.n % 8 == 0 && g.p_col_off % 8 == 0 && g.q_col_off % 8 == 0 && (g.out_col_off & 3) == 0,
-                     "umoe_tiled_gemm_tn: group %d: m, n, column offsets must be multiples of 8 (m=%d n=%d)", i, g.m, g.n);
+        // (the DMA fetches whole 8-column chunks: a last chunk that straddles m or n must lie inside the row -- its surplus columns only feed
+        //  output rows / columns the stores skip)
+        UMOE_REQUIRE(g.m > 0 && g.n > 0 && g.n % 4 == 0 && g.p_col_off % 8 == 0 && g.q_col_off % 8 == 0 && (g.out_col_off & 3) == 0 &&
+                         g.p_col_off + ((g.m + 7) & ~7) <= ldp && g.q_col_off + ((g.n + 7) & ~7) <= ldq,
+                     "umoe_tiled_gemm_tn: group %d: n %% 4, column offsets %% 8, and the 8-column chunks that hold m / n must lie inside a row (m=%d n=%d)", i, g.m, g.n);
         UMOE_REQUIRE((g.k_off_dev == nullptr) == (g.k_count_dev == nullptr), "umoe_tiled_gemm_tn: group %d: k_off_dev and k_count_dev come together", i);
         UMOE_REQUIRE(g.k_count_dev || (g.k >= 0 && g.k_off >= 0), "umoe_tiled_gemm_tn: group %d: bad static window", i);
         if (g.m > max_m) max_m = g.m;
@@ -287,18 +324,23 @@ extern "C" int umoe_tiled_gemm_tn(const umoe_tgemm_tn_args* a, umoe_stream_t str
         ragged |= g.k_count_dev != nullptr && a->num_groups > 1;
     }
     hipStream_t s = (hipStream_t)stream;
-    const int ks = a->k_split > 1 ? a->k_split : 1;
+    const int ks = tn_effective_split(a);
     if (ks == 1) return launch_tn<false>(a, max_m, max_n, ragged, 1, s);
     // K split: fp32 partial slabs [k_split][part_stride] in the caller's workspace, summed in fixed order
     UMOE_REQUIRE(a->ws && ks <= 16, "umoe_tiled_gemm_tn: k_split needs a workspace (umoe_tiled_gemm_tn_workspace_bytes), k_split <= 16");
+    UMOE_REQUIRE(!ragged, "umoe_tiled_gemm_tn: k_split needs static windows");
     UMOE_REQUIRE(a->part_stride % 4 == 0 && (reinterpret_cast<size_t>(a->ws) & 15) == 0, "umoe_tiled_gemm_tn: part_stride %% 4, 16-byte aligned workspace");
     umoe_tgemm_tn_args b = *a;
     umoe_tn_group_t gs[TN_MAXG];
     memcpy(gs, a->groups, sizeof(umoe_tn_group_t) * a->num_groups);
     for (int i = 0; i < a->num_groups; ++i) {
-        UMOE_REQUIRE(!gs[i].out, "umoe_tiled_gemm_tn: k_split with per-group output pointers is not supported");
+        UMOE_REQUIRE(!gs[i].out && !gs[i].k_count_dev && gs[i].out_col_off == 0 && gs[i].n == a->ldo,
+                     "umoe_tiled_gemm_tn: k_split needs static windows and groups that are whole rows of ONE dense output (n == ldo)");
         UMOE_REQUIRE(((long)gs[i].out_row_base + gs[i].m) * (long)a->ldo <= a->part_stride, "umoe_tiled_gemm_tn: part_stride smaller than the output");
     }
+    long covered = 0;
+    for (int i = 0; i < a->num_groups; ++i) covered += (long)gs[i].m * a->ldo;
+    UMOE_REQUIRE(covered == a->part_stride, "umoe_tiled_gemm_tn: k_split: the groups must cover the whole output slab (part_stride = %ld, covered %ld)", a->part_stride, covered);
     b.groups = gs;
     b.out = a->ws;
     if (int rc = launch_tn<true>(&b, max_m, max_n, 0, ks, s)) return rc;

@@ -469,10 +469,8 @@ class _DCMoETrainFn(torch.autograd.Function):
         noise = ctx.noise
         gate_only = noise is not None and not ctx.jitter_all               # fp32 gate: only the gate's copy was jittered
         jit = lambda t: _jitter_rows(t, noise)
-        xT = ops.transpose(jit(x) if gate_only else x)                      # [D][Sp]; the gate saw the jittered input
-        dlT = ops.transpose(dl16)                                            # [16][Sp]
-        dWgate = torch.empty((16, D), dtype=bf, device=dev)
-        ops.tiled_gemm([dict(w=xT, static_count=16)], dlT, dWgate, max_rows=16)
+        dWgate = torch.empty((16, D), dtype=bf, device=dev)                 # dl16^T x: the gate saw the jittered input
+        ops.tiled_gemm_tn([dict(m=16, n=D, k=S)], dl16, jit(x) if gate_only else x, dWgate, k_split=-1)
         grads[0] = dWgate[:E]
         dx_router = ops.tlinear(dl16, ops.transpose(params[0]))              # [S][16] x [D][16]^T
         if gate_only:

@@ -470,12 +470,21 @@ def tiled_gemm_tn(groups: Sequence[dict], p: torch.Tensor, q: torch.Tensor, out:
     args = L.TGemmTnArgs(groups=C.cast(arr, C.c_void_p), num_groups=len(groups), p=_pv(p), ldp=p.stride(0), q=_pv(q), ldq=q.stride(0),
                          out=_pv(out), ldo=out.stride(-2), k_split=k_split)
     ws = None
-    if k_split > 1:
+    if k_split > 1 or k_split < 0:                            # (< 0: the library chooses from the tile count and K)
         args.part_stride = out.numel()
         ws = torch.empty(L.lib().umoe_tiled_gemm_tn_workspace_bytes(C.byref(args)), dtype=torch.uint8, device=out.device)
         args.ws = ws.data_ptr()
     L.check(L.lib().umoe_tiled_gemm_tn(C.byref(args), _stream()), "umoe_tiled_gemm_tn")
     return out
+
+
+def linear_weight_grad(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """dW [N][K] = dy[:, :N]^T x for y = x W^T (torch.nn.functional.linear backward, core.py:21-49): no transposed copies; dy may carry
+    zero-padded columns behind N (row stride a multiple of 8)."""
+    N, K = w.shape
+    assert x.shape[0] == dy.shape[0] and x.shape[1] == K and dy.shape[1] >= N
+    dw = torch.empty((N, K), dtype=torch.bfloat16, device=w.device)
+    return tiled_gemm_tn([dict(m=N, n=K, k=x.shape[0])], dy, x, dw, k_split=-1)
 
 
 def tlinear(x: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, resid=None, out_f32=False) -> torch.Tensor:
@@ -652,8 +661,9 @@ def experts_swiglu_bwd(ws_list, *, x, h, gu, dy, dx_slots, D: int, I: int, max_r
     dev = x.device
     arr = lambda ts: (C.c_void_p * G)(*[t.data_ptr() for t in ts])
     # one stacked allocation per kind: the composite then runs each kind's G weight-gradient products as ONE grouped launch
-    dwg = list(torch.empty((G,) + tuple(ws_list[0][0].shape), dtype=torch.bfloat16, device=dev).unbind(0))
-    dwu = list(torch.empty((G,) + tuple(ws_list[0][1].shape), dtype=torch.bfloat16, device=dev).unbind(0))
+    # (gate and up in ONE allocation [2][G][I][D]: the shared experts' K-split weight-gradient launch writes them as one slab)
+    dwgu = torch.empty((2, G) + tuple(ws_list[0][0].shape), dtype=torch.bfloat16, device=dev)
+    dwg, dwu = list(dwgu[0].unbind(0)), list(dwgu[1].unbind(0))
     dwd = list(torch.empty((G,) + tuple(ws_list[0][2].shape), dtype=torch.bfloat16, device=dev).unbind(0))
     keep = (arr([w[0] for w in ws_list]), arr([w[1] for w in ws_list]), arr([w[2] for w in ws_list]), arr(dwg), arr(dwu), arr(dwd))
     a = L.SwigluBwdArgs(num_groups=G, w_gate=keep[0], w_up=keep[1], w_down=keep[2], D=D, I=I, counts=_p(counts), offsets=_p(offsets),

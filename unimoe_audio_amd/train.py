@@ -6,7 +6,7 @@ Reference graph: Qwen2_5_VLMoEDecoderLayer.forward utils/UniMoE_Audio_model.py:2
 training loss :817-854; attention / RMSNorm / mRoPE arithmetic = the transformers classes imported at :52-56.
 
 Backward of the contractions: umoe_tiled_gemm needs K-contiguous operands, so dX = dY W uses a transposed weight copy and
-dW = dY^T X contracts over token columns of transposed activations (umoe_transpose_slots).  Attention backward is the
+dW = dY^T X runs on the row-major activations themselves (umoe_tiled_gemm_tn, transposing LDS reads; K split chosen by the library).  Attention backward is the
 "unfused" first version: scores are materialised per (row, kv head) group, P is recomputed, every contraction is a tiled
 GEMM (see umoe_bwd.hip).  No CPU fallback: CPU tensors raise.
 """
@@ -45,11 +45,11 @@ class LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = dy.to(torch.bfloat16).contiguous()
         S = x.shape[0]
-        dx = ops.tlinear(_pad8(dy), ops.transpose_weight_cached(w)) if ctx.needs_input_grad[0] else None   # [S][N] x [K][N]^T
+        dy8 = _pad8(dy)
+        dx = ops.tlinear(dy8, ops.transpose_weight_cached(w)) if ctx.needs_input_grad[0] else None   # [S][N] x [K][N]^T
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            ops.tiled_gemm([dict(w=ops.transpose(x), static_count=w.shape[0])], ops.transpose(dy), dw, max_rows=w.shape[0])
+            dw = ops.linear_weight_grad(dy8, x, w)
         db = dy.float().sum(0).to(torch.bfloat16) if ctx.has_b and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
@@ -255,10 +255,8 @@ class _HeadFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dyb = dy.to(torch.bfloat16).contiguous()
-        dx = ops.tlinear(_pad8(dyb), ops.transpose_weight_cached(w))
-        dw = torch.empty_like(w)
-        ops.tiled_gemm([dict(w=ops.transpose(x), static_count=w.shape[0])], ops.transpose(dyb), dw, max_rows=w.shape[0])
-        return dx, dw
+        dy8 = _pad8(dyb)
+        return ops.tlinear(dy8, ops.transpose_weight_cached(w)), ops.linear_weight_grad(dy8, x, w)
 
 
 def ops_f32_head(x, w):
