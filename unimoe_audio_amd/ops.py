@@ -290,11 +290,24 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, resid: Optional[torch.
     return (y, s) if resid is not None else y
 
 
+_ROPE_TABLES: dict = {}
+
+
 def rope_tables(max_pos: int, head_dim: int, theta: float, device) -> tuple:
-    """cos/sin [max_pos][hd/2] bf16, built with the same torch ops as Qwen2_5_VLRotaryEmbedding (fp32 -> bf16)."""
-    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
-    fr = torch.arange(max_pos, dtype=torch.float)[:, None] * inv[None, :]
-    return fr.cos().to(torch.bfloat16).to(device), fr.sin().to(torch.bfloat16).to(device)
+    """cos/sin [>= max_pos][hd/2] bf16, built with the same torch ops as Qwen2_5_VLRotaryEmbedding (fp32 -> bf16).  A row depends on its
+    position only, so a table is built once per (length rounded up to 1024, head_dim, theta, device) and kept: building it on the host and
+    uploading it took 5 ms of every training step (two idle gaps of 2.6 ms in the kernel trace, profiles/r03n)."""
+    n = (int(max_pos) + 1023) & ~1023
+    key = (n, int(head_dim), float(theta), str(device))
+    hit = _ROPE_TABLES.get(key)
+    if hit is None:
+        inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+        fr = torch.arange(n, dtype=torch.float)[:, None] * inv[None, :]
+        hit = (fr.cos().to(torch.bfloat16).to(device), fr.sin().to(torch.bfloat16).to(device))
+        if len(_ROPE_TABLES) >= 8:
+            _ROPE_TABLES.pop(next(iter(_ROPE_TABLES)))
+        _ROPE_TABLES[key] = hit
+    return hit
 
 
 def qkv_mrope_kvappend(qkv, cos_tab, sin_tab, pos3, kv_pos, T, H, KVH, hd, sections, k_cache, v_cache):
