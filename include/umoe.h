@@ -229,6 +229,11 @@ typedef struct {
                                * umoe_transpose_slots_compact writes): this group's block starts at element *k_off * k_compact_a (the
                                * operand's total row count) and its rows are roundup8(*k_count) apart, columns [0, roundup8(*k_count)) */
     int k_compact_w;          /* the same for the weight operand (total rows of `w`) */
+    int w_kmajor;             /* != 0: `w` is row-major [K][ldw] with the CONTRACTION index as its row and n columns (Y = A W): the input
+                               * gradient dX = dY W on an nn.Linear weight as stored, no transposed copy.  UMOE_EPI_BF16 only, every group of
+                               * the launch alike, n % 8 == 0, no bias / K window; the launch runs whatever its size on 256 x 256 tiles */
+    int k_w1;                 /* w_kmajor with w2 != NULL: rows [0, k_w1) of the contraction come from w, rows [k_w1, k) from w2 (same ldw, */
+                              /* k_w1 % 32 == 0): (dG | dU) against Wg then Wu */
 } umoe_tgroup_t;
 
 typedef struct {
@@ -417,9 +422,10 @@ typedef struct {
     uint16_t* const* dw_up;
     uint16_t* const* dw_down;
     void* ws; size_t ws_bytes;       /* umoe_swiglu_bwd_workspace_bytes() */
-    const uint16_t* w_down_T;        /* optional, both or neither: transposed weight copies kept by the caller while the weights are */
-    const uint16_t* w_gateup_T;      /* unchanged (gradient accumulation): group g's Wd^T [I][roundup8(D)] at w_down_T + g*I*roundup8(D),
-                                      * (Wg^T | Wu^T) [D][2I] at w_gateup_T + g*D*2I -- the layout the composite builds itself otherwise */
+    const uint16_t* w_down_T;        /* optional, both or neither, read ONLY when I % 32 != 0 (otherwise the input gradients read the weights */
+    const uint16_t* w_gateup_T;      /* as stored, umoe_tgroup_t.w_kmajor): transposed weight copies of the caller, group g's Wd^T [I][roundup8(D)]
+                                      * at w_down_T + g*I*roundup8(D), (Wg^T | Wu^T) [D][2I] at w_gateup_T + g*D*2I -- what the composite
+                                      * builds per call itself otherwise */
 } umoe_swiglu_bwd_args;
 size_t umoe_swiglu_bwd_workspace_bytes(const umoe_swiglu_bwd_args* a);
 int umoe_grouped_swiglu_bwd(const umoe_swiglu_bwd_args* a, umoe_stream_t stream);

@@ -66,19 +66,20 @@ for _ in range(steps):
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
 dt = sorted(ts)[len(ts) // 2]
-# a trainer that steps the optimizer after every backward cannot reuse the transposed weight copies: same steps without the cache
-from unimoe_audio_amd import ops as _ops
-_ops.clear_weight_transpose_cache()
-os.environ["UMOE_WT_CACHE"] = "0"
+# a trainer steps the optimizer after every backward: the same steps with every parameter updated in place (untimed) in between --
+# nothing is kept across steps that depends on the weights (round 2 kept transposed weight copies; the input gradients read the weights
+# as stored now), so this is the same number
 tn = []
 for _ in range(int(os.environ.get("TB_NOCACHE_STEPS", "3"))):
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     step()
     torch.cuda.synchronize()
     tn.append(time.perf_counter() - t0)
 dtn = sorted(tn)[len(tn) // 2] if tn else None
-os.environ.pop("UMOE_WT_CACHE")
 tf = []
 with torch.no_grad():
     for _ in range(2):
@@ -98,7 +99,5 @@ print(json.dumps({"workload": f"BASELINE configs[2]: fwd+bwd, {layers} layers, b
                                "frac": round(step_flops(k_real[0]) / dt / 2.5e15, 4),
                                "note": "whole step: algorithmic FLOPs (3 x forward, logged k_real routed experts per token) / step time; "
                                        "peak = dense bf16 MFMA (MI355X_MICROARCH.md)"},
-                  "weights_unchanged_between_steps": True,
-                  "note": "layer math only, no optimizer step (SURVEY 8d config 3): the weights keep their versions, so from the third step on "
-                          "the transposed weight copies of the input-gradient GEMMs are reused (ops._WT_CACHE, the gradient-accumulation "
-                          "case); UMOE_WT_CACHE=0 rebuilds them every step as a trainer stepping after every backward would"}))
+                  "note": "layer math only, no optimizer step (SURVEY 8d config 3); step_ms_weights_change_every_step = the same step after an "
+                          "in-place update of every parameter (nothing weight-dependent is cached across steps)"}))

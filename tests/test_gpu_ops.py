@@ -102,6 +102,60 @@ def test_tiled_gemm_tn_static_windows(dev, T, M, N, G, ksplit):
                 assert (nt.float() - got).abs().max() <= 2 ** -7 * scale + 1e-3
 
 
+@pytest.mark.parametrize("S,K,N,k1", [(6240, 2560, 2048, 0),          # dX of the QKV projection at the training width
+                                      (300, 12324, 2048, 0),          # codec head: contraction length not a multiple of 8 (zero-padded dY)
+                                      (1100, 11, 2048, 0),            # router gate: 11 experts in 16 padded columns
+                                      (2304, 704, 3584, 352),         # (dG | dU) against Wg then Wu: the contraction continues in a second matrix
+                                      (2600, 520, 264, 0)])
+def test_tiled_gemm_kmajor_weights(dev, S, K, N, k1):
+    """umoe_tiled_gemm with umoe_tgroup_t.w_kmajor: Y = A W on a weight whose ROW is the contraction index (dX = dY W on an nn.Linear
+    weight as stored) against an fp32 reference, and bit-identical to the same product on a transposed copy where that runs the 256 x 256
+    kernel as well."""
+    from unimoe_audio_amd import ops
+    g = torch.Generator().manual_seed(S + K + N)
+    K8 = (K + 7) & ~7
+    a = torch.zeros(S, K8, dtype=torch.bfloat16)
+    a[:, :K] = (torch.randn(S, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(K, N, generator=g) * 0.05).to(torch.bfloat16)
+    ad, wd = a.to(dev), w.to(dev)
+    out = torch.full((S, N), 5.0, dtype=torch.bfloat16, device=dev)
+    if k1:
+        w1, w2 = wd[:k1].contiguous(), wd[k1:].contiguous()
+        ops.tiled_gemm([dict(w=w1, w2=w2, w_kmajor=1, k=K, k_w1=k1, static_count=S)], ad, out, max_rows=S)
+    else:
+        ops.tiled_gemm([dict(w=wd, w_kmajor=1, static_count=S)], ad, out, max_rows=S)
+    ref = a[:, :K].float() @ w.float()
+    assert (out.float().cpu() - ref).abs().max() <= 2 ** -7 * float(ref.abs().max()) + 1e-3
+    if K % 8 == 0 and S >= 1024 and -(-S // 256) * -(-N // 256) >= 128:
+        nt = ops.tlinear(ad, ops.transpose(wd))
+        assert torch.equal(nt, out)
+
+
+def test_tiled_gemm_kmajor_weights_ragged_groups(dev):
+    """k-major weights with the routed experts' row conventions: per-group row offset and count read on the device, rows behind a count
+    untouched."""
+    from unimoe_audio_amd import ops
+    g = torch.Generator().manual_seed(77)
+    E, D, I = 4, 512, 352
+    counts = [300, 0, 1025, 17]
+    offs, tot = [], 0
+    for c in counts:
+        offs.append(tot)
+        tot += (c + 7) & ~7
+    dy = (torch.randn(tot, D, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    wd = [(torch.randn(D, I, generator=g) * 0.05).to(torch.bfloat16).to(dev) for _ in range(E)]     # down_proj [D][I]: dH = dY Wd
+    cnt = torch.tensor(counts, dtype=torch.int32, device=dev)
+    off = torch.tensor(offs, dtype=torch.int32, device=dev)
+    out = torch.full((tot, I), 9.0, dtype=torch.bfloat16, device=dev)
+    ops.tiled_gemm([dict(w=wd[e], w_kmajor=1, row_off=off[e:e + 1], count=cnt[e:e + 1]) for e in range(E)], dy, out, max_rows=max(counts))
+    for e in range(E):
+        c, o = counts[e], offs[e]
+        if c:
+            ref = dy[o:o + c].float() @ wd[e].float()
+            assert (out[o:o + c].float() - ref).abs().max() <= 2 ** -7 * float(ref.abs().max()) + 1e-3
+        assert bool((out[o + c:o + ((c + 7) & ~7)] == 9.0).all())
+
+
 @pytest.mark.parametrize("E,D,I,counts", [(8, 2048, 2752, [2700, 0, 3111, 8, 1, 2999, 4096, 2048]),
                                           (3, 512, 264, [40, 300, 31])])
 def test_tiled_gemm_tn_expert_windows_on_device(dev, E, D, I, counts):
@@ -1021,16 +1075,15 @@ def test_aux_loss_two_launch_form_vs_oracle(dev, weighted, bf16):
     assert torch.allclose(got.cpu().float(), one.cpu()[0].float(), rtol=1e-4, atol=1e-6)
 
 
-def test_backward_with_kept_weight_transposes_is_bit_identical(dev):
-    """Three backward passes over unchanged weights: the third reuses the transposed weight copies built during the second
-    (ops._WT_CACHE, umoe_swiglu_bwd_args.w_down_T / w_gateup_T) and must give the gradients of the first, bit for bit; an in-place
-    weight update drops the copies."""
-    from unimoe_audio_amd import ops
+@pytest.mark.parametrize("I_dyn,I_sh", [(128, 64), (136, 72)])
+def test_backward_is_deterministic_and_sees_weight_updates(dev, I_dyn, I_sh):
+    """Repeated backward passes over unchanged weights give the same gradients bit for bit, and an in-place weight update is seen by the
+    next pass: nothing weight-dependent is kept across calls (round 2 cached transposed weight copies; the input gradients now read the
+    weights as stored -- intermediate sizes that are multiples of 32 -- or transpose them per call)."""
     from unimoe_audio_amd.config import UniMoEAudioConfig
     from unimoe_audio_amd.dcmoe import UniMoEAudioSparseMoeBlock
-    ops._WT_CACHE.clear()
     torch.manual_seed(4)
-    cfg = UniMoEAudioConfig(hidden_size=256, dynamic_intermediate_size=128, shared_intermediate_size=64, input_jitter_noise=0.0)
+    cfg = UniMoEAudioConfig(hidden_size=256, dynamic_intermediate_size=I_dyn, shared_intermediate_size=I_sh, input_jitter_noise=0.0)
     blk = UniMoEAudioSparseMoeBlock(cfg)
     with torch.no_grad():
         for p in blk.parameters():
@@ -1049,14 +1102,12 @@ def test_backward_with_kept_weight_transposes_is_bit_identical(dev):
         (out[0].float() * G.float()).sum().backward()
         return [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
     a, b, c = run(), run(), run()
-    built = [e for e in ops._WT_CACHE.values() if e["t"] is not None]
-    assert len(built) >= 2                       # routed and shared experts of the block
     for u, v, w in zip(a, b, c):
         assert torch.equal(u, v) and torch.equal(u, w)
     with torch.no_grad():
         next(iter(blk._experts()[0].parameters())).mul_(1.5)
     d = run()
-    assert not torch.equal(d[0], a[0])           # the new weights were used, not the stale copies
+    assert not torch.equal(d[0], a[0])           # the new weights were used
     e = run()
     assert all(torch.equal(p, q) for p, q in zip(d, e))
 

@@ -101,42 +101,3 @@ def test_moe_optimizer_param_groups():
     assert len(opt.param_groups) == 3
 
 
-def test_weight_transpose_cache_rule_is_version_keyed(monkeypatch):
-    """ops._cached_weight_transposes: nothing is built on the first sight of a set of parameter versions, the copies are built on the second
-    and reused on the third, and a version bump (an optimizer step) drops them -- checked on CPU tensors (the rule is host logic)."""
-    import torch
-    from unimoe_audio_amd import ops
-    ops._WT_CACHE.clear()
-    D, I = 16, 8
-    ws = [(torch.randn(I, D).to(torch.bfloat16), torch.randn(I, D).to(torch.bfloat16), torch.randn(D, I).to(torch.bfloat16)) for _ in range(2)]
-    assert ops._cached_weight_transposes(ws, D, I) is None
-    kept = ops._cached_weight_transposes(ws, D, I)
-    assert kept is not None and kept[0].shape == (2, I, 16) and kept[1].shape == (2, D, 2 * I)
-    for g, (wg, wu, wd) in enumerate(ws):
-        assert torch.equal(kept[0][g], wd.t()) and torch.equal(kept[1][g, :, :I], wg.t()) and torch.equal(kept[1][g, :, I:], wu.t())
-    assert ops._cached_weight_transposes(ws, D, I)[0] is kept[0]
-    ws[1][2].add_(1)                                    # in-place update = new version
-    assert ops._cached_weight_transposes(ws, D, I) is None
-    again = ops._cached_weight_transposes(ws, D, I)
-    assert again is not None and torch.equal(again[0][1], ws[1][2].t())
-
-
-def test_weight_transpose_cache_gives_the_copies_back_when_the_parameters_die():
-    """An entry lives as long as the tensors it describes (the module-level cache never evicted -- a deleted model kept
-    10 GB of transposed copies): deleting the weights drops the entry, and clear_weight_transpose_cache() empties it on demand."""
-    import gc
-    import torch
-    from unimoe_audio_amd import ops
-    ops.clear_weight_transpose_cache()
-    D, I = 16, 8
-    ws = [(torch.randn(I, D).to(torch.bfloat16), torch.randn(I, D).to(torch.bfloat16), torch.randn(D, I).to(torch.bfloat16))]
-    assert ops._cached_weight_transposes(ws, D, I) is None and ops._cached_weight_transposes(ws, D, I) is not None
-    assert len(ops._WT_CACHE) == 1
-    other = [(torch.randn(I, D).to(torch.bfloat16), torch.randn(I, D).to(torch.bfloat16), torch.randn(D, I).to(torch.bfloat16))]
-    ops._cached_weight_transposes(other, D, I)
-    assert len(ops._WT_CACHE) == 2
-    del ws
-    gc.collect()
-    assert len(ops._WT_CACHE) == 1                     # the dead model's entry (and its copies) are gone
-    ops.clear_weight_transpose_cache()
-    assert len(ops._WT_CACHE) == 0

@@ -52,7 +52,7 @@ class GemmArgs(C.Structure):
 
 class TGroup(C.Structure):
     _fields_ = [("w", vp), ("w2", vp), ("bias", vp), ("rows", vp), ("row_off", vp), ("count", vp), ("static_count", i32),
-                ("a_row_base", i32), ("out_row_base", i32), ("n", i32), ("k", i32), ("ldw", i32), ("a_col_off", i32), ("k_off", vp), ("k_count", vp), ("out_col_off", i32), ("k_compact_a", i32), ("k_compact_w", i32)]
+                ("a_row_base", i32), ("out_row_base", i32), ("n", i32), ("k", i32), ("ldw", i32), ("a_col_off", i32), ("k_off", vp), ("k_count", vp), ("out_col_off", i32), ("k_compact_a", i32), ("k_compact_w", i32), ("w_kmajor", i32), ("k_w1", i32)]
 
 
 class TGemmArgs(C.Structure):

@@ -912,8 +912,9 @@ static size_t swiglu_bwd_carve(const umoe_swiglu_bwd_args* a, void* ws, size_t c
                                uint16_t** dgu, uint16_t** xe, float** tn_ws) {
     WsCarver k(ws, cap);
     const int G = a->num_groups, D = a->D, I = a->I;
-    *wdT = k.take<uint16_t>((size_t)G * I * r8(D));        // per group [I][r8(D)]
-    *wguT = k.take<uint16_t>((size_t)G * D * 2 * I);       // per group [D][2I]
+    // (transposed weight copies only where the k-major weight read of umoe_tiled_gemm does not apply: I % 32 != 0)
+    *wdT = I % 32 ? k.take<uint16_t>((size_t)G * I * r8(D)) : nullptr;        // per group [I][r8(D)]
+    *wguT = I % 32 ? k.take<uint16_t>((size_t)G * D * 2 * I) : nullptr;       // per group [D][2I]
     *dh = k.take<uint16_t>((size_t)a->slot_rows * I);
     *dgu = k.take<uint16_t>((size_t)a->slot_rows * 2 * I);
     // routed experts: the gathered input rows in slot order (the weight-gradient product reads its operands by row window);
@@ -960,7 +961,11 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     int rc;
     // transposed weight copies: Wd^T [I][r8(D)], (Wg^T | Wu^T) [D][2I] -- the caller's, when it kept them (unchanged weights)
     UMOE_REQUIRE((a->w_down_T == nullptr) == (a->w_gateup_T == nullptr), "umoe_*_swiglu_bwd: w_down_T and w_gateup_T come together");
-    if (a->w_down_T) {
+    // input gradients on the weights AS STORED (umoe_tgroup_t.w_kmajor: the contraction index is the weight's row) -- no transposed copies;
+    // (dG | dU) runs against Wg then Wu in one contraction, which needs I % 32 == 0 (K tiles of 32 rows); otherwise the transposed copies
+    const bool kmaj = I % 32 == 0;
+    if (kmaj) {
+    } else if (a->w_down_T) {
         wdT = const_cast<uint16_t*>(a->w_down_T);
         wguT = const_cast<uint16_t*>(a->w_gateup_T);
     } else {
@@ -983,7 +988,11 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     };
     // dH = dY * Wd
     memset(tg, 0, sizeof(tg));
-    for (int g = 0; g < G; ++g) { tg[g].w = wdT + (size_t)g * I * r8(D); tg[g].n = I; tg[g].k = D; tg[g].ldw = r8(D); rows_of(tg[g], g); }
+    for (int g = 0; g < G; ++g) {
+        if (kmaj) { tg[g].w = a->w_down[g]; tg[g].w_kmajor = 1; tg[g].n = I; tg[g].k = D; tg[g].ldw = I; }       // Wd [D][I]: row = contraction index
+        else { tg[g].w = wdT + (size_t)g * I * r8(D); tg[g].n = I; tg[g].k = D; tg[g].ldw = r8(D); }
+        rows_of(tg[g], g);
+    }
     umoe_tgemm_args ta{};
     ta.groups = tg; ta.num_groups = G; ta.max_rows = S; ta.a = a->dy; ta.lda = a->lddy; ta.out = dh; ta.ldo = I; ta.epilogue = UMOE_EPI_BF16;
     if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
@@ -996,7 +1005,11 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     }
     // dX_slots = (dG | dU) * (Wg^T | Wu^T)^T
     memset(tg, 0, sizeof(tg));
-    for (int g = 0; g < G; ++g) { tg[g].w = wguT + (size_t)g * D * 2 * I; tg[g].n = D; tg[g].k = 2 * I; tg[g].ldw = 2 * I; rows_of(tg[g], g); }
+    for (int g = 0; g < G; ++g) {
+        if (kmaj) { tg[g].w = a->w_gate[g]; tg[g].w2 = a->w_up[g]; tg[g].w_kmajor = 1; tg[g].k_w1 = I; tg[g].n = D; tg[g].k = 2 * I; tg[g].ldw = D; }
+        else { tg[g].w = wguT + (size_t)g * D * 2 * I; tg[g].n = D; tg[g].k = 2 * I; tg[g].ldw = 2 * I; }
+        rows_of(tg[g], g);
+    }
     ta = umoe_tgemm_args{};
     ta.groups = tg; ta.num_groups = G; ta.max_rows = S; ta.a = dgu; ta.lda = 2 * I; ta.out = a->dx_slots; ta.ldo = a->lddx; ta.epilogue = UMOE_EPI_BF16;
     if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;

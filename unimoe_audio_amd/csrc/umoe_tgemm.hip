@@ -26,6 +26,8 @@
 #include <type_traits>
 #include <string.h>
 
+int umoe_tiled_gemm_nn_launch(const umoe_tgemm_args* a, int max_n, hipStream_t s);
+
 #define TG_MAXG 12
 struct tg_pack { umoe_tgroup_t g[TG_MAXG]; };
 
@@ -802,6 +804,7 @@ extern "C" int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream) {
     int max_n = 0;
     for (int i = 0; i < a->num_groups; ++i) {
         const umoe_tgroup_t& g = a->groups[i];
+        if (g.w_kmajor) { UMOE_REQUIRE(g.w && g.n > 0 && g.k > 0, "umoe_tiled_gemm: group %d: need w, n, k", i); if (g.n > max_n) max_n = g.n; continue; }
         UMOE_REQUIRE(g.w && g.n > 0 && (g.k_count || (g.k > 0 && g.k % 8 == 0 && g.ldw >= g.k)) && g.ldw % 8 == 0 && (g.a_col_off & 7) == 0,
                      "umoe_tiled_gemm: group %d: need w, n > 0, k %% 8 == 0, ldw %% 8 == 0 (n=%d k=%d ldw=%d)", i, g.n, g.k, g.ldw);
         UMOE_REQUIRE(a->epilogue != UMOE_EPI_SWIGLU || g.w2, "umoe_tiled_gemm: SwiGLU needs w2 (up_proj)");
@@ -836,8 +839,8 @@ extern "C" int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream) {
             flop += 2.0 * cnt * (double)g.n * kk * (a->epilogue == UMOE_EPI_SWIGLU ? 2 : 1);
         }
         const umoe_tgroup_t& g0 = a->groups[0];
-        fprintf(stderr, "TG epi=%d groups=%d max_rows=%d rows=%ld n=%d k=%d ragged=%d kwin=%d gather=%d pp=%d us=%.1f tflops=%.0f\n", a->epilogue, a->num_groups,
-                a->max_rows, rows_total, max_n, g0.k, g0.count != nullptr, g0.k_count != nullptr, g0.rows != nullptr, (int)tgemm_pp_pays(a, max_n), ms * 1e3,
+        fprintf(stderr, "TG epi=%d groups=%d max_rows=%d rows=%ld n=%d k=%d ragged=%d kwin=%d gather=%d pp=%d kmaj=%d us=%.1f tflops=%.0f\n", a->epilogue, a->num_groups,
+                a->max_rows, rows_total, max_n, g0.k, g0.count != nullptr, g0.k_count != nullptr, g0.rows != nullptr, (int)tgemm_pp_pays(a, max_n), g0.w_kmajor, ms * 1e3,
                 flop / (ms * 1e-3) * 1e-12);
         (void)hipEventDestroy(e0);
         (void)hipEventDestroy(e1);
@@ -845,6 +848,7 @@ extern "C" int umoe_tiled_gemm(const umoe_tgemm_args* a, umoe_stream_t stream) {
         return rc;
     }
 #endif
+    if (a->groups[0].w_kmajor) return umoe_tiled_gemm_nn_launch(a, max_n, s);      // (umoe_tgemm_tn.hip)
     switch (a->epilogue) {
         case UMOE_EPI_BF16: return launch_tgemm<UMOE_EPI_BF16>(a, max_n, s);
         case UMOE_EPI_BF16_RESID:

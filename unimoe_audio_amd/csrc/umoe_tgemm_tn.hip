@@ -229,6 +229,240 @@ __global__ __launch_bounds__(512, 2) void tgemm_tn_kernel(const umoe_tgemm_tn_ar
     }
 }
 
+// ------------------------------------------------------------------------------------ input gradients on the weights as stored ("NN")
+//   Y[rows(g)][n] = sum_k A[rows(g)][k] * W_g[k][n],   W_g row-major [K][ldw] with the CONTRACTION index as its row
+// -- dX = dY W for an nn.Linear weight W [N_out][K_in] as the optimizer holds it: no W^T copy (round 2 kept transposed copies of every
+// weight while the parameters were unchanged, +10.5 GB, and rebuilt them in every step of a trainer that steps after each backward).
+// The tile is tgemm_pp_kernel's; the token unit is its image (256 rows x 64 B, ds_read_b128), the weight unit is the k-major image of
+// tgemm_tn_kernel (transposing reads).  `w2` continues the contraction behind the first k_w1 rows of `w` ((dG | dU) against Wg then Wu).
+struct tn_tgpack { umoe_tgroup_t g[12]; };
+
+__global__ __launch_bounds__(512, 2) void tgemm_nn_kernel(const umoe_tgemm_args p, const tn_tgpack gp, const int nx, const int ny, const int nz, const int ragged_order,
+                                                           const unsigned total_wgs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = 4, AH = NS - 1;
+    constexpr int PAIR = 1088, UNITW = 16 * PAIR, UNITT = 256 * 64, SLOT = UNITW + UNITT;
+    int bx, by, bz;
+    {
+        const unsigned lin = blockIdx.x, xcd = lin & 7, seq = lin >> 3;
+        if (ragged_order) {
+            const unsigned rr = seq / (unsigned)nx;
+            bx = (int)(seq - rr * (unsigned)nx);
+            const unsigned RR = rr * 8 + xcd;
+            if (RR >= (unsigned)(ny * nz)) return;
+            bz = (int)(RR / (unsigned)ny);
+            by = (int)(RR - (unsigned)bz * (unsigned)ny);
+        } else {
+            const unsigned nwg = total_wgs, q = nwg >> 3, r = nwg & 7;
+            const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + seq;
+            bx = (int)(id % (unsigned)nx);
+            const unsigned RR = id / (unsigned)nx;
+            bz = (int)(RR / (unsigned)ny);
+            by = (int)(RR - (unsigned)bz * (unsigned)ny);
+        }
+    }
+    const umoe_tgroup_t g = gp.g[bz];
+    const int count = g.count ? *g.count : g.static_count;
+    const int roff = g.row_off ? *g.row_off : 0;
+    const int row0 = by * 256, n0 = bx * 256;
+    if (row0 >= count || n0 >= g.n) return;
+    const int K = g.k;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const char* zero = reinterpret_cast<const char*>(&tn_zero16);
+
+    // ---- weight unit (k-major): this wave stages the row pairs `wave`, `wave + 8`; two sources: w for tiles below sw, w2 behind
+    const int rodd = lane >> 5;
+    const int cl = (lane & 31) ^ (rodd << 1);
+    const int sw = g.w2 ? g.k_w1 >> 5 : 0x7fffffff;          // first K tile that comes from w2
+    long wdel[2], wdel2[2];
+    int rrow[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        rrow[q] = 8 * (wave >> 1) + 4 * q + 2 * (wave & 1) + rodd;
+        const int nc = n0 + 8 * cl;
+        wdel[q] = nc < g.n ? reinterpret_cast<const char*>(g.w + (long)rrow[q] * g.ldw + nc) - zero : 0;
+        wdel2[q] = (nc < g.n && g.w2) ? reinterpret_cast<const char*>(g.w2 + (long)rrow[q] * g.ldw + nc) - zero : 0;
+    }
+    const long wstep = 64 * (long)g.ldw;
+    // ---- token unit (contraction-contiguous rows, as in tgemm_pp_kernel): row groups `wave`, `wave + 8` of 16 rows
+    const int rl = lane >> 2, slot = lane & 3;
+    const int gch = slot ^ ((0 - (rl >> 2)) & 3);
+    long tdel[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int tr = (wave + 8 * q) * 16 + rl;
+        const int r = row0 + tr;
+        tdel[q] = 0;
+        if (r < count) {
+            const long arow = g.rows ? (long)g.rows[roff + r] : (long)(g.a_row_base + roff + r);
+            tdel[q] = reinterpret_cast<const char*>(p.a + arow * (long)p.lda + g.a_col_off + gch * 8) - zero;
+        }
+    }
+    auto stage_w = [&](const int tile) {
+        char* base = smem + (tile % NS) * SLOT;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const long live = (tile * 32 + rrow[q] < K) ? -1L : 0L;
+            const long src = tile < sw ? (wdel[q] == 0 ? 0 : wdel[q] + (long)tile * wstep) : (wdel2[q] == 0 ? 0 : wdel2[q] + (long)(tile - sw) * wstep);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(zero + (src & live)),
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * q) * PAIR), 16, 0, 0);
+        }
+    };
+    auto stage_t = [&](const int tile) {
+        const int k0 = tile * 32;
+        const long live = (k0 + gch * 8 < K) ? -1L : 0L;
+        char* base = smem + (tile % NS) * SLOT + UNITW;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const long d = tdel[q] == 0 ? 0 : ((tdel[q] + 2L * k0) & live);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(zero + d),
+                                             (__attribute__((address_space(3))) void*)(base + (wave + 8 * q) * 1024), 16, 0, 0);
+        }
+    };
+    const char* tptr[2];
+    const char* wptr[2];
+    long tinc[2], winc[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        tinc[q] = tdel[q] ? 64 : 0;
+        winc[q] = wdel[q] ? wstep : 0;
+        tptr[q] = zero + tdel[q] + AH * tinc[q];
+        wptr[q] = zero + wdel[q] + AH * winc[q];          // (re-based at the switch to w2, below)
+    }
+    auto run_w = [&](const int tile, const int slot_off) {
+        if (tile == sw) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wptr[q] = zero + wdel2[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wptr[q],
+                                             (__attribute__((address_space(3))) void*)(smem + slot_off + (wave + 8 * q) * PAIR), 16, 0, 0);
+            wptr[q] += winc[q];
+        }
+    };
+    auto run_t = [&](const int slot_off) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)tptr[q],
+                                             (__attribute__((address_space(3))) void*)(smem + slot_off + UNITW + (wave + 8 * q) * 1024), 16, 0, 0);
+            tptr[q] += tinc[q];
+        }
+    };
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int h = lane >> 4, c16 = lane & 15, rq = c16 >> 2, rp = c16 & 3;
+    const int wbase = (2 * h + (rq >> 1)) * PAIR + (rq & 1) * 512 + (rp & 1) * 8 + (((2 * wc + (rp >> 1)) ^ ((rq & 1) << 1)) << 4);   // fragment j: + 128 j
+    const int trow = 128 * wr + c16;
+    const int tbase = UNITW + trow * 64 + ((h ^ ((0 - (trow >> 2)) & 3)) << 4);                                                       // fragment i: + 1024 i
+    const unsigned lds0 = (unsigned)reinterpret_cast<size_t>(smem);
+    const int KT = (K + 31) >> 5;
+#pragma unroll
+    for (int u = 0; u < AH; ++u) {
+        stage_w(u);
+        stage_t(u);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    auto tile_step = [&](const int v, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int so = (v % NS) * SLOT;
+        const int sn = ((v + AH) % NS) * SLOT;
+        const unsigned Wf = lds0 + so + wbase;
+        const char* Tb = smem + so + tbase;
+        bf16x8_t wf[4], af[4];
+        tn_frags<4, 128, 0>(wf, Wf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + i * 1024));
+        if (STEADY) run_w(v + AH, sn);
+        else stage_w(v + AH);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + (4 + i) * 1024));
+        if (STEADY) run_t(sn);
+        else stage_t(v + AH);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    const int v_steady = KT - (AH + 1) > 0 ? KT - (AH + 1) : 0;
+    int v = 0;
+    for (; v < v_steady; ++v) tile_step(v, std::true_type{});
+    for (; v < KT; ++v) tile_step(v, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.out) + g.out_col_off;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = row0 + 128 * wr + 16 * i + c16;
+        if (r >= count) continue;
+        const long orow = (long)g.out_row_base + roff + r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + 16 * (4 * j + wc) + 4 * h;
+            if (col >= g.n) continue;
+            *reinterpret_cast<uint2*>(out + orow * (long)p.ldo + col) = make_uint2((uint32_t)f2bf(acc[j][i][0]) | ((uint32_t)f2bf(acc[j][i][1]) << 16),
+                                                                                   (uint32_t)f2bf(acc[j][i][2]) | ((uint32_t)f2bf(acc[j][i][3]) << 16));
+        }
+    }
+}
+
+// called by umoe_tiled_gemm when the groups' weights are k-major (umoe_tgroup_t.w_kmajor)
+int umoe_tiled_gemm_nn_launch(const umoe_tgemm_args* a, int max_n, hipStream_t s) {
+    UMOE_REQUIRE(a->epilogue == UMOE_EPI_BF16, "umoe_tiled_gemm: k-major weights (w_kmajor) take the plain bf16 epilogue only");
+    UMOE_REQUIRE((a->ldo & 3) == 0, "umoe_tiled_gemm: k-major weights: ldo must be a multiple of 4");
+    int ragged = 0;
+    for (int i = 0; i < a->num_groups; ++i) {
+        const umoe_tgroup_t& g = a->groups[i];
+        // (k need not be a multiple of 8: the weight rows behind k read as zeros; the activation's last 8-column chunk must lie inside
+        //  its row -- lda >= roundup8(k) -- and hold finite values, zeros as train._pad8 writes them)
+        UMOE_REQUIRE(g.w_kmajor && !g.bias && !g.k_off && !g.k_count && g.n % 8 == 0 && g.ldw % 8 == 0 && g.ldw >= g.n && (g.out_col_off & 3) == 0 &&
+                         (reinterpret_cast<size_t>(g.w) & 15) == 0 && g.a_col_off + ((g.k + 7) & ~7) <= a->lda,
+                     "umoe_tiled_gemm: group %d: k-major weights need n %% 8, ldw %% 8, no bias / K window, 16-byte aligned rows, lda >= roundup8(k) (all groups of a launch alike)", i);
+        UMOE_REQUIRE(!g.w2 || (g.k_w1 > 0 && g.k_w1 % 32 == 0 && g.k_w1 < g.k && (reinterpret_cast<size_t>(g.w2) & 15) == 0),
+                     "umoe_tiled_gemm: group %d: w2 continues the contraction behind k_w1 rows of w: 0 < k_w1 < k, k_w1 %% 32 == 0", i);
+        ragged |= g.count != nullptr;
+    }
+    tn_tgpack gp;
+    memset(&gp, 0, sizeof(gp));
+    memcpy(gp.g, a->groups, sizeof(umoe_tgroup_t) * a->num_groups);
+    constexpr int lds = 4 * (16 * 1088 + 256 * 64);
+    static bool configured = false;
+    if (!configured) {
+        UMOE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tgemm_nn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    const int nx = ceil_div(max_n, 256), ny = ceil_div(a->max_rows, 256), nz = a->num_groups;
+    const long nwg = ragged ? (long)nx * (((long)ny * nz + 7) & ~7L) : (long)nx * ny * nz;
+    UMOE_REQUIRE(nwg < (1L << 31), "umoe_tiled_gemm: too many tiles (%ld)", nwg);
+    tgemm_nn_kernel<<<dim3((unsigned)nwg), 512, lds, s>>>(*a, gp, nx, ny, nz, ragged, (unsigned)nwg);
+    UMOE_LAUNCH_CHECK();
+    return 0;
+}
+
 // fixed-order sum of the K-split partials: out = bf16(part 0 + part 1 + ...)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ parts, const long part_stride, const int nparts, const long n4, uint16_t* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

@@ -472,7 +472,7 @@ class _DCMoETrainFn(torch.autograd.Function):
         dWgate = torch.empty((16, D), dtype=bf, device=dev)                 # dl16^T x: the gate saw the jittered input
         ops.tiled_gemm_tn([dict(m=16, n=D, k=S)], dl16, jit(x) if gate_only else x, dWgate, k_split=-1)
         grads[0] = dWgate[:E]
-        dx_router = ops.tlinear(dl16, ops.transpose(params[0]))              # [S][16] x [D][16]^T
+        dx_router = ops.linear_input_grad(dl16, params[0])                   # [S][16 >= E] x [E][D], the gate weight as stored
         if gate_only:
             dx_router = jit(dx_router)
         # 7. input gradient: slot rows back to tokens + shared experts + router

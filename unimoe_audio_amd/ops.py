@@ -450,7 +450,11 @@ def tiled_gemm(groups: Sequence[dict], a: torch.Tensor, out: torch.Tensor, *, ma
         arr[i].static_count = int(g.get("static_count", 0))
         arr[i].a_row_base = int(g.get("a_row_base", 0))
         arr[i].out_row_base = int(g.get("out_row_base", 0))
-        arr[i].n, arr[i].k, arr[i].ldw = int(w.shape[0]), int(g.get("k", w.shape[1])), int(w.stride(0))
+        if g.get("w_kmajor"):                 # w [K][N]: the contraction index is the weight's row (input gradients on nn.Linear weights as stored)
+            arr[i].n, arr[i].k, arr[i].ldw, arr[i].w_kmajor = int(w.shape[1]), int(g.get("k", w.shape[0])), int(w.stride(0)), 1
+            arr[i].k_w1 = int(g.get("k_w1", 0))
+        else:
+            arr[i].n, arr[i].k, arr[i].ldw = int(w.shape[0]), int(g.get("k", w.shape[1])), int(w.stride(0))
         arr[i].a_col_off = int(g.get("a_col_off", 0))
         arr[i].out_col_off = int(g.get("out_col_off", 0))
     args = L.TGemmArgs(groups=C.cast(arr, C.c_void_p), num_groups=len(groups), max_rows=max_rows, a=_pv(a), lda=a.stride(0),
@@ -489,6 +493,15 @@ def tiled_gemm_tn(groups: Sequence[dict], p: torch.Tensor, q: torch.Tensor, out:
         args.ws = ws.data_ptr()
     L.check(L.lib().umoe_tiled_gemm_tn(C.byref(args), _stream()), "umoe_tiled_gemm_tn")
     return out
+
+
+def linear_input_grad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """dX [S][K] = dy[:, :N] W for y = x W^T with W [N][K] as stored (its row is the contraction index: umoe_tgroup_t.w_kmajor) -- no
+    transposed weight copy; dy may carry ZERO-padded columns behind N (row stride a multiple of 8)."""
+    S, (N, K) = dy.shape[0], w.shape
+    assert dy.shape[1] >= N and dy.stride(0) >= _r8(N)
+    out = torch.empty((S, K), dtype=torch.bfloat16, device=dy.device)
+    return tiled_gemm([dict(w=w, w_kmajor=1, static_count=S)], dy, out, max_rows=S)
 
 
 def linear_weight_grad(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
@@ -591,81 +604,6 @@ def rmsnorm_bwd(h: torch.Tensor, w: torch.Tensor, dy: torch.Tensor, eps: float, 
     return dh, dw
 
 
-# Transposed expert-weight copies kept across calls while the weights are unchanged (gradient accumulation: several backward passes
-# per optimizer step).  Keyed by the first weight's storage; an entry is BUILT only when two consecutive calls saw the same parameter
-# versions (a trainer that steps the optimizer after every backward never pays for a copy it cannot reuse) and replaced when they change.
-_WT_CACHE: dict = {}
-
-
-def _wt_cache_on() -> bool:
-    import os
-    return os.environ.get("UMOE_WT_CACHE", "1") != "0"
-
-
-def clear_weight_transpose_cache() -> None:
-    """Drops every kept transposed weight copy (they come back on the second backward over unchanged parameters)."""
-    _WT_CACHE.clear()
-
-
-def _wt_cache_put(key, ver, tensors) -> None:
-    """New (empty) entry.  An entry lives exactly as long as the parameters it describes: each tensor's finalizer drops it, so a
-    deleted model gives its transposed copies back; a sweep on insert removes entries whose tensors are gone already."""
-    import weakref
-    for k in [k for k, e in _WT_CACHE.items() if any(r() is None for r in e["refs"])]:
-        _WT_CACHE.pop(k, None)
-    ent = dict(ver=ver, t=None, refs=[weakref.ref(t) for t in tensors])
-    _WT_CACHE[key] = ent
-
-    def _drop(key=key, ent_id=id(ent)):
-        cur = _WT_CACHE.get(key)
-        if cur is not None and id(cur) == ent_id:
-            _WT_CACHE.pop(key, None)
-
-    for t in tensors:
-        weakref.finalize(t, _drop)
-
-
-def _cached_weight_transposes(ws_list, D: int, I: int):
-    if not _wt_cache_on():
-        return None
-    import weakref
-    key = ws_list[0][0].data_ptr()
-    ver = tuple((t.data_ptr(), t._version) for w in ws_list for t in w)
-    ent = _WT_CACHE.get(key)
-    # (address + version can repeat when a model is freed and another one lands on the same memory: the entry also has to be about
-    #  the very same tensor OBJECTS, which the weak references can only return while those are alive)
-    if ent is not None and ent["ver"] == ver and all(r() is t for r, t in zip(ent["refs"], (t for w in ws_list for t in w))):
-        if ent["t"] is None:                         # second call with these versions: worth keeping the copies
-            G, Dp = len(ws_list), _r8(D)
-            dev = ws_list[0][0].device
-            wdT = torch.zeros((G, I, Dp), dtype=torch.bfloat16, device=dev)
-            wguT = torch.empty((G, D, 2 * I), dtype=torch.bfloat16, device=dev)
-            for g, (wg, wu, wd) in enumerate(ws_list):
-                wdT[g, :, :D] = wd.detach().t()
-                wguT[g, :, :I] = wg.detach().t()
-                wguT[g, :, I:] = wu.detach().t()
-            ent["t"] = (wdT, wguT)
-        return ent["t"]
-    _wt_cache_put(key, ver, [t for w in ws_list for t in w])
-    return None
-
-
-def transpose_weight_cached(w: torch.Tensor) -> torch.Tensor:
-    """transpose(w) for an input-gradient GEMM; a PARAMETER's copy is kept while its version is unchanged (same two-call rule)."""
-    if not (w.is_leaf and w.requires_grad and _wt_cache_on()):
-        return transpose(w)
-    import weakref
-    key = ("lin", w.data_ptr())
-    ver = (w.data_ptr(), w._version, tuple(w.shape))
-    ent = _WT_CACHE.get(key)
-    if ent is not None and ent["ver"] == ver and ent["refs"][0]() is w:
-        if ent["t"] is None:
-            ent["t"] = transpose(w.detach())
-        return ent["t"]
-    _wt_cache_put(key, ver, [w])
-    return transpose(w)
-
-
 def experts_swiglu_bwd(ws_list, *, x, h, gu, dy, dx_slots, D: int, I: int, max_rows: int, counts=None, offsets=None, slot_token=None,
                        row_base: int = 0):
     """umoe_grouped_swiglu_bwd (counts/offsets given: routed experts) or umoe_shared_swiglu_bwd (static groups).
@@ -686,9 +624,6 @@ def experts_swiglu_bwd(ws_list, *, x, h, gu, dy, dx_slots, D: int, I: int, max_r
     nbytes = L.lib().umoe_swiglu_bwd_workspace_bytes(C.byref(a))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     a.ws, a.ws_bytes = ws.data_ptr(), nbytes
-    kept = _cached_weight_transposes(ws_list, D, I)
-    if kept is not None:
-        a.w_down_T, a.w_gateup_T = kept[0].data_ptr(), kept[1].data_ptr()
     fn = L.lib().umoe_grouped_swiglu_bwd if counts is not None else L.lib().umoe_shared_swiglu_bwd
     L.check(fn(C.byref(a), _stream()), "umoe_swiglu_bwd (composite)")
     return dwg, dwu, dwd

@@ -5,7 +5,7 @@ torch itself only owns the tape, the tensors and a few glue elementwise ops (res
 Reference graph: Qwen2_5_VLMoEDecoderLayer.forward utils/UniMoE_Audio_model.py:210-256, text model :319-457,
 training loss :817-854; attention / RMSNorm / mRoPE arithmetic = the transformers classes imported at :52-56.
 
-Backward of the contractions: umoe_tiled_gemm needs K-contiguous operands, so dX = dY W uses a transposed weight copy and
+Backward of the contractions: dX = dY W reads the weight as stored (k-major operand of umoe_tiled_gemm, transposing LDS reads) and
 dW = dY^T X runs on the row-major activations themselves (umoe_tiled_gemm_tn, transposing LDS reads; K split chosen by the library).  Attention backward is the
 "unfused" first version: scores are materialised per (row, kv head) group, P is recomputed, every contraction is a tiled
 GEMM (see umoe_bwd.hip).  No CPU fallback: CPU tensors raise.
@@ -46,7 +46,7 @@ class LinearFn(torch.autograd.Function):
         dy = dy.to(torch.bfloat16).contiguous()
         S = x.shape[0]
         dy8 = _pad8(dy)
-        dx = ops.tlinear(dy8, ops.transpose_weight_cached(w)) if ctx.needs_input_grad[0] else None   # [S][N] x [K][N]^T
+        dx = ops.linear_input_grad(dy8, w) if ctx.needs_input_grad[0] else None            # [S][N] x [N][K], the weight as stored
         dw = None
         if ctx.needs_input_grad[1]:
             dw = ops.linear_weight_grad(dy8, x, w)
@@ -256,7 +256,7 @@ class _HeadFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dyb = dy.to(torch.bfloat16).contiguous()
         dy8 = _pad8(dyb)
-        return ops.tlinear(dy8, ops.transpose_weight_cached(w)), ops.linear_weight_grad(dy8, x, w)
+        return ops.linear_input_grad(dy8, w), ops.linear_weight_grad(dy8, x, w)
 
 
 def ops_f32_head(x, w):
