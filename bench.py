@@ -297,25 +297,41 @@ def cpu_baseline(args, batch=None, steps=None):
     cache = [(torch.randn(rows, KV, L, hd).to(bf), torch.randn(rows, KV, L, hd).to(bf)) for _ in range(cfg.num_hidden_layers)]
     key_valid = torch.ones(rows, L, dtype=torch.bool)
     tok = torch.randint(0, 1024, (B, 1, cfg.codec_channels))
-    times = []
+    state = {"kv": key_valid, "cache": cache, "tok": tok}
+
+    def one_step():
+        t0 = time.perf_counter()
+        kv = torch.cat([state["kv"], torch.ones(rows, 1, dtype=torch.bool)], -1)
+        pos = (kv.long().cumsum(-1) - 1)[:, -1:]
+        h, c2, _ = tm.forward(OD.codec_embedding(cfg, w, state["tok"].repeat_interleave(2, dim=0)), kv, pos, state["cache"])
+        logits = torch.nn.functional.linear(h, w["codec_head.weight"]).float().view(rows, -1, cfg.codec_channels, cfg.codec_vocab_size)[:, -1]
+        guided = OD.cfg_and_mask(cfg, logits, 3.0, False, 0.8)
+        pred = OD.sample_next_token(guided.reshape(B * cfg.codec_channels, -1), 1.2, 0.95, 45, cfg.codec_eos_value)
+        state.update(kv=kv, cache=c2, tok=pred.view(B, 1, cfg.codec_channels))
+        return time.perf_counter() - t0
+
+    times, probe = [], {}
     with torch.no_grad():
-        for s in range(n_steps + 2):
-            t0 = time.perf_counter()
-            key_valid = torch.cat([key_valid, torch.ones(rows, 1, dtype=torch.bool)], -1)
-            pos = (key_valid.long().cumsum(-1) - 1)[:, -1:]
-            h, cache, _ = tm.forward(OD.codec_embedding(cfg, w, tok.repeat_interleave(2, dim=0)), key_valid, pos, cache)
-            logits = torch.nn.functional.linear(h, w["codec_head.weight"]).float().view(rows, -1, cfg.codec_channels, cfg.codec_vocab_size)[:, -1]
-            guided = OD.cfg_and_mask(cfg, logits, 3.0, False, 0.8)
-            pred = OD.sample_next_token(guided.reshape(B * cfg.codec_channels, -1), 1.2, 0.95, 45, cfg.codec_eos_value)
-            tok = pred.view(B, 1, cfg.codec_channels)
-            times.append(time.perf_counter() - t0)
+        one_step()                                       # warm-up: thread pool, page faults of the 14 GB of weights
+        one_step()
+        # thread count: one per physical core is SURVEY 8d's rule, but a 16-row step on 128 cores of two sockets is dominated by the
+        # fork/join of many small ops -- time one step at a few counts and keep the fastest for the sample
+        top = max(1, min(n_phys, usable))
+        for nt in sorted({top, max(1, top // 2), max(1, top // 4), min(top, 16)}, reverse=True):
+            torch.set_num_threads(nt)
+            one_step()                                   # (settle the pool at this size)
+            probe[nt] = round(one_step() * 1e3, 1)
+        torch.set_num_threads(min(probe, key=probe.get))
+        for s in range(n_steps):
+            times.append(one_step())
+    times = [0.0, 0.0] + times
     steady = sorted(times[2:])                           # first two steps = warm-up (thread pool, page faults of the 14 GB of weights)
     sec = steady[len(steady) // 2]                       # median
     return {"value": round(B / sec, 3), "unit": "audio-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "cpu_model": cpu_model, "physical_cores": n_phys, "logical_cpus_usable": usable,
+            "cpu_model": cpu_model, "physical_cores": n_phys, "logical_cpus_usable": usable, "ms_per_step_by_threads": probe,
             "router": "C oracle (oracle/router_oracle.c through liboracle_router.so), not the reference's per-k Python loop: the port is "
                       "not op-for-op the reference, its routing is faster than the reference's",
-            "sample": f"median of {len(steady)} decode steps (after 2 warm-up steps) of the full {cfg.num_hidden_layers}-layer model, batch {B} "
+            "sample": f"median of {len(steady)} decode steps (after 2 warm-up steps and a probe of the thread count: the fastest of {sorted(probe)} is used) of the full {cfg.num_hidden_layers}-layer model, batch {B} "
                       f"({2 * B} CFG rows), synthetic KV cache of {L} tokens, torch-CPU bf16 oracle (oracle/decode.py), "
                       f"{sec * 1e3:.0f} ms/step"}
 
