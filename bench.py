@@ -317,7 +317,7 @@ def cpu_baseline(args, batch=None, steps=None):
         # thread count: one per physical core is SURVEY 8d's rule, but a 16-row step on 128 cores of two sockets is dominated by the
         # fork/join of many small ops -- time one step at a few counts and keep the fastest for the sample
         top = max(1, min(n_phys, usable))
-        for nt in sorted({top, max(1, top // 2), max(1, top // 4), min(top, 16)}, reverse=True):
+        for nt in sorted({top, max(1, top // 2), max(1, top // 4), min(top, 16), min(top, 8)}, reverse=True):
             torch.set_num_threads(nt)
             one_step()                                   # (settle the pool at this size)
             probe[nt] = round(one_step() * 1e3, 1)
