@@ -41,7 +41,8 @@ def parse():
                     help="0 = the reference's 12 channels (16 kHz DAC, 50 frames/s); 9 = the 44.1 kHz reading of BASELINE (SURVEY 8d: delay [0,8..15], 86.1 frames/s)")
     ap.add_argument("--parallel", default="auto", choices=["auto", "ep", "replica"],
                     help="N > 1: ep = expert-parallel decode (BASELINE configs[3] layout: batch-sharded rows, n_real/N routed experts per "
-                         "GPU, exchange inside the step graph); replica = N independent full models; auto = ep")
+                         "GPU, exchange inside the step graph); replica = N independent full models; auto = both are timed (they give the "
+                         "same tokens), `value` is the faster one and the other is reported beside it")
     ap.add_argument("--ep-backend", default=os.environ.get("UMOE_EP_BACKEND", "peer"), choices=["peer", "rccl"],
                     help="exchange of the expert-parallel step: xGMI peer stores (default) or RCCL calls captured in the graph")
     ap.add_argument("--ep-emulate", type=int, default=0,
@@ -397,6 +398,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # the contract is ONE JSON line on stdout: native libraries (gloo's "[Gloo] Rank 0 is connected ..." banner) write to fd 1 too, so in a
+    # multi-rank run everything written to fd 1 goes to stderr and the line goes to the saved descriptor
+    line_fd = 1
+    if world > 1:
+        sys.stdout.flush()
+        line_fd = os.dup(1)
+        os.dup2(2, 1)
     ndev = torch.cuda.device_count()                   # (does not initialise the GPU)
     if ndev < 1:
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
@@ -464,18 +472,27 @@ def main():
             notes["ep"] = "no expert-parallel backend worked on this node: `value` is the replica number"
     rep_info = None
     if mode != "ep" or not args.no_replica_check:
-        rep_info = decode_leg(model, cfg, args, device, rank, B, profile=(mode != "ep"))
+        rep_info = decode_leg(model, cfg, args, device, rank, B)
+    if mode == "ep" and rep_info is not None:
+        # both layouts were timed with the same K steps and give the same tokens (checked below): `auto` reports the faster one as `value`
+        # and names the other in config; --parallel ep keeps the expert-parallel number whatever the replicas do
+        t_ep, t_rep = max_over_ranks(ep_info["dt"]), max_over_ranks(rep_info["dt"])
+        same = float(torch.equal(ep_info["tokens"], rep_info["tokens"]))
+        notes["ep_tokens_equal_replica"] = bool(-max_over_ranks(-same) >= 1.0)
+        notes["ep_value"] = round(world * B * K / t_ep, 2)
+        notes["ep_ms_per_step"] = round(t_ep / K * 1e3, 4)
+        notes["ep_backend_used"] = ep_info["backend"]
+        notes["replica_value"] = round(world * B * K / t_rep, 2)
+        notes["replica_ms_per_step"] = round(t_rep / K * 1e3, 4)
+        if args.parallel == "auto" and t_rep < t_ep:
+            mode = "replica"
+            notes["parallelism_choice"] = "auto: the N independent replicas were faster than the expert-parallel layout on this node; both numbers above"
+        elif args.parallel == "auto":
+            notes["parallelism_choice"] = "auto: the expert-parallel layout was faster than N independent replicas on this node; both numbers above"
     info = ep_info if mode == "ep" else rep_info
     dt = max_over_ranks(info["dt"])                                     # the slowest rank defines the step time
     out = None
-    if rank == 0 or mode == "ep":
-        value = world * B * K / dt
-    if mode == "ep" and rep_info is not None:
-        # secondary: N independent replicas on the same prompts and seeds; the expert-parallel tokens must equal them bit for bit
-        same = float(torch.equal(ep_info["tokens"], rep_info["tokens"]))
-        notes["ep_tokens_equal_replica"] = bool(-max_over_ranks(-same) >= 1.0)
-        notes["replica_value"] = round(world * B * K / max_over_ranks(rep_info["dt"]), 2)
-        notes["replica_ms_per_step"] = round(max_over_ranks(rep_info["dt"]) / K * 1e3, 4)
+    value = world * B * K / dt
     if rank == 0:
         ep = world if mode == "ep" else 1
         info_dt = dict(info)
@@ -540,7 +557,8 @@ def main():
                     out["config1"]["cpu_baseline"] = cpu_baseline(args, batch=1, steps=3)
             except Exception as e:  # the GPU number must not be lost to a host-side problem
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
