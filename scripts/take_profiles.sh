@@ -10,13 +10,13 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-config1 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-config1 --no-config3 --no-config5 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err
 T=$(find $OUT/prof_$TAG -name "*kernel_trace.csv" | head -1)
 S=$(find $OUT/prof_$TAG -name "*kernel_stats.csv" | head -1)
 python3 $ROOT/scripts/summarize_trace.py $T > $OUT/${TAG}_decode_kernels.md
 [ -n "$S" ] && head -40 $S > $OUT/${TAG}_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -o f -- python3 $ROOT/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-config1 > $OUT/${TAG}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -o w -- python3 $ROOT/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-config1 > $OUT/${TAG}_pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -o f -- python3 $ROOT/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-config1 --no-config3 --no-config5 > $OUT/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -o w -- python3 $ROOT/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-config1 --no-config3 --no-config5 > $OUT/${TAG}_pmc_write.log 2>&1
 python3 $ROOT/scripts/summarize_pmc.py $OUT/pmc_fetch_$TAG $OUT/pmc_write_$TAG $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_traffic.md
 TAG=$TAG OUT=$OUT python3 - <<'PY'
 import json, os
