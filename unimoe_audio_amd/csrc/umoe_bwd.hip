@@ -942,6 +942,30 @@ __global__ __launch_bounds__(256) void gather_slots_kernel(const uint16_t* __res
     }
 }
 
+// The weight-gradient products are off the dependency chain of a backward pass (nothing in the pass reads dW): they run on a SIDE stream
+// beside the input-gradient chain, forked and joined INSIDE the call (events), so the HBM-bound kernels of the chain (SwiGLU backward, the
+// row gather) and the round tails of the GEMMs overlap with them.  UMOE_BWD_OVERLAP=0: everything on the caller's stream.
+struct BwdSide {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
+    bool ok = false;
+};
+static BwdSide& bwd_side() {
+    static BwdSide b;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* v = getenv("UMOE_BWD_OVERLAP");
+        if (!(v && atoi(v) == 0)) {
+            b.ok = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&b.fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&b.mid, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&b.join, hipEventDisableTiming) == hipSuccess;
+        }
+    }
+    return b;
+}
+
 // backward of down(silu(gate x) * up x) over groups of rows (core.py:16-49,406-416):
 //   dH = dY Wd ; (dG | dU) = swiglu'(G, U, dH) ; dX_slots = dG Wg + dU Wu ; dWd = dY^T H ; dWg = dG^T X ; dWu = dU^T X
 // ragged groups (routed experts): counts/offsets (8-aligned, umoe_dispatch_build_aligned) + optional gather list for x;
@@ -986,6 +1010,75 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
         if (ragged) { t.row_off = a->offsets + g; t.count = a->counts + g; }
         else { t.static_count = S; t.a_row_base = a->row_base + g * S; t.out_row_base = a->row_base + g * S; }
     };
+    // ---- weight gradients straight from the row-major slot buffers (umoe_tiled_gemm_tn; round 2 wrote dY^T, H^T, (dG|dU)^T and X^T first):
+    //   dWd_g [D][I] = dY_g^T H_g ; (dWg_g ; dWu_g) [I][D] = (dG_g | dU_g)^T X_g
+    // routed experts: ONE grouped launch per product kind with the experts' slot windows read on the device (gate and up together:
+    // 2 G groups); shared experts: static windows, the K split chosen by the library when the outputs of a launch are one stacked slab
+    // (ops.experts_swiglu_bwd allocates them so).
+    auto stacked = [&](uint16_t* const* ptrs, size_t elems) {
+        for (int g = 1; g < G; ++g)
+            if (ptrs[g] != ptrs[0] + (size_t)g * elems) return false;
+        return true;
+    };
+    umoe_tn_group_t tn[24];
+    auto wgrad_down = [&](umoe_stream_t st) -> int {
+        umoe_tgemm_tn_args b{};
+        memset(tn, 0, sizeof(tn));
+        if (ragged) {
+            for (int g = 0; g < G; ++g) {
+                tn[g].m = D; tn[g].n = I; tn[g].k_off_dev = a->offsets + g; tn[g].k_count_dev = a->counts + g; tn[g].out = a->dw_down[g];
+            }
+        } else {       // shared experts: group g owns the slot rows [row_base + g S, + S) of dY / H
+            const bool slab = stacked(a->dw_down, (size_t)D * I);
+            for (int g = 0; g < G; ++g) {
+                const size_t r0 = (size_t)a->row_base + (size_t)g * S;
+                tn[g].m = D; tn[g].n = I; tn[g].k = S;
+                tn[g].p = a->dy + r0 * a->lddy; tn[g].ldp = a->lddy; tn[g].q = a->h + r0 * a->ldh; tn[g].ldq = a->ldh;
+                if (slab) tn[g].out_row_base = g * D; else tn[g].out = a->dw_down[g];
+            }
+            if (slab) { b.k_split = -1; b.ws = tn_ws; b.part_stride = (long)G * D * I; }
+        }
+        b.groups = tn; b.num_groups = G; b.p = a->dy; b.ldp = a->lddy; b.q = a->h; b.ldq = a->ldh; b.out = a->dw_down[0]; b.ldo = I;
+        return umoe_tiled_gemm_tn(&b, st);
+    };
+    auto wgrad_gateup = [&](umoe_stream_t st) -> int {
+        umoe_tgemm_tn_args b{};
+        memset(tn, 0, sizeof(tn));
+        if (ragged) {
+            gather_slots_kernel<<<dim3((unsigned)(S < 2048 ? ceil_div(S, 4) : 512), (unsigned)G), 256, 0, (hipStream_t)st>>>(a->x, a->ldx, D, a->slot_token, a->counts, a->offsets, xe);
+            UMOE_LAUNCH_CHECK();
+            for (int g = 0; g < G; ++g) {
+                tn[g].m = I; tn[g].n = D; tn[g].k_off_dev = a->offsets + g; tn[g].k_count_dev = a->counts + g; tn[g].out = a->dw_gate[g];
+                tn[G + g] = tn[g];
+                tn[G + g].p_col_off = I; tn[G + g].out = a->dw_up[g];
+            }
+            b.q = xe; b.ldq = D;
+        } else {       // ... and of (dG | dU); x is read by identity (rows 0 .. S-1)
+            const bool slab = stacked(a->dw_gate, (size_t)I * D) && stacked(a->dw_up, (size_t)I * D) && a->dw_up[0] == a->dw_gate[0] + (size_t)G * I * D;
+            for (int g = 0; g < G; ++g) {
+                const size_t r0 = (size_t)a->row_base + (size_t)g * S;
+                tn[g].m = I; tn[g].n = D; tn[g].k = S;
+                tn[g].p = dgu + r0 * 2 * I; tn[g].ldp = 2 * I;
+                if (slab) tn[g].out_row_base = g * I; else tn[g].out = a->dw_gate[g];
+                tn[G + g] = tn[g];
+                tn[G + g].p_col_off = I;
+                if (slab) tn[G + g].out_row_base = (G + g) * I; else tn[G + g].out = a->dw_up[g];
+            }
+            if (slab) { b.k_split = -1; b.ws = tn_ws; b.part_stride = (long)2 * G * I * D; }
+            b.q = a->x; b.ldq = a->ldx;
+        }
+        b.groups = tn; b.num_groups = 2 * G; b.p = dgu; b.ldp = 2 * I; b.out = a->dw_gate[0]; b.ldo = D;
+        return umoe_tiled_gemm_tn(&b, st);
+    };
+    // fork: dWd needs only the call's inputs
+    BwdSide& bs = bwd_side();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool overlap = bs.ok && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    if (overlap) {
+        UMOE_HIP(hipEventRecord(bs.fork, (hipStream_t)stream));
+        UMOE_HIP(hipStreamWaitEvent(bs.side, bs.fork, 0));
+        if ((rc = wgrad_down(bs.side))) return rc;
+    }
     // dH = dY * Wd
     memset(tg, 0, sizeof(tg));
     for (int g = 0; g < G; ++g) {
@@ -1003,6 +1096,12 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
         const size_t r0 = (size_t)a->row_base;
         if ((rc = umoe_swiglu_bwd(dh + r0 * I, I, a->gu + r0 * a->ldgu, a->ldgu, I, nullptr, G * S, dgu + r0 * 2 * I, 2 * I, stream))) return rc;
     }
+    if (overlap) {      // (dG | dU) exists: the side stream takes dWg / dWu while this one computes dX
+        UMOE_HIP(hipEventRecord(bs.mid, (hipStream_t)stream));
+        UMOE_HIP(hipStreamWaitEvent(bs.side, bs.mid, 0));
+        if ((rc = wgrad_gateup(bs.side))) return rc;
+        UMOE_HIP(hipEventRecord(bs.join, bs.side));
+    }
     // dX_slots = (dG | dU) * (Wg^T | Wu^T)^T
     memset(tg, 0, sizeof(tg));
     for (int g = 0; g < G; ++g) {
@@ -1013,68 +1112,12 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     ta = umoe_tgemm_args{};
     ta.groups = tg; ta.num_groups = G; ta.max_rows = S; ta.a = dgu; ta.lda = 2 * I; ta.out = a->dx_slots; ta.ldo = a->lddx; ta.epilogue = UMOE_EPI_BF16;
     if ((rc = umoe_tiled_gemm(&ta, stream))) return rc;
-    // Weight gradients straight from the row-major slot buffers (umoe_tiled_gemm_tn; round 2 wrote dY^T, H^T, (dG|dU)^T and X^T first):
-    //   dWd_g [D][I] = dY_g^T H_g ; (dWg_g ; dWu_g) [I][D] = (dG_g | dU_g)^T X_g
-    // routed experts: ONE grouped launch per product kind with the experts' slot windows read on the device (gate and up together:
-    // 2 G groups); shared experts: static windows, the K split chosen by the library when the outputs of a launch are one stacked slab
-    // (ops.experts_swiglu_bwd allocates them so).
-    auto stacked = [&](uint16_t* const* ptrs, size_t elems) {
-        for (int g = 1; g < G; ++g)
-            if (ptrs[g] != ptrs[0] + (size_t)g * elems) return false;
-        return true;
-    };
-    umoe_tn_group_t tn[24];
-    if (ragged) {
-        gather_slots_kernel<<<dim3((unsigned)(S < 2048 ? ceil_div(S, 4) : 512), (unsigned)G), 256, 0, (hipStream_t)stream>>>(a->x, a->ldx, D, a->slot_token, a->counts, a->offsets, xe);
-        UMOE_LAUNCH_CHECK();
-        umoe_tgemm_tn_args b{};
-        memset(tn, 0, sizeof(tn));
-        for (int g = 0; g < G; ++g) {
-            tn[g].m = D; tn[g].n = I; tn[g].k_off_dev = a->offsets + g; tn[g].k_count_dev = a->counts + g; tn[g].out = a->dw_down[g];
-        }
-        b.groups = tn; b.num_groups = G; b.p = a->dy; b.ldp = a->lddy; b.q = a->h; b.ldq = a->ldh; b.out = a->dw_down[0]; b.ldo = I;
-        if ((rc = umoe_tiled_gemm_tn(&b, stream))) return rc;
-        memset(tn, 0, sizeof(tn));
-        for (int g = 0; g < G; ++g) {
-            tn[g].m = I; tn[g].n = D; tn[g].k_off_dev = a->offsets + g; tn[g].k_count_dev = a->counts + g; tn[g].out = a->dw_gate[g];
-            tn[G + g] = tn[g];
-            tn[G + g].p_col_off = I; tn[G + g].out = a->dw_up[g];
-        }
-        b.groups = tn; b.num_groups = 2 * G; b.p = dgu; b.ldp = 2 * I; b.q = xe; b.ldq = D; b.out = a->dw_gate[0]; b.ldo = D;
-        return umoe_tiled_gemm_tn(&b, stream);
+    if (overlap) {
+        UMOE_HIP(hipStreamWaitEvent((hipStream_t)stream, bs.join, 0));      // join: the caller's stream continues behind the weight gradients
+        return 0;
     }
-    // shared experts: group g owns the slot rows [row_base + g S, + S) of dY / H / (dG|dU) and reads x by identity (rows 0 .. S-1)
-    const bool down_slab = stacked(a->dw_down, (size_t)D * I);
-    const bool gu_slab = stacked(a->dw_gate, (size_t)I * D) && stacked(a->dw_up, (size_t)I * D) && a->dw_up[0] == a->dw_gate[0] + (size_t)G * I * D;
-    {
-        umoe_tgemm_tn_args b{};
-        memset(tn, 0, sizeof(tn));
-        for (int g = 0; g < G; ++g) {
-            const size_t r0 = (size_t)a->row_base + (size_t)g * S;
-            tn[g].m = D; tn[g].n = I; tn[g].k = S;
-            tn[g].p = a->dy + r0 * a->lddy; tn[g].ldp = a->lddy; tn[g].q = a->h + r0 * a->ldh; tn[g].ldq = a->ldh;
-            if (down_slab) tn[g].out_row_base = g * D; else tn[g].out = a->dw_down[g];
-        }
-        b.groups = tn; b.num_groups = G; b.p = a->dy; b.ldp = a->lddy; b.q = a->h; b.ldq = a->ldh; b.out = a->dw_down[0]; b.ldo = I;
-        if (down_slab) { b.k_split = -1; b.ws = tn_ws; b.part_stride = (long)G * D * I; }
-        if ((rc = umoe_tiled_gemm_tn(&b, stream))) return rc;
-    }
-    {
-        umoe_tgemm_tn_args b{};
-        memset(tn, 0, sizeof(tn));
-        for (int g = 0; g < G; ++g) {
-            const size_t r0 = (size_t)a->row_base + (size_t)g * S;
-            tn[g].m = I; tn[g].n = D; tn[g].k = S;
-            tn[g].p = dgu + r0 * 2 * I; tn[g].ldp = 2 * I;
-            if (gu_slab) tn[g].out_row_base = g * I; else tn[g].out = a->dw_gate[g];
-            tn[G + g] = tn[g];
-            tn[G + g].p_col_off = I;
-            if (gu_slab) tn[G + g].out_row_base = (G + g) * I; else tn[G + g].out = a->dw_up[g];
-        }
-        b.groups = tn; b.num_groups = 2 * G; b.p = dgu; b.ldp = 2 * I; b.q = a->x; b.ldq = a->ldx; b.out = a->dw_gate[0]; b.ldo = D;
-        if (gu_slab) { b.k_split = -1; b.ws = tn_ws; b.part_stride = (long)2 * G * I * D; }
-        return umoe_tiled_gemm_tn(&b, stream);
-    }
+    if ((rc = wgrad_down(stream))) return rc;
+    return wgrad_gateup(stream);
 }
 
 extern "C" int umoe_grouped_swiglu_bwd(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) {

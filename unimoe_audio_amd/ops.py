@@ -513,6 +513,31 @@ def linear_weight_grad(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> to
     return tiled_gemm_tn([dict(m=N, n=K, k=x.shape[0])], dy, x, dw, k_split=-1)
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def linear_grads(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx: bool = True, need_dw: bool = True):
+    """(dX, dW) of y = x W^T.  Nothing in a backward pass reads dW, so when both are wanted the weight gradient runs on a SIDE stream beside
+    the input gradient (fork / join inside this call, like the expert composite in umoe_bwd.hip): the round tails of the two GEMMs and the
+    K-split reduction overlap.  UMOE_BWD_OVERLAP=0: both on the current stream."""
+    import os
+    if not (need_dx and need_dw) or os.environ.get("UMOE_BWD_OVERLAP", "1") == "0":
+        return (linear_input_grad(dy, w) if need_dx else None), (linear_weight_grad(dy, x, w) if need_dw else None)
+    main = torch.cuda.current_stream()
+    side = _SIDE_STREAMS.get(dy.device)
+    if side is None:
+        side = _SIDE_STREAMS[dy.device] = torch.cuda.Stream(device=dy.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw = linear_weight_grad(dy, x, w)
+    dy.record_stream(side)          # (the caching allocator must not hand these blocks out again before the side stream is through)
+    x.record_stream(side)
+    dx = linear_input_grad(dy, w)
+    main.wait_stream(side)
+    dw.record_stream(main)
+    return dx, dw
+
+
 def tlinear(x: torch.Tensor, w: torch.Tensor, *, bias: Optional[torch.Tensor] = None, resid=None, out_f32=False) -> torch.Tensor:
     """y = x @ w^T (+bias) (+resid) with row-major w [N, K]: the tiled MFMA path for many rows."""
     S = x.shape[0]

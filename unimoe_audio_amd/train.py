@@ -45,11 +45,7 @@ class LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dy = dy.to(torch.bfloat16).contiguous()
         S = x.shape[0]
-        dy8 = _pad8(dy)
-        dx = ops.linear_input_grad(dy8, w) if ctx.needs_input_grad[0] else None            # [S][N] x [N][K], the weight as stored
-        dw = None
-        if ctx.needs_input_grad[1]:
-            dw = ops.linear_weight_grad(dy8, x, w)
+        dx, dw = ops.linear_grads(_pad8(dy), x, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1])   # [S][N] x [N][K] (weight as stored) | dy^T x
         db = dy.float().sum(0).to(torch.bfloat16) if ctx.has_b and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
@@ -255,8 +251,7 @@ class _HeadFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dyb = dy.to(torch.bfloat16).contiguous()
-        dy8 = _pad8(dyb)
-        return ops.linear_input_grad(dy8, w), ops.linear_weight_grad(dy8, x, w)
+        return ops.linear_grads(_pad8(dyb), x, w)
 
 
 def ops_f32_head(x, w):
