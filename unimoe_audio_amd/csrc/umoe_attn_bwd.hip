@@ -367,12 +367,24 @@ int umoe_attn_bwd_fused(const umoe_attn_bwd_args* a, umoe_stream_t stream) {
     UMOE_HIP(hipMemcpyAsync(kvs, a->kv_start_host, sizeof(int32_t) * a->rows, hipMemcpyHostToDevice, s));
     attn_bwd_d_kernel<<<dim3((unsigned)ceil_div((int)nD, 4)), 256, 0, s>>>(a->d_out, a->out, (long)nD, D);
     UMOE_LAUNCH_CHECK();
+    // the dQ pass and the dK / dV pass are independent (both read Q, K, V, dO, D; disjoint outputs) and each leaves the chip half empty
+    // (784 / 416 workgroups of 64 KiB LDS, causal imbalance): the dQ pass runs on the side stream beside the other, joined below
+    BwdSide& bs = bwd_side();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool overlap = bs.ok && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    hipStream_t sq = s;
+    if (overlap) {
+        UMOE_HIP(hipEventRecord(bs.fork, s));
+        UMOE_HIP(hipStreamWaitEvent(bs.side, bs.fork, 0));
+        sq = bs.side;
+    }
     int rc;
-    if (G <= 1) rc = launch_dq<1>(a, kvs, D, s);
-    else if (G <= 2) rc = launch_dq<2>(a, kvs, D, s);
-    else if (G <= 4) rc = launch_dq<4>(a, kvs, D, s);
-    else rc = launch_dq<8>(a, kvs, D, s);
+    if (G <= 1) rc = launch_dq<1>(a, kvs, D, sq);
+    else if (G <= 2) rc = launch_dq<2>(a, kvs, D, sq);
+    else if (G <= 4) rc = launch_dq<4>(a, kvs, D, sq);
+    else rc = launch_dq<8>(a, kvs, D, sq);
     if (rc) return rc;
+    if (overlap) UMOE_HIP(hipEventRecord(bs.join, bs.side));
     // head split of the dK / dV pass: as many parts as divide the group (up to 4) and fit the workspace behind D and kv_start
     static int psplit = -1;
     if (psplit < 0) {
@@ -411,5 +423,6 @@ int umoe_attn_bwd_fused(const umoe_attn_bwd_args* a, umoe_stream_t stream) {
         attn_bwd_dkv_sum_kernel<<<dim3((unsigned)((per / 8 + 255) / 256)), 256, 0, s>>>(*a, P, slab_k, slab_v);
         UMOE_LAUNCH_CHECK();
     }
+    if (overlap) UMOE_HIP(hipStreamWaitEvent(s, bs.join, 0));
     return 0;
 }

@@ -945,12 +945,7 @@ __global__ __launch_bounds__(256) void gather_slots_kernel(const uint16_t* __res
 // The weight-gradient products are off the dependency chain of a backward pass (nothing in the pass reads dW): they run on a SIDE stream
 // beside the input-gradient chain, forked and joined INSIDE the call (events), so the HBM-bound kernels of the chain (SwiGLU backward, the
 // row gather) and the round tails of the GEMMs overlap with them.  UMOE_BWD_OVERLAP=0: everything on the caller's stream.
-struct BwdSide {
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
-    bool ok = false;
-};
-static BwdSide& bwd_side() {
+BwdSide& bwd_side() {
     static BwdSide b;
     static bool tried = false;
     if (!tried) {

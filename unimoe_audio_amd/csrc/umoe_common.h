@@ -180,6 +180,15 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 #endif
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// side stream + events of the backward composites (umoe_bwd.hip): independent kernels of ONE call run beside each other, forked and joined
+// inside the call (UMOE_BWD_OVERLAP=0: ok == false, everything on the caller's stream)
+struct BwdSide {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, mid = nullptr, join = nullptr;
+    bool ok = false;
+};
+BwdSide& bwd_side();
+
 // ---- expert-parallel peer exchange (umoe_ep.hip; used by the decode engine) -----------------------------------------
 // Region of one rank (uncached device memory, mapped by every peer through HIP IPC):
 //   [flag block: 2 kinds x UMOE_MAX_EP tiles x UMOE_EP_PARTS words, one 64-byte line each][dispatch slab][return slab]
