@@ -437,9 +437,36 @@ class _DCMoETrainFn(torch.autograd.Function):
         dy = torch.empty((rows_total, D), dtype=bf, device=dev)
         y_sh = ybuf[cap:] if n_fix else None
         d_mw, d_gs = ops.combine_bwd(d_out, ybuf, disp["slot_of"], moe_w, y_sh, global_w, n_dyn, n_fix, dy, dy[cap:] if n_fix else None)
+        grads = [None] * len(params)
+        # 6. router: d(moe_w), d(shared weights), d(aux) -> d(logits) -> gate weight and input gradients.  A chain of ten small kernels
+        # (one wave per token, 16-column GEMMs) that only needs step 1: it runs on a side stream beside the expert MLPs' backward (steps
+        # 2.-5., GEMM bound) and is joined in front of step 7 (UMOE_BWD_OVERLAP=0: in program order on the one stream)
+        noise = ctx.noise
+        gate_only = noise is not None and not ctx.jitter_all               # fp32 gate: only the gate's copy was jittered
+        jit = lambda t: _jitter_rows(t, noise)
+        E = n_dyn + n_fix
+
+        def router_chain():
+            d_lg_aux = None
+            if d_aux is not None:
+                d_lg_aux = ops.aux_loss_bwd(logits, ctx.mask0, n_dyn, ctx.tw, d_aux)
+            d_lg = ops.router_bwd(logits, sel, top_k, mask, d_mw, d_gs, d_lg_aux, n_dyn, n_real, n_fix, float(blk.router_jitter_noise),
+                                  token_drop=bool(blk.token_drop), round_factor=ctx.round_factor)
+            dl16 = torch.zeros((S, 16), dtype=bf, device=dev)
+            dl16[:, :E] = d_lg.to(bf)
+            dWgate = torch.empty((16, D), dtype=bf, device=dev)             # dl16^T x: the gate saw the jittered input
+            ops.tiled_gemm_tn([dict(m=16, n=D, k=S)], dl16, jit(x) if gate_only else x, dWgate, k_split=-1)
+            dxr = ops.linear_input_grad(dl16, params[0])                    # [S][16 >= E] x [E][D], the gate weight as stored
+            return dWgate, (jit(dxr) if gate_only else dxr)
+
+        main = torch.cuda.current_stream()
+        side = ops.side_stream(dev, "router") if ops.bwd_overlap() else None
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dWgate, dx_router = router_chain()
         # 2.-5. expert MLP backward (umoe_grouped_swiglu_bwd / umoe_shared_swiglu_bwd): dH = dY Wd, SwiGLU', dX_slots, dWd/dWg/dWu
         dxe = torch.empty((rows_total, D), dtype=bf, device=dev)
-        grads = [None] * len(params)
         if ep > 1:
             dwg, dwu, dwd = _ep_experts_bwd(ctx.ep_state, ex, dy, dxe, disp, ep, n_loc, n_real, S, D, I_d, cap)
             for q in range(n_loc):
@@ -456,25 +483,13 @@ class _DCMoETrainFn(torch.autograd.Function):
             for i in range(n_fix):
                 b0 = 1 + 3 * n_loc + 3 * i
                 grads[b0], grads[b0 + 1], grads[b0 + 2] = dwg[i], dwu[i], dwd[i]
-        Sp = ops._r8(S)
-        # 6. router: d(moe_w), d(shared weights), d(aux) -> d(logits) -> gate weight and input gradients
-        d_lg_aux = None
-        if d_aux is not None:
-            d_lg_aux = ops.aux_loss_bwd(logits, ctx.mask0, n_dyn, ctx.tw, d_aux)
-        d_lg = ops.router_bwd(logits, sel, top_k, mask, d_mw, d_gs, d_lg_aux, n_dyn, n_real, n_fix, float(blk.router_jitter_noise),
-                              token_drop=bool(blk.token_drop), round_factor=ctx.round_factor)
-        E = n_dyn + n_fix
-        dl16 = torch.zeros((S, 16), dtype=bf, device=dev)
-        dl16[:, :E] = d_lg.to(bf)
-        noise = ctx.noise
-        gate_only = noise is not None and not ctx.jitter_all               # fp32 gate: only the gate's copy was jittered
-        jit = lambda t: _jitter_rows(t, noise)
-        dWgate = torch.empty((16, D), dtype=bf, device=dev)                 # dl16^T x: the gate saw the jittered input
-        ops.tiled_gemm_tn([dict(m=16, n=D, k=S)], dl16, jit(x) if gate_only else x, dWgate, k_split=-1)
+        if side is not None:
+            main.wait_stream(side)
+            dWgate.record_stream(main)          # (allocated on the side stream, read on this one from here on)
+            dx_router.record_stream(main)
+        else:
+            dWgate, dx_router = router_chain()
         grads[0] = dWgate[:E]
-        dx_router = ops.linear_input_grad(dl16, params[0])                   # [S][16 >= E] x [E][D], the gate weight as stored
-        if gate_only:
-            dx_router = jit(dx_router)
         # 7. input gradient: slot rows back to tokens + shared experts + router
         dx = ops.permute_bwd(dxe, disp["slot_of"], dxe[cap:] if n_fix else None, n_fix, extra=dx_router)
         if ctx.jitter_all:

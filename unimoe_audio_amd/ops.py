@@ -516,17 +516,29 @@ def linear_weight_grad(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor) -> to
 _SIDE_STREAMS: dict = {}
 
 
+def bwd_overlap() -> bool:
+    """Independent kernels of one backward call run beside each other on side streams (forked and joined inside the call): UMOE_BWD_OVERLAP,
+    default on; the C library reads the same variable for its composites."""
+    import os
+    return os.environ.get("UMOE_BWD_OVERLAP", "1") != "0"
+
+
+def side_stream(device, tag: str = "wgrad"):
+    key = (str(device), tag)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def linear_grads(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx: bool = True, need_dw: bool = True):
     """(dX, dW) of y = x W^T.  Nothing in a backward pass reads dW, so when both are wanted the weight gradient runs on a SIDE stream beside
     the input gradient (fork / join inside this call, like the expert composite in umoe_bwd.hip): the round tails of the two GEMMs and the
     K-split reduction overlap.  UMOE_BWD_OVERLAP=0: both on the current stream."""
-    import os
-    if not (need_dx and need_dw) or os.environ.get("UMOE_BWD_OVERLAP", "1") == "0":
+    if not (need_dx and need_dw) or not bwd_overlap():
         return (linear_input_grad(dy, w) if need_dx else None), (linear_weight_grad(dy, x, w) if need_dw else None)
     main = torch.cuda.current_stream()
-    side = _SIDE_STREAMS.get(dy.device)
-    if side is None:
-        side = _SIDE_STREAMS[dy.device] = torch.cuda.Stream(device=dy.device)
+    side = side_stream(dy.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         dw = linear_weight_grad(dy, x, w)
