@@ -375,7 +375,15 @@ class _DCMoETrainFn(torch.autograd.Function):
         if aux_balance_weight is not None:
             b, t = aux_balance_weight.shape
             tw = aux_balance_weight.reshape(1, b * t).expand(S // (b * t), -1).reshape(-1).to(x.device).float().contiguous()
-        aux = ops.aux_loss(logits, mask, n_dyn, tw)                     # on the mask BEFORE the drop (core.py:293)
+        # aux loss on the mask BEFORE the drop (core.py:293): two small launches nobody in this forward waits for -- beside the expert GEMMs
+        # on the side stream, joined in front of the return
+        aux_side = ops.side_stream(x.device, "router") if ops.bwd_overlap() else None
+        if aux_side is not None:
+            aux_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aux_side):
+                aux = ops.aux_loss(logits, mask, n_dyn, tw)
+        else:
+            aux = ops.aux_loss(logits, mask, n_dyn, tw)
         mask0 = mask
         if blk.token_drop:                                              # core.py:302-329
             td = ops.token_drop(logits, mask, r["routing_weights"], n_dyn=n_dyn, n_real=n_real, n_fix=n_fix,
@@ -409,6 +417,9 @@ class _DCMoETrainFn(torch.autograd.Function):
             ops.tiled_gemm(g_dn, hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16)
         y_sh = ybuf[cap:] if n_fix else None
         out = ops.combine(ybuf, disp["slot_of"], moe_w, y_sh, global_w, None, n_dyn, n_fix)
+        if aux_side is not None:
+            torch.cuda.current_stream().wait_stream(aux_side)
+            aux.record_stream(torch.cuda.current_stream())
         ctx.blk, ctx.dims = blk, (S, D, n_dyn, n_real, n_fix, I_d, I_s, Imax, cap, rows_total)
         ctx.disp, ctx.tw, ctx.noise, ctx.mask0 = disp, tw, noise, mask0
         ctx.round_factor = r.get("round_factor")
