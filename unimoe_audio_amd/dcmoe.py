@@ -355,8 +355,10 @@ class _DCMoETrainFn(torch.autograd.Function):
         I_d, I_s = blk.dynamic_intermediate_size, blk.shared_intermediate_size
         Imax = max(I_d, I_s if n_fix else 0)
         gate_w = params[0]
-        ex = [params[1 + 3 * e: 4 + 3 * e] for e in range(n_real)]
-        sh = [params[1 + 3 * n_real + 3 * i: 4 + 3 * n_real + 3 * i] for i in range(n_fix)]
+        ep = int(blk.dynamic_real_moe.ep_size)
+        E_loc = n_real // ep                     # expert parallel: params carries this rank's experts only
+        ex = [params[1 + 3 * e: 4 + 3 * e] for e in range(E_loc)]
+        sh = [params[1 + 3 * E_loc + 3 * i: 4 + 3 * E_loc + 3 * i] for i in range(n_fix)]
         fp32_gate = bool(blk.training and blk.fp32_gate)
         # input jitter (core.py:243-244): multiplicative uniform noise, drawn with torch's device RNG (a stochastic regulariser: no
         # bit parity with the CPU generator exists; tests inject the samples).  fp32 gate: on the gate's float copy only, multiplied
@@ -365,6 +367,23 @@ class _DCMoETrainFn(torch.autograd.Function):
         ctx.jitter_all = noise is not None and not fp32_gate
         if ctx.jitter_all:
             x = _jitter_rows(x, noise)
+        # buffers of the expert MLPs (the slot capacity is a host bound: S * n_real rows + alignment; what ops.dispatch_build_aligned sizes for)
+        dev = x.device
+        cap0 = ops._r8(S * n_real + n_real * 7)
+        rows_total = cap0 + n_fix * S
+        hbuf = torch.empty((rows_total, Imax), dtype=torch.bfloat16, device=dev)
+        gu = torch.empty((rows_total, 2 * Imax), dtype=torch.bfloat16, device=dev)
+        ybuf = torch.empty((rows_total, D), dtype=torch.bfloat16, device=dev)
+        # the shared experts read x only: their two GEMMs start now, on a side stream, beside the gate / router / dispatch chain (a dozen
+        # latency-bound launches the routed experts have to wait for), and are joined in front of the combine
+        sh_side = ops.side_stream(dev, "shared") if (ops.bwd_overlap() and n_fix and S >= 1024) else None
+        if sh_side is not None:
+            sh_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(sh_side):
+                ops.tiled_gemm([dict(w=sh[i][0], w2=sh[i][1], static_count=S, out_row_base=cap0 + i * S) for i in range(n_fix)], x, hbuf,
+                               max_rows=S, epilogue=ops.EPI_SWIGLU, aux_out=gu)
+                ops.tiled_gemm([dict(w=sh[i][2], static_count=S, a_row_base=cap0 + i * S, out_row_base=cap0 + i * S) for i in range(n_fix)], hbuf, ybuf,
+                               max_rows=S, epilogue=ops.EPI_BF16)
         gmb, ru = blk._mixer_noise(S, x.device)
         r = ops.router_fwd(x, gate_w, n_dyn=n_dyn, n_real=n_real, n_fix=n_fix, top_p=float(blk.mlp_dynamic_top_p),
                            fixed_top_k=int(blk.mlp_dynamic_top_k), jitter_eps=float(blk.router_jitter_noise),
@@ -391,11 +410,7 @@ class _DCMoETrainFn(torch.autograd.Function):
             mask, moe_w, global_w = td["expert_mask"], td["moe_weight"], td["global_weight"]
         disp = ops.dispatch_build_aligned(mask, n_real, 8)
         cap = ops._r8(disp["cap"])                       # routed slot rows [0, cap); shared expert i at cap + i*S
-        rows_total = cap + n_fix * S
-        dev = x.device
-        hbuf = torch.empty((rows_total, Imax), dtype=torch.bfloat16, device=dev)
-        gu = torch.empty((rows_total, 2 * Imax), dtype=torch.bfloat16, device=dev)
-        ybuf = torch.empty((rows_total, D), dtype=torch.bfloat16, device=dev)
+        assert cap == cap0
         ep = int(blk.dynamic_real_moe.ep_size)
         E_loc = n_real // ep
         ctx.ep_state = None
@@ -409,12 +424,14 @@ class _DCMoETrainFn(torch.autograd.Function):
             off, cnt = disp["offsets"][e:e + 1], disp["counts"][e:e + 1]
             g_gu.append(dict(w=ex[e][0], w2=ex[e][1], rows=disp["slot_token"], row_off=off, count=cnt))
             g_dn.append(dict(w=ex[e][2], row_off=off, count=cnt))
-        for i in range(n_fix):
+        for i in range(n_fix if sh_side is None else 0):
             g_gu.append(dict(w=sh[i][0], w2=sh[i][1], static_count=S, out_row_base=cap + i * S))
             g_dn.append(dict(w=sh[i][2], static_count=S, a_row_base=cap + i * S, out_row_base=cap + i * S))
         if g_gu:
             ops.tiled_gemm(g_gu, x, hbuf, max_rows=S, epilogue=ops.EPI_SWIGLU, aux_out=gu)
             ops.tiled_gemm(g_dn, hbuf, ybuf, max_rows=S, epilogue=ops.EPI_BF16)
+        if sh_side is not None:
+            torch.cuda.current_stream().wait_stream(sh_side)
         y_sh = ybuf[cap:] if n_fix else None
         out = ops.combine(ybuf, disp["slot_of"], moe_w, y_sh, global_w, None, n_dyn, n_fix)
         if aux_side is not None:
