@@ -6,9 +6,9 @@ Reference graph: Qwen2_5_VLMoEDecoderLayer.forward utils/UniMoE_Audio_model.py:2
 training loss :817-854; attention / RMSNorm / mRoPE arithmetic = the transformers classes imported at :52-56.
 
 Backward of the contractions: dX = dY W reads the weight as stored (k-major operand of umoe_tiled_gemm, transposing LDS reads) and
-dW = dY^T X runs on the row-major activations themselves (umoe_tiled_gemm_tn, transposing LDS reads; K split chosen by the library).  Attention backward is the
-"unfused" first version: scores are materialised per (row, kv head) group, P is recomputed, every contraction is a tiled
-GEMM (see umoe_bwd.hip).  No CPU fallback: CPU tensors raise.
+dW = dY^T X runs on the row-major activations themselves (umoe_tiled_gemm_tn, transposing LDS reads; K split chosen by the library).  Attention backward: the fused
+flash-style kernels of umoe_attn_bwd.hip (the unfused composite of umoe_bwd.hip for shapes they do not cover).  No CPU fallback: CPU
+tensors raise.
 """
 from __future__ import annotations
 
