@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--ep-emulate", type=int, default=0,
                     help="single GPU only: time ONE rank of an N-rank expert-parallel job in loopback (no peers; a kernel-time proxy, "
                          "reported as a secondary field, never as `value`)")
+    ap.add_argument("--ep-trial", default="", help=argparse.SUPPRESS)      # internal: the sandboxed rehearsal of an exchange backend (see main)
     ap.add_argument("--no-replica-check", action="store_true", help="N > 1, ep: skip the replica leg (secondary number + bit check)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -442,13 +443,48 @@ def main():
     model, t_build = build_model(cfg, device)
     notes = {}
     ep_info = None
+    if args.ep_trial:          # the child of the sandbox above: one short expert-parallel run, exit code = verdict
+        from unimoe_audio_amd.ep import EpLink
+        code = 0
+        try:
+            link = EpLink.from_dist(args.ep_trial, None, device)
+            trial = decode_leg(model, cfg, args, device, rank, B, ep=link, profile=False, steps=4, warmup=2)
+            code = 3 if trial["ep_error"] else 0
+        except Exception as e:
+            print(f"[bench ep-trial] rank {rank}: {e!r}", file=sys.stderr)
+            code = 2
+        dist.barrier()
+        dist.destroy_process_group()
+        raise SystemExit(code)
     if mode == "ep":
         from unimoe_audio_amd.ep import EpLink
         backends = [args.ep_backend] + [b for b in ("peer", "rccl") if b != args.ep_backend and not (b == "rccl" and shared_gpu)]
         for be in backends:
-            # a backend that cannot be set up, or whose exchange times out in a short rehearsal, is skipped by ALL ranks together
+            # a backend that cannot be set up, or whose exchange times out in a short rehearsal, is skipped by ALL ranks together.
+            # The FIRST rehearsal of a backend runs in a child process per rank (a 4-layer model, 4 steps, its own rendezvous port): an
+            # exchange that faults on this node's links (nothing here has crossed a real xGMI link yet) takes down the child, not the run
+            # -- the replicas' number still gets printed
             ok, why = 1, ""
             link = None
+            if not args.ep_trial:
+                import subprocess
+                # (under torchrun the workers are CLIENTS of the agent's store at MASTER_PORT; the children rendezvous on a port of their
+                #  own, so their rank 0 has to serve the store itself)
+                env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29511")) + 101 + backends.index(be)),
+                           TORCHELASTIC_USE_AGENT_STORE="False")
+                try:
+                    rr = subprocess.run([sys.executable, os.path.abspath(__file__), "--ep-trial", be, "--gpus", str(world), "--layers", "4",
+                                         "--batch", str(args.batch), "--prompt", str(args.prompt)], env=env, timeout=300,
+                                        stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+                    if rr.returncode != 0:
+                        ok, why = 0, f"sandboxed rehearsal exited with {rr.returncode}: {rr.stderr.strip().splitlines()[-1][:200] if rr.stderr.strip() else ''}"
+                except subprocess.TimeoutExpired:
+                    ok, why = 0, "sandboxed rehearsal timed out"
+                if -max_over_ranks(-float(ok)) < 1.0:
+                    notes[f"ep_backend_{be}"] = f"not used: {why or 'the sandboxed rehearsal failed on another rank'}"
+                    if rank == 0:
+                        print(f"[bench] expert-parallel backend {be!r} not usable: {why or 'sandboxed rehearsal failed on another rank'}", file=sys.stderr)
+                    continue
             try:
                 link = EpLink.from_dist(be, None, device)
                 trial = decode_leg(model, cfg, args, device, rank, B, ep=link, profile=False, steps=4, warmup=2)
