@@ -156,6 +156,38 @@ def test_tiled_gemm_kmajor_weights_ragged_groups(dev):
         assert bool((out[o + c:o + ((c + 7) & ~7)] == 9.0).all())
 
 
+def test_tiled_gemm_tn_and_kmajor_random_shapes(dev):
+    """Twenty-four seeded random shapes through both k-major kernels (ragged last tiles in every dimension, K tails of every length mod 32,
+    column windows, row windows, K splits) against fp32 references on the device."""
+    from unimoe_audio_amd import ops
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        T = int(rng.integers(1, 700))
+        M = int(rng.integers(1, 80)) * 8
+        N = int(rng.integers(1, 80)) * 8
+        po, qo = int(rng.integers(0, 3)) * 8, int(rng.integers(0, 3)) * 8
+        k0 = int(rng.integers(0, 40))
+        g = torch.Generator().manual_seed(case)
+        P = (torch.randn(k0 + T + 3, po + M + 8, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+        Q = (torch.randn(k0 + T + 3, qo + N + 16, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+        out = torch.full((M, N), 2.0, dtype=torch.bfloat16, device=dev)
+        ks = int(rng.choice([1, 1, 2, 3])) if T >= 64 else 1
+        ops.tiled_gemm_tn([dict(m=M, n=N, p_col_off=po, q_col_off=qo, k_off=k0, k=T)], P, Q, out, k_split=ks)
+        ref = P[k0:k0 + T, po:po + M].float().t() @ Q[k0:k0 + T, qo:qo + N].float()
+        assert (out.float() - ref).abs().max() <= 2 ** -7 * float(ref.abs().max()) + 1e-3, ("tn", case, T, M, N, ks)
+        # Y = A W with the weight's row as the contraction index: S rows, K = T (any length; A zero-padded to a multiple of 8 columns)
+        S = int(rng.integers(1, 600))
+        K8 = (T + 7) & ~7
+        A = torch.zeros(S, K8, dtype=torch.bfloat16)
+        A[:, :T] = (torch.randn(S, T, generator=g) * 0.5).to(torch.bfloat16)
+        W = (torch.randn(T, N, generator=g) * 0.1).to(torch.bfloat16)
+        Ad, Wd = A.to(dev), W.to(dev)
+        y = torch.full((S, N), 4.0, dtype=torch.bfloat16, device=dev)
+        ops.tiled_gemm([dict(w=Wd, w_kmajor=1, static_count=S)], Ad, y, max_rows=S)
+        ref2 = Ad[:, :T].float() @ Wd.float()
+        assert (y.float() - ref2).abs().max() <= 2 ** -7 * float(ref2.abs().max()) + 1e-3, ("kmajor", case, S, T, N)
+
+
 @pytest.mark.parametrize("E,D,I,counts", [(8, 2048, 2752, [2700, 0, 3111, 8, 1, 2999, 4096, 2048]),
                                           (3, 512, 264, [40, 300, 31])])
 def test_tiled_gemm_tn_expert_windows_on_device(dev, E, D, I, counts):
