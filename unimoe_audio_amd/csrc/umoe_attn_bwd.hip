@@ -371,7 +371,11 @@ int umoe_attn_bwd_fused(const umoe_attn_bwd_args* a, umoe_stream_t stream) {
     // (784 / 416 workgroups of 64 KiB LDS, causal imbalance): the dQ pass runs on the side stream beside the other, joined below
     BwdSide& bs = bwd_side();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool overlap = bs.ok && hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    bool overlap = false;
+    if (bs.ok) {
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess) overlap = cap == hipStreamCaptureStatusNone;
+        else (void)hipGetLastError();
+    }
     hipStream_t sq = s;
     if (overlap) {
         UMOE_HIP(hipEventRecord(bs.fork, s));

@@ -1068,7 +1068,11 @@ static int swiglu_bwd_impl(const umoe_swiglu_bwd_args* a, umoe_stream_t stream) 
     // fork: dWd needs only the call's inputs
     BwdSide& bs = bwd_side();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    const bool overlap = bs.ok && hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone;
+    bool overlap = false;
+    if (bs.ok) {
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess) overlap = cap == hipStreamCaptureStatusNone;
+        else (void)hipGetLastError();       // (a stream that cannot be queried: no overlap, and no stale error for the launch checks below)
+    }
     if (overlap) {
         UMOE_HIP(hipEventRecord(bs.fork, (hipStream_t)stream));
         UMOE_HIP(hipStreamWaitEvent(bs.side, bs.fork, 0));
