@@ -280,6 +280,7 @@ typedef struct {
     void* ws; long part_stride;      /* k_split > 1 or < 0: fp32 workspace (umoe_tiled_gemm_tn_workspace_bytes), part_stride = rows * ldo of the output */
 } umoe_tgemm_tn_args;
 size_t umoe_tiled_gemm_tn_workspace_bytes(const umoe_tgemm_tn_args* a);
+int umoe_tiled_gemm_tn_split(const umoe_tgemm_tn_args* a);      /* the K split the call would use (k_split < 0: the library's choice) */
 int umoe_tiled_gemm_tn(const umoe_tgemm_tn_args* a, umoe_stream_t stream);
 
 /* Named wrappers required by the scope table; thin calls of umoe_grouped_gemm.

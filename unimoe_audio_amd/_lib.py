@@ -139,7 +139,7 @@ EXPORTS = [
     "umoe_codec_embed_sum", "umoe_codec_embed_sum_bwd", "umoe_mul_noise", "umoe_codec_head_cfg_sample", "umoe_delay_step", "umoe_rvq_from_codes",
     "umoe_rvq_nearest", "umoe_codec_ce_fwd", "umoe_codec_ce_bwd", "umoe_engine_create", "umoe_engine_destroy", "umoe_engine_set_layer",
     "umoe_engine_set_globals", "umoe_engine_workspace_bytes", "umoe_engine_prefill", "umoe_engine_decode_step",
-    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm", "umoe_tiled_gemm_tn", "umoe_tiled_gemm_tn_workspace_bytes", "umoe_dispatch_build_aligned", "umoe_transpose_slots", "umoe_swiglu_bwd",
+    "umoe_engine_capture", "umoe_engine_replay", "umoe_engine_buffer", "umoe_engine_profile_step", "umoe_prefetch", "umoe_tiled_gemm", "umoe_tiled_gemm_tn", "umoe_tiled_gemm_tn_workspace_bytes", "umoe_tiled_gemm_tn_split", "umoe_dispatch_build_aligned", "umoe_transpose_slots", "umoe_swiglu_bwd",
     "umoe_unpermute_combine_bwd", "umoe_permute_bwd", "umoe_router_bwd", "umoe_rmsnorm_residual_bwd", "umoe_aux_loss_bwd", "umoe_attn_softmax_fwd", "umoe_attn_softmax_bwd", "umoe_qkv_mrope_bwd",
     "umoe_swiglu_bwd_workspace_bytes", "umoe_grouped_swiglu_bwd", "umoe_shared_swiglu_bwd",
     "umoe_attn_prefill_bwd_workspace_bytes", "umoe_attn_prefill_bwd",
@@ -212,6 +212,7 @@ def lib():
         L.umoe_tiled_gemm_tn.argtypes = [C.POINTER(TGemmTnArgs), vp]
         L.umoe_tiled_gemm_tn_workspace_bytes.argtypes = [C.POINTER(TGemmTnArgs)]
         L.umoe_tiled_gemm_tn_workspace_bytes.restype = C.c_size_t
+        L.umoe_tiled_gemm_tn_split.argtypes = [C.POINTER(TGemmTnArgs)]
         L.umoe_swiglu_bwd_workspace_bytes.argtypes = [C.POINTER(SwigluBwdArgs)]
         L.umoe_swiglu_bwd_workspace_bytes.restype = C.c_size_t
         L.umoe_grouped_swiglu_bwd.argtypes = [C.POINTER(SwigluBwdArgs), vp]

@@ -513,6 +513,8 @@ static int tn_effective_split(const umoe_tgemm_tn_args* a) {
         hipDeviceProp_t prop;
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        else (void)hipGetLastError();
+        if (const char* v = getenv("UMOE_FAKE_CUS")) cus = atoi(v);      // (the co-residency guards' override: tests)
         if (cus <= 0) cus = 256;
     }
     const int KT = (kmax + 31) / 32;
@@ -525,6 +527,12 @@ static int tn_effective_split(const umoe_tgemm_tn_args* a) {
         if (t < best_t - 1e-9) { best_t = t; best = ks; }
     }
     return best;
+}
+
+// the K split umoe_tiled_gemm_tn would use for these arguments (host logic only: tests/test_tn_plan_cpu.py pins the model's choices)
+extern "C" int umoe_tiled_gemm_tn_split(const umoe_tgemm_tn_args* a) {
+    if (!a || !a->groups || a->num_groups <= 0 || a->num_groups > TN_MAXG) return -1;
+    return tn_effective_split(a);
 }
 
 extern "C" size_t umoe_tiled_gemm_tn_workspace_bytes(const umoe_tgemm_tn_args* a) {
