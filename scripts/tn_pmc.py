@@ -19,7 +19,10 @@ out = torch.empty(8 * I, D, dtype=torch.bfloat16, device=dev)
 groups = [dict(m=I, n=D, k_off_dev=off[e:e + 1], k_count_dev=cnt[e:e + 1], out_row_base=e * I) for e in range(8)]
 x = (torch.randn(6240, 2048, device=dev) * 0.5).to(torch.bfloat16)
 w = (torch.randn(2560, 2048, device=dev) * 0.02).to(torch.bfloat16)
+dy = (torch.randn(6240, 2560, device=dev) * 0.5).to(torch.bfloat16)
+dx = torch.empty(6240, 2048, dtype=torch.bfloat16, device=dev)
 for _ in range(5):
     ops.tiled_gemm_tn(groups, P, Q, out)
     ops.tlinear(x, w)
+    ops.tiled_gemm([dict(w=w, w_kmajor=1, static_count=6240)], dy, dx, max_rows=6240)      # dX = dY W on the weight as stored
 torch.cuda.synchronize()
