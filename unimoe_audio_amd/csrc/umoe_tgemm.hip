@@ -586,48 +586,37 @@ __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args 
 #else
 #define PP_ST(k)
 #endif
+    // ONE load segment and ONE MFMA segment of 32 per K tile (rounds 1-2: two of 16 with a barrier pair each): half as many barriers per
+    // MFMA, 5-7 % on every shape (scripts/gemm_ab.py).  The fragment reads are waited for IN FRONT of the barrier that ends the load
+    // segment (lgkmcnt(0)): the partner group restages the slot of tile v - 1 in its next load segment, one barrier behind this group's
+    // last read of it, so those reads have to be complete when anybody passes that barrier (WAR with one phase of distance; RAW: the
+    // counted vmcnt in front of the same barrier retires every wave's pieces of tile v + 1, which is read one phase later).
     auto tile_step = [&](const int v, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         const int so = (v % NS) * SLOT;              // ring slot of tile v (read); tile v + AH goes to slot (v + AH) % NS
         const int sn = ((v + AH) % NS) * SLOT;
         const char* Wb = smem + so + wbase;
         const char* Tb = smem + so + tbase;
-        bf16x8_t wf[4], af[4];
-        // ---- phase 2v
+        bf16x8_t wf[4], af[8];
         PP_ST(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Wb + wfo(j)));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + i * 1024));
-        if (STEADY) stage_run(wptr, winc, 0, sn);
-        else stage(wdel, 0, v + AH);
+        for (int i = 0; i < 8; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + i * 1024));
+        if (STEADY) { stage_run(wptr, winc, 0, sn); stage_run(tptr, tinc, UNIT, sn); }
+        else { stage(wdel, 0, v + AH); stage(tdel, UNIT, v + AH); }
         PP_ST(1);
-        __builtin_amdgcn_s_barrier();
-        PP_ST(2);
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
-        PP_ST(3);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 2v + 1
-        PP_ST(4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + (4 + i) * 1024));
-        if (STEADY) stage_run(tptr, tinc, UNIT, sn);
-        else stage(tdel, UNIT, v + AH);
-        PP_ST(5);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");    // all but the AH - 1 newest tiles have landed: tile v + 1 is in
-        PP_ST(6);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        PP_ST(2);
         __builtin_amdgcn_s_barrier();
-        PP_ST(7);
+        PP_ST(3);
         if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][4 + i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
         if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         PP_ST(8);
         __builtin_amdgcn_s_barrier();

@@ -162,41 +162,32 @@ __global__ __launch_bounds__(512, 2) void tgemm_tn_kernel(const umoe_tgemm_tn_ar
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();      // group 1 runs one barrier behind group 0 from here on
+    // ONE load segment and ONE MFMA segment of 32 per K tile (tgemm_pp_kernel: two of 16): half as many barriers per MFMA -- 5-7 % on
+    // every shape of the training step (scripts/gemm_ab.py).  The fragment reads are waited for IN FRONT of the barrier that ends the load
+    // segment (lgkmcnt(0)): the partner group restages the slot of tile v - 1 in its next load segment, one barrier behind this group's
+    // last read of it, so those reads have to be complete when anybody passes that barrier (WAR with one phase of distance; RAW as in
+    // tgemm_pp_kernel: the counted vmcnt in front of the same barrier retires every wave's pieces of tile v + 1, read one phase later).
     auto tile_step = [&](const int v, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         const int so = (v % NS) * SLOT;
         const int sn = ((v + AH) % NS) * SLOT;
         const unsigned Qf = lds0 + so + qbase;
         const unsigned Pf = lds0 + so + pbase;
-        bf16x8_t wf[4], af[4];
-        // ---- phase 2v: Q fragments + first half of the P fragments; stage Q(v + AH)
+        bf16x8_t wf[4], af[8];
         tn_frags<4, 128, 0>(wf, Qf);
-        tn_frags<4, 64, 0>(af, Pf);
-        if (STEADY) stage_run(qptr, qinc, 0, sn);
-        else stage(qdel, qstep, 0, v + AH);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- phase 2v + 1: second half of the P fragments; stage P(v + AH); tile v + 1 has landed after the wait
-        tn_frags<4, 64, 256>(af, Pf);
-        if (STEADY) stage_run(pptr, pinc, UNIT, sn);
-        else stage(pdel, pstep, UNIT, v + AH);
+        tn_frags<4, 64, 0>(*reinterpret_cast<bf16x8_t (*)[4]>(&af[0]), Pf);
+        tn_frags<4, 64, 256>(*reinterpret_cast<bf16x8_t (*)[4]>(&af[4]), Pf);
+        if (STEADY) { stage_run(qptr, qinc, 0, sn); stage_run(pptr, pinc, UNIT, sn); }
+        else { stage(qdel, qstep, 0, v + AH); stage(pdel, pstep, UNIT, v + AH); }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
-        __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][4 + i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     };
@@ -371,39 +362,28 @@ __global__ __launch_bounds__(512, 2) void tgemm_nn_kernel(const umoe_tgemm_args 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();
+    // ONE load segment and ONE MFMA segment of 32 per K tile, as in tgemm_tn_kernel above (same hazard argument)
     auto tile_step = [&](const int v, auto steady_tag) {
         constexpr bool STEADY = decltype(steady_tag)::value;
         const int so = (v % NS) * SLOT;
         const int sn = ((v + AH) % NS) * SLOT;
         const unsigned Wf = lds0 + so + wbase;
         const char* Tb = smem + so + tbase;
-        bf16x8_t wf[4], af[4];
+        bf16x8_t wf[4], af[8];
         tn_frags<4, 128, 0>(wf, Wf);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + i * 1024));
-        if (STEADY) run_w(v + AH, sn);
-        else stage_w(v + AH);
-        __builtin_amdgcn_s_barrier();
+        for (int i = 0; i < 8; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + i * 1024));
+        if (STEADY) { run_w(v + AH, sn); run_t(sn); }
+        else { stage_w(v + AH); stage_t(v + AH); }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Tb + (4 + i) * 1024));
-        if (STEADY) run_t(sn);
-        else stage_t(v + AH);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (AH - 1)) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][4 + i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     };
