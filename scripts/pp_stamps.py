@@ -1,4 +1,4 @@
-"""Diagnostic (not the product path): cycle stamps of one K tile (two phases) of the ping-pong tiled GEMM, workgroup 0,
+"""Diagnostic (not the product path): cycle stamps of one K tile (one load + one MFMA segment) of the ping-pong tiled GEMM, workgroup 0,
 all 8 waves.  Needs the instrumented build (make -C unimoe_audio_amd/csrc tl: -DUMOE_PP_STAMPS)."""
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,7 +28,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 st = aux.view(torch.int64).cpu().reshape(8, 16)
 t0 = int(st[:, 0].min())
-names = ["L0 start", "L0 issued", "after bar1", "M0 issued", "after bar2/L1 start", "L1 issued", "vmcnt(8) done", "after bar3", "M1 issued", "after bar4"]
+# (one load segment + one MFMA segment of 32 per K tile since the end of round 3: stamps 4-7 of the two-phase form are unused and read 0)
+names = ["L start", "L issued", "waits done", "after bar1", "-", "-", "-", "-", "M issued", "after bar2"]
 print("cycles relative to the earliest wave's phase start (shader clock); one row per wave (0-3 group 0, 4-7 group 1)")
 print(" " * 8 + " ".join(f"{n[:12]:>13s}" for n in names))
 for wv in range(8):
