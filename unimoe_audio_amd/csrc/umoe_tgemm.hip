@@ -424,12 +424,12 @@ __device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const 
 //   K runs in tiles of 32 (one MFMA k-step); LDS = ring of NS = 4 tiles x [W unit 256 rows x 64 B | token unit 256 rows x 64 B] =
 //   128 KiB; a unit is staged by all 8 waves (2 global_load_lds_dwordx4 each) and the DMA runs NS - 1 = THREE tiles ahead
 //   (the comments below use NS = 4; NS = 5 is the measured-slower experiment UMOE_TGEMM_RING=5).
-//   phase 2v   : L: read W(v) (4 fragments) + tokens(v) first half (4); stage W(v+3)         | barrier | M: 16 MFMA | barrier
-//   phase 2v+1 : L: read tokens(v) second half (4); stage tokens(v+3); s_waitcnt vmcnt(8)    | barrier | M: 16 MFMA | barrier
-//   RAW: a wave's vmcnt(8) in phase 2v+1 retires ITS pieces of tile v+1 (the 8 newer DMAs are W/tokens of v+2, v+3); the reads
-//        of tile v+1 start in phase 2v+2, behind a barrier that both groups have passed after their waits.
-//   WAR: W(v+3) overwrites W(v-1), last read in phase 2v-2; tokens(v+3) overwrite tokens(v-1), last read in phase 2v-1: two
-//        phases earlier, i.e. also the lagging group has retired those reads (lgkmcnt) before any wave issues the DMA.
+//   tile v: L: read W(v) (4 fragments) + tokens(v) (8); stage W(v+3), tokens(v+3); s_waitcnt vmcnt(8), lgkmcnt(0) | barrier | M: 32 MFMA | barrier
+//   (rounds 1-2: two phases per tile, 16 MFMAs each: twice the barriers per MFMA)
+//   RAW: a wave's vmcnt(8) in front of the barrier that ends L(v) retires ITS pieces of tile v+1 (the 8 newer DMAs are W/tokens of v+2,
+//        v+3); the reads of tile v+1 start in L(v+1), behind a barrier that both groups have passed after their waits.
+//   WAR: the partner group stages tile v+3 into the slot of tile v-1 in ITS L(v), one barrier behind this group's L(v-1) -- whose reads
+//        are complete by then: lgkmcnt(0) stands in front of the barrier that ends every load segment.
 //   Tiles beyond K are staged from the zero block, so the vmcnt arithmetic is the same in every iteration.
 template <int EPI, int PRIO, int NS>
 __global__ __launch_bounds__(512, 2) void tgemm_pp_kernel(const umoe_tgemm_args p, const tg_pack gp, const int epi_lds_mask, const int nx, const int ny, const int nz, const int ragged_order,
