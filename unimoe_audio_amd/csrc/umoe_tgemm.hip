@@ -419,7 +419,7 @@ __device__ __forceinline__ void tg_epilogue_lds(const umoe_tgemm_args& p, const 
 // ------------------------------------------------------------------------------------ 256 x 256 tiles, two wave groups in ping-pong
 // 512 threads = 8 waves as 2 (token halves, wr) x 4 (feature quarters, wc); a wave owns 128 tokens x 64 features = 4 x 8
 // accumulators (128 registers).  Each SIMD carries one wave of each group; the groups run ONE BARRIER APART, so while group 0
-// issues its 16 MFMAs group 1 reads its operands / issues the next LDS-DMA, and vice versa -- the matrix pipe of every SIMD
+// issues its MFMAs group 1 reads its operands / issues the next LDS-DMA, and vice versa -- the matrix pipe of every SIMD
 // always has a wave in its MFMA segment (MI355X_MICROARCH.md, LDS section: one wave per SIMD cannot hide its own ds_reads).
 //   K runs in tiles of 32 (one MFMA k-step); LDS = ring of NS = 4 tiles x [W unit 256 rows x 64 B | token unit 256 rows x 64 B] =
 //   128 KiB; a unit is staged by all 8 waves (2 global_load_lds_dwordx4 each) and the DMA runs NS - 1 = THREE tiles ahead
